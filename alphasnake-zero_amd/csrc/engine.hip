@@ -1,0 +1,821 @@
+// engine.hip -- gfx950 kernels + C ABI for the batched Battlesnake engine.
+//
+// One wavefront (64 lanes) owns one game for the duration of a kernel: the game's HBM record
+// (common.h) is streamed into LDS with 16-byte loads, the rules are evaluated with lanes 0..S-1
+// holding one snake each (cross-snake questions go through wave shuffles / ballots), body
+// occupancy is rebuilt as an LDS byte plane by all 64 lanes, and the record is streamed back.
+// Reference semantics: Game.tic game.py:87-205, Game.make_state game.py:215-257,
+// Game.__init__ game.py:13-61, Game.subgame game.py:266-276 (see the per-kernel comments).
+#include "common.h"
+#include <stdarg.h>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+void snk_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *snk_last_error(void) { return g_err; }
+extern "C" int snk_version(void) { return 100; }
+
+#define WAVES_PER_BLOCK 4
+#define BLOCK_THREADS (WAVES_PER_BLOCK * 64)
+
+template <int NC> struct CellT { using type = uint16_t; };
+template <> struct CellT<121> { using type = uint8_t; };
+template <> struct CellT<49> { using type = uint8_t; };
+
+__device__ static inline bool food_bit(const uint64_t *food, int c) { return (food[c >> 6] >> (c & 63)) & 1ull; }
+
+// per-wave LDS carve-up used by step / observe
+__host__ __device__ static inline int lds_per_wave(const Layout &L) { return L.stride + 4 * L.nc_pad + 64; }
+
+// ------------------------------------------------------------------------------------------
+// Game.tic (game.py:87-205)
+// ------------------------------------------------------------------------------------------
+template <int H, int W>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ state, Layout L,
+                                                       const int32_t *__restrict__ slots, int n,
+                                                       const uint8_t *__restrict__ moves,
+                                                       const int16_t *__restrict__ spawn_tape,
+                                                       uint8_t *__restrict__ done_out,
+                                                       int16_t *__restrict__ spawned_out,
+                                                       uint64_t *__restrict__ empty_out, int health_dec,
+                                                       double chance, uint32_t seed_lo, uint32_t seed_hi)
+{
+    using cell_t = typename CellT<H * W>::type;
+    constexpr int NC = H * W;
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int gi = blockIdx.x * WAVES_PER_BLOCK + wv;
+    const bool valid = gi < n;
+    const int S = L.S, mask = L.cap_mask;
+    uint8_t *g = smem + wv * lds_per_wave(L);
+    uint8_t *occ = g + L.stride;       // 1 = some snake's non-head node sits here (Game.bodies)
+    uint8_t *hd = occ + L.nc_pad;      // 1 = some snake's head sits here (Game.heads, on-board ones)
+    const int slot = valid ? (slots ? slots[gi] : gi) : 0;
+    uint8_t *gsrc = state + (size_t)slot * L.stride;
+
+    if (valid)
+        for (int i = lane; i < L.stride / 16; i += 64) ((uint4 *)g)[i] = ((const uint4 *)gsrc)[i];
+    for (int i = lane * 4; i < 2 * L.nc_pad; i += 256) *(uint32_t *)(occ + i) = 0u;
+    __syncthreads();
+
+    SnakeMeta *meta = (SnakeMeta *)(g + L.meta_off);
+    uint64_t *food = (uint64_t *)(g + L.food_off);
+    uint32_t *cnt = (uint32_t *)(g + L.cnt_off);
+    int8_t *rew = (int8_t *)(g + L.rew_off);
+
+    const bool act = valid && lane < S;
+    SnakeMeta m = {0, 0, 0, 0, 0};
+    if (act) m = meta[lane];
+    const bool alive0 = act && m.alive;
+    const int n_alive0 = __popcll(__ballot(alive0));
+    const bool ended = !valid || n_alive0 <= 1;     // tic already returned the rewards list earlier
+    const bool go = alive0 && !ended;
+    cell_t *ring = (cell_t *)(g + (lane < S ? lane : 0) * L.ring_bytes);
+
+    // ---- execute moves (game.py:90-114; Snake.move game.py:329-358) + health (117-118)
+    int head_cell = -1;
+    bool oob = false;
+    if (go) {
+        const int mv = moves[(size_t)gi * S + lane];
+        const int d = (mv + m.dir + 3) & 3;            // (move + last - 1) % 4
+        m.dir = (uint8_t)d;
+        const int hi = (m.tail + m.len - 1) & mask;
+        const int hc = ring[hi];
+        int y = hc / W, x = hc - y * W;
+        y += (d == 2) - (d == 0);
+        x += (d == 1) - (d == 3);
+        oob = (y < 0) | (y >= H) | (x < 0) | (x >= W);
+        head_cell = oob ? -1 : y * W + x;
+        m.tail = (uint16_t)((m.tail + 1) & mask);      // pop the tail node, push the new head
+        if (!oob) ring[(hi + 1) & mask] = (cell_t)head_cell;
+        m.health = (int16_t)(m.health - health_dec);
+    }
+    // ---- food (game.py:121-127): list order, the first snake on a cell eats; Snake.grow (360-365)
+    const bool hasfood = go && !oob && food_bit(food, head_cell);
+    bool eats = hasfood;
+    for (int o = 0; o < S; ++o) {
+        const int ho = __shfl(head_cell, o, 64);
+        const int fo = __shfl((int)hasfood, o, 64);
+        if (o < lane && fo && ho == head_cell) eats = false;
+    }
+    if (eats) {
+        m.health = 100;
+        const int t = (m.tail - 1) & mask;
+        ring[t] = ring[m.tail];                        // duplicate the tail node
+        m.tail = (uint16_t)t;
+        m.len = (uint16_t)(m.len + 1);
+    }
+    const int n_eat = __popcll(__ballot(eats));
+    for (int o = 0; o < S; ++o) {
+        const int eo = __shfl((int)eats, o, 64);
+        const int co = __shfl(head_cell, o, 64);
+        if (eo && lane == 0) food[co >> 6] &= ~(1ull << (co & 63));
+    }
+    __syncthreads();
+
+    // ---- Game.bodies / Game.heads as LDS byte planes, rebuilt from the rings by all lanes
+    for (int s = 0; s < S; ++s) {
+        const int len_s = __shfl((int)m.len, s, 64);
+        const int tail_s = __shfl((int)m.tail, s, 64);
+        const int go_s = __shfl((int)go, s, 64);
+        if (go_s) {
+            const cell_t *r = (const cell_t *)(g + s * L.ring_bytes);
+            for (int k = lane; k < len_s - 1; k += 64) occ[r[(tail_s + k) & mask]] = 1;
+        }
+    }
+    if (go && !oob) hd[head_cell] = 1;
+    __syncthreads();
+
+    // ---- spawn food (game.py:130-138)
+    int spawn = -1;
+    if (chance > 0.0 && !ended) {
+        int n_food = 0;
+        for (int w = 0; w < L.FW; ++w) n_food += __popcll(food[w]);
+        int n_empty = 0;
+        for (int w = 0; w < L.FW; ++w) {
+            const int c = w * 64 + lane;
+            const bool e = c < NC && !occ[c] && !hd[c] && !food_bit(food, c);
+            const uint64_t mk = __ballot(e);
+            if (empty_out && lane == 0) empty_out[(size_t)gi * L.FW + w] = mk;
+            n_empty += __popcll(mk);
+        }
+        if (spawn_tape) {
+            spawn = spawn_tape[gi];
+        } else {
+            const uint32_t uid = *(const uint32_t *)(g + L.uid_off);
+            uint32_t r[4];
+            philox4x32(uid, cnt[5], 0x5350574Eu /* 'SPWN' */, 0u, seed_lo, seed_hi, r);
+            const double u1 = ((double)r[0] + 0.5) * (1.0 / 4294967296.0);
+            if ((n_food == 0 || u1 <= chance) && n_empty > 0) {
+                int k = (int)(((uint64_t)r[1] * (uint64_t)n_empty) >> 32);   // uniform in [0, n_empty)
+                for (int w = 0; w < L.FW; ++w) {
+                    const int c = w * 64 + lane;
+                    const bool e = c < NC && !occ[c] && !hd[c] && !food_bit(food, c);
+                    const uint64_t mk = __ballot(e);
+                    const int pc = __popcll(mk);
+                    if (spawn < 0) {
+                        if (k < pc) {
+                            const int rank = __popcll(mk & ((1ull << lane) - 1ull));
+                            const uint64_t sel = __ballot(e && rank == k);
+                            spawn = w * 64 + (__ffsll((unsigned long long)sel) - 1);
+                        } else {
+                            k -= pc;
+                        }
+                    }
+                }
+            }
+        }
+    } else if (empty_out && valid && lane == 0) {
+        for (int w = 0; w < L.FW; ++w) empty_out[(size_t)gi * L.FW + w] = 0ull;
+    }
+    if (spawned_out && valid && lane == 0) spawned_out[gi] = (int16_t)spawn;
+
+    // ---- deaths (game.py:144-165, an if/elif chain) and removal (167-192)
+    const bool body_hit = go && !oob && occ[head_cell];
+    bool shared = false, lose = false;
+    for (int o = 0; o < S; ++o) {
+        const int ho = __shfl(head_cell, o, 64);
+        const int lo = __shfl((int)m.len, o, 64);
+        if (o != lane && ho >= 0 && ho == head_cell) {
+            shared = true;
+            if ((int)m.len <= lo) lose = true;
+        }
+    }
+    int cause = -1;
+    if (go) {
+        if (oob) cause = 0;
+        else if (body_hit) cause = 1;
+        else if (shared) { if (lose) cause = 2; }      // a head-on survivor skips the starvation test
+        else if (m.health <= 0) cause = 3;
+    }
+    const bool dead = cause >= 0;
+    const int c0 = __popcll(__ballot(cause == 0)), c1 = __popcll(__ballot(cause == 1));
+    const int c2 = __popcll(__ballot(cause == 2)), c3 = __popcll(__ballot(cause == 3));
+    const int n_alive = __popcll(__ballot(go && !dead));
+    if (!ended) {
+        if (spawn >= 0 && lane == 0) food[spawn >> 6] |= 1ull << (spawn & 63);
+        if (dead) {
+            m.alive = 0; m.len = 0; m.health = 0; m.dir = 0; m.tail = 0;
+            rew[lane] = -1;
+        } else if (go && n_alive == 1) {
+            rew[lane] = 1;                             // game.py:199-202
+        }
+        if (act) meta[lane] = m;
+        if (lane == 0) {
+            cnt[0] += c0; cnt[1] += c1; cnt[2] += c2; cnt[3] += c3;
+            cnt[4] += n_eat; cnt[5] += 1;              // game_length (game.py:197)
+        }
+    }
+    __syncthreads();
+    if (!ended)
+        for (int i = lane; i < L.stride / 16; i += 64) ((uint4 *)gsrc)[i] = ((const uint4 *)g)[i];
+    if (done_out && valid && lane == 0) done_out[gi] = (uint8_t)(ended || n_alive <= 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// Game.__init__ (game.py:13-61)
+// ------------------------------------------------------------------------------------------
+template <int H, int W>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_reset(uint8_t *__restrict__ state, Layout L,
+                                                        const int32_t *__restrict__ slots, int n,
+                                                        const uint8_t *__restrict__ tape, uint32_t uid_base,
+                                                        uint32_t seed_lo, uint32_t seed_hi)
+{
+    using cell_t = typename CellT<H * W>::type;
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int gi = blockIdx.x * WAVES_PER_BLOCK + wv;
+    const bool valid = gi < n;
+    const int S = L.S;
+    uint8_t *g = smem + wv * lds_per_wave(L);
+    for (int i = lane; i < L.stride / 16; i += 64) ((uint4 *)g)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    if (valid && lane == 0) {
+        const int sy[8] = {1, H - 2, H - 2, 1, 1, H / 2, H - 2, H / 2};
+        const int sx[8] = {1, W - 2, 1, W - 2, W / 2, W - 2, W / 2, 1};
+        uint8_t pos[8], dirs[8], fc[8];
+        const uint32_t uid = uid_base + (uint32_t)gi;
+        if (tape) {
+            for (int s = 0; s < S; ++s) {
+                pos[s] = tape[((size_t)gi * 3 + 0) * S + s];
+                dirs[s] = tape[((size_t)gi * 3 + 1) * S + s];
+                fc[s] = tape[((size_t)gi * 3 + 2) * S + s];
+            }
+        } else {
+            uint32_t r[24];
+            for (int q = 0; q < 6; ++q) philox4x32(uid, (uint32_t)q, 0x494E4954u /* 'INIT' */, 0u, seed_lo, seed_hi, r + 4 * q);
+            uint8_t perm[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+            for (int s = 0; s < S; ++s) {          // random.sample(8 start cells, S): ordered S-subset
+                const int j = s + (int)(((uint64_t)r[s] * (uint64_t)(8 - s)) >> 32);
+                const uint8_t t = perm[s]; perm[s] = perm[j]; perm[j] = t;
+                pos[s] = perm[s];
+                dirs[s] = (uint8_t)(r[8 + s] >> 30);
+                fc[s] = (uint8_t)(r[16 + s] >> 30);
+            }
+        }
+        SnakeMeta *meta = (SnakeMeta *)(g + L.meta_off);
+        uint64_t *food = (uint64_t *)(g + L.food_off);
+        const int center = (H / 2) * W + W / 2;
+        food[center >> 6] |= 1ull << (center & 63);
+        for (int s = 0; s < S; ++s) {
+            const int y = sy[pos[s]], x = sx[pos[s]];
+            cell_t *ring = (cell_t *)(g + s * L.ring_bytes);
+            ring[0] = ring[1] = ring[2] = (cell_t)(y * W + x);      // 3 stacked nodes (game.py:37)
+            meta[s].tail = 0; meta[s].len = 3; meta[s].health = 100; meta[s].dir = dirs[s]; meta[s].alive = 1;
+            const int fy = y + ((fc[s] & 2) ? 1 : -1), fx = x + ((fc[s] & 1) ? 1 : -1);
+            const int c = fy * W + fx;
+            food[c >> 6] |= 1ull << (c & 63);
+        }
+        *(uint32_t *)(g + L.uid_off) = uid;
+    }
+    __syncthreads();
+    if (valid) {
+        const int slot = slots ? slots[gi] : gi;
+        uint8_t *gdst = state + (size_t)slot * L.stride;
+        for (int i = lane; i < L.stride / 16; i += 64) ((uint4 *)gdst)[i] = ((const uint4 *)g)[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Game.subgame (game.py:266-276): one wavefront reads a parent once and writes `fanout` copies
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK_THREADS) void k_clone(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                        Layout L, const int32_t *__restrict__ src_slots, int n,
+                                                        const int32_t *__restrict__ dst_slots, int fanout)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int gi = blockIdx.x * WAVES_PER_BLOCK + wv;
+    if (gi >= n) return;
+    const int ss = src_slots ? src_slots[gi] : gi;
+    const uint4 *p = (const uint4 *)(src + (size_t)ss * L.stride);
+    const int nq = L.stride / 16;
+    // the counters (6 x u32 at cnt_off, 8-byte aligned) are zeroed in flight
+    const int c_lo = L.cnt_off, c_hi = L.cnt_off + 24;
+    for (int i = lane; i < nq; i += 64) {
+        uint4 v = p[i];
+        uint32_t *w = (uint32_t *)&v;
+        for (int q = 0; q < 4; ++q) {
+            const int off = i * 16 + q * 4;
+            if (off >= c_lo && off < c_hi) w[q] = 0u;
+        }
+        for (int j = 0; j < fanout; ++j) {
+            const int ds = dst_slots ? dst_slots[(size_t)gi * fanout + j] : gi * fanout + j;
+            ((uint4 *)(dst + (size_t)ds * L.stride))[i] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// alive flags (Game.get_ids, game.py:76-77)
+// ------------------------------------------------------------------------------------------
+__global__ void k_alive(const uint8_t *__restrict__ state, Layout L, const int32_t *__restrict__ slots, int n,
+                        uint8_t *__restrict__ alive_out, int32_t *__restrict__ n_alive_out)
+{
+    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= n) return;
+    const int slot = slots ? slots[gi] : gi;
+    const SnakeMeta *meta = (const SnakeMeta *)(state + (size_t)slot * L.stride + L.meta_off);
+    int c = 0;
+    for (int s = 0; s < L.S; ++s) {
+        const uint8_t a = meta[s].alive;
+        alive_out[(size_t)gi * L.S + s] = a;
+        c += a;
+    }
+    if (n_alive_out) n_alive_out[gi] = c;
+}
+
+__global__ void k_sum_counters(const uint8_t *__restrict__ state, Layout L, const int32_t *__restrict__ slots, int n,
+                               unsigned long long *__restrict__ out6)
+{
+    unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int gi = blockIdx.x * blockDim.x + threadIdx.x; gi < n; gi += gridDim.x * blockDim.x) {
+        const int slot = slots ? slots[gi] : gi;
+        const uint32_t *c = (const uint32_t *)(state + (size_t)slot * L.stride + L.cnt_off);
+        for (int q = 0; q < 6; ++q) acc[q] += c[q];
+    }
+    for (int q = 0; q < 6; ++q) {
+        const unsigned long long s = wave_sum_u64(acc[q]);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&out6[q], s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Game.make_state (game.py:215-257) + obstacle test (alpha_nnet.py:63-76) + observation key
+// One wavefront per (slot, snake) pair.
+// ------------------------------------------------------------------------------------------
+template <int H, int W>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_observe(const uint8_t *__restrict__ state, Layout L,
+                                                          const int32_t *__restrict__ pairs, int m, int layout,
+                                                          float *__restrict__ planes, uint8_t *__restrict__ mask_out,
+                                                          uint64_t *__restrict__ key_out, int legacy_mask)
+{
+    using cell_t = typename CellT<H * W>::type;
+    constexpr int NC = H * W, N = 2 * H - 1, NPIX = N * N, NEL = NPIX * 3;
+    static_assert(H == W, "only square boards batch (rot90 transposes odd-k shapes)");
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int pi = blockIdx.x * WAVES_PER_BLOCK + wv;
+    const bool valid = pi < m;
+    const int S = L.S, mask = L.cap_mask;
+    uint8_t *g = smem + wv * lds_per_wave(L);
+    uint16_t *ttl = (uint16_t *)(g + L.stride);             // max tail-distance of any node on the cell
+    uint8_t *hidx = (uint8_t *)(g + L.stride + 2 * L.nc_pad);  // 1 + id of the snake whose head is here
+    float *hval = (float *)(g + L.stride + 4 * L.nc_pad);   // channel-0 value per snake id (8 floats)
+
+    const int slot = valid ? pairs[2 * pi] : 0;
+    const int you = valid ? pairs[2 * pi + 1] : 0;
+    const uint8_t *gsrc = state + (size_t)slot * L.stride;
+    if (valid)
+        for (int i = lane; i < L.stride / 16; i += 64) ((uint4 *)g)[i] = ((const uint4 *)gsrc)[i];
+    for (int i = lane * 4; i < 4 * L.nc_pad; i += 256) *(uint32_t *)((uint8_t *)ttl + i) = 0u;
+    __syncthreads();
+
+    const SnakeMeta *meta = (const SnakeMeta *)(g + L.meta_off);
+    const uint64_t *food = (const uint64_t *)(g + L.food_off);
+    const SnakeMeta me = meta[you];
+    const bool live = valid && me.alive;
+
+    // body plane: walking tail -> head with dist 1,2,... the last write wins (game.py:236-241);
+    // only the node nearest the head of a run of stacked nodes writes, so there is no race.
+    for (int s = 0; s < S; ++s) {
+        if (!valid) break;                               // an idle wave holds no record: touch nothing
+        const SnakeMeta ms = meta[s];
+        if (!ms.alive) continue;
+        const cell_t *r = (const cell_t *)(g + s * L.ring_bytes);
+        for (int k = lane; k < ms.len; k += 64) {
+            const int c = r[(ms.tail + k) & mask];
+            const bool last = (k == ms.len - 1) || (r[(ms.tail + k + 1) & mask] != c);
+            if (last) ttl[c] = (uint16_t)(k + 1);
+            if (k == ms.len - 1) hidx[c] = (uint8_t)(s + 1);
+        }
+        if (lane == 0)   // (snake.length - (you.length - 0.5)) * 0.04 in float64, then float32 (game.py:229-232,257)
+            hval[s] = (float)(((double)ms.len - ((double)me.len - 0.5)) * 0.04);
+    }
+    __syncthreads();
+
+    const int my_head = (int)((const cell_t *)(g + you * L.ring_bytes))[(me.tail + me.len - 1) & mask];
+    const int hy = my_head / W, hx = my_head - hy * W;
+    const int k = me.dir & 3;
+    const float fval = (float)((double)(101 - (int)me.health) * 0.01);   // game.py:243-244
+
+    // value of board cell c, channel ch, exactly as make_state writes it
+    auto cell_val = [&](int c, int ch) -> float {
+        if (c == my_head) return -1.0f;                                   // game.py:248
+        if (ch == 0) { const int h = hidx[c]; return h ? hval[h - 1] : 0.0f; }
+        if (ch == 1) { const int t = ttl[c]; return t ? (float)((double)t * 0.02) : 0.0f; }
+        return food_bit(food, c) ? fval : 0.0f;
+    };
+
+    if (planes) {
+        float *out = planes + (size_t)pi * NEL;
+        if (!live) {
+            if (valid) for (int e = lane; e < NEL; e += 64) out[e] = 0.0f;
+        } else {
+            for (int e = lane; e < NEL; e += 64) {
+                int p, ch;
+                if (layout == SNK_NHWC_F32) { p = e / 3; ch = e - 3 * p; }
+                else { ch = e / NPIX; p = e - ch * NPIX; }
+                const int i = p / N, j = p - i * N;
+                int si, sj;                              // numpy.rot90(grid, k): out[i][j] = grid[si][sj]
+                if (k == 0) { si = i; sj = j; }
+                else if (k == 1) { si = j; sj = N - 1 - i; }
+                else if (k == 2) { si = N - 1 - i; sj = N - 1 - j; }
+                else { si = N - 1 - j; sj = i; }
+                const int y = si - (H - 1) + hy, x = sj - (W - 1) + hx;
+                float v;
+                if (y < 0 || y >= H || x < 0 || x >= W) v = (ch == 1) ? 1.0f : 0.0f;   // WALL (game.py:4,219)
+                else v = cell_val(y * W + x, ch);
+                out[e] = v;
+            }
+        }
+    }
+    if (mask_out && valid && lane < 3) {
+        uint8_t b = 1;
+        if (live) {
+            const int ad = (k + 3 + lane) & 3;           // left / straight / right of the heading
+            const int y = hy + (ad == 2) - (ad == 0), x = hx + (ad == 1) - (ad == 3);
+            float v = 1.0f;
+            if (y >= 0 && y < H && x >= 0 && x < W) v = cell_val(y * W + x, 1);
+            b = legacy_mask ? ((double)v >= 0.04) : (v >= 0.04f);          // alpha_nnet.py:75-76
+        }
+        mask_out[(size_t)pi * 3 + lane] = b;
+    }
+    if (key_out) {
+        uint64_t lo = 0, hi = 0;
+        if (live) {
+            for (int c = lane; c < NC; c += 64) {
+                const uint32_t b0 = __float_as_uint(cell_val(c, 0)), b1 = __float_as_uint(cell_val(c, 1)),
+                               b2 = __float_as_uint(cell_val(c, 2));
+                if (b0 == 0u && b1 == 0x3F800000u && b2 == 0u) continue;   // indistinguishable from a wall
+                const int y = c / W, x = c - y * W;
+                const int si = y - hy + (H - 1), sj = x - hx + (W - 1);
+                int i, j;                                // inverse of the rot90 map above
+                if (k == 0) { i = si; j = sj; }
+                else if (k == 1) { i = N - 1 - sj; j = si; }
+                else if (k == 2) { i = N - 1 - si; j = N - 1 - sj; }
+                else { i = sj; j = N - 1 - si; }
+                const uint64_t p = (uint64_t)(i * N + j);
+                uint64_t xk = sm64((p << 32) | b0);
+                xk = sm64(xk ^ (((uint64_t)b1 << 32) | b2));
+                lo += xk;
+                hi += sm64(xk ^ 0xD6E8FEB86659FD93ull);
+            }
+        }
+        lo = wave_sum_u64(lo);
+        hi = wave_sum_u64(hi);
+        if (valid && lane == 0) { key_out[2 * (size_t)pi] = lo; key_out[2 * (size_t)pi + 1] = hi; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// deterministic stream compaction: indices of non-zero flags, ascending
+// ------------------------------------------------------------------------------------------
+#define CMP_THREADS 256
+#define CMP_ITEMS 8
+#define CMP_TILE (CMP_THREADS * CMP_ITEMS)
+
+__device__ static inline int block_exclusive_scan_256(int v, int *total, int *sh /* >= 8 ints */)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) sh[wv] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; ++w) base += sh[w];
+    *total = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(CMP_THREADS) void k_cmp_count(const uint8_t *__restrict__ flags, int n, int32_t *__restrict__ tile_sums)
+{
+    __shared__ int sh[8];
+    const int base = blockIdx.x * CMP_TILE + threadIdx.x * CMP_ITEMS;
+    int c = 0;
+    for (int q = 0; q < CMP_ITEMS; ++q) { const int i = base + q; if (i < n && flags[i]) ++c; }
+    int total;
+    block_exclusive_scan_256(c, &total, sh);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of tile sums (any count, processed 256 at a time)
+__global__ __launch_bounds__(CMP_THREADS) void k_cmp_scan(int32_t *__restrict__ tile_sums, int n_tiles, int32_t *__restrict__ count)
+{
+    __shared__ int sh[8];
+    int carry = 0;
+    for (int b = 0; b < n_tiles; b += CMP_THREADS) {
+        const int i = b + threadIdx.x;
+        const int v = i < n_tiles ? tile_sums[i] : 0;
+        int total;
+        const int ex = block_exclusive_scan_256(v, &total, sh);
+        if (i < n_tiles) tile_sums[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *count = carry;
+}
+
+__global__ __launch_bounds__(CMP_THREADS) void k_cmp_scatter(const uint8_t *__restrict__ flags, int n, const int32_t *__restrict__ tile_offs,
+                                                             int32_t *__restrict__ out)
+{
+    __shared__ int sh[8];
+    const int base = blockIdx.x * CMP_TILE + threadIdx.x * CMP_ITEMS;
+    int c = 0;
+    uint8_t f[CMP_ITEMS];
+    for (int q = 0; q < CMP_ITEMS; ++q) { const int i = base + q; f[q] = (i < n) ? flags[i] : 0; if (f[q]) ++c; }
+    int total;
+    int pos = tile_offs[blockIdx.x] + block_exclusive_scan_256(c, &total, sh);
+    for (int q = 0; q < CMP_ITEMS; ++q) if (f[q]) out[pos++] = base + q;
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+static bool supported_board(int H, int W) { return (H == 11 && W == 11) || (H == 7 && W == 7) || (H == 19 && W == 19); }
+
+#define DISPATCH_BOARD(L, CALL)                                         \
+    do {                                                                \
+        if ((L).H == 11) { constexpr int BH = 11, BW = 11; CALL; }      \
+        else if ((L).H == 7) { constexpr int BH = 7, BW = 7; CALL; }    \
+        else { constexpr int BH = 19, BW = 19; CALL; }                  \
+    } while (0)
+
+extern "C" int snk_engine_create(snk_engine **out, int n_slots, int H, int W, int S, int health_dec,
+                                 double food_spawn_chance, uint64_t seed, int device)
+{
+    SNK_REQUIRE(out != nullptr, "snk_engine_create: out is NULL");
+    SNK_REQUIRE(supported_board(H, W), "snk_engine_create: unsupported board %dx%d (11x11, 7x7, 19x19)", H, W);
+    SNK_REQUIRE(S >= 2 && S <= SNK_MAX_SNAKES, "snk_engine_create: snake count %d outside 2..8", S);
+    SNK_REQUIRE(n_slots > 0, "snk_engine_create: n_slots must be positive");
+    SNK_CHECK_HIP(hipSetDevice(device));
+    snk_engine *e = new snk_engine();
+    e->L = make_layout(H, W, S);
+    e->n_slots = n_slots;
+    e->health_dec = health_dec;
+    e->food_chance = food_spawn_chance;
+    e->seed = seed;
+    e->next_uid = 1;
+    e->device = device;
+    e->d_state = nullptr;
+    e->d_scratch64 = nullptr;
+    hipError_t err = hipMalloc((void **)&e->d_state, (size_t)n_slots * e->L.stride);
+    if (err == hipSuccess) err = hipMalloc((void **)&e->d_scratch64, 8 * sizeof(unsigned long long));
+    if (err == hipSuccess) err = hipMemset(e->d_state, 0, (size_t)n_slots * e->L.stride);
+    if (err != hipSuccess) {
+        snk_set_error("snk_engine_create: device allocation of %zu bytes failed: %s", (size_t)n_slots * e->L.stride, hipGetErrorString(err));
+        if (e->d_state) (void)hipFree(e->d_state);
+        if (e->d_scratch64) (void)hipFree(e->d_scratch64);
+        delete e;
+        return -2;
+    }
+    *out = e;
+    return 0;
+}
+
+extern "C" int snk_engine_destroy(snk_engine *e)
+{
+    if (!e) return 0;
+    (void)hipFree(e->d_state);
+    (void)hipFree(e->d_scratch64);
+    delete e;
+    return 0;
+}
+
+extern "C" int snk_engine_info(const snk_engine *e, int *n_slots, int *H, int *W, int *S, int *slot_bytes)
+{
+    SNK_REQUIRE(e != nullptr, "snk_engine_info: engine is NULL");
+    if (n_slots) *n_slots = e->n_slots;
+    if (H) *H = e->L.H;
+    if (W) *W = e->L.W;
+    if (S) *S = e->L.S;
+    if (slot_bytes) *slot_bytes = e->L.stride;
+    return 0;
+}
+
+extern "C" int snk_engine_raw(const snk_engine *e, void **d_base, int *slot_bytes)
+{
+    SNK_REQUIRE(e != nullptr, "snk_engine_raw: engine is NULL");
+    if (d_base) *d_base = e->d_state;
+    if (slot_bytes) *slot_bytes = e->L.stride;
+    return 0;
+}
+
+extern "C" int snk_engine_set_params(snk_engine *e, int health_dec, double food_spawn_chance)
+{
+    SNK_REQUIRE(e != nullptr, "snk_engine_set_params: engine is NULL");
+    e->health_dec = health_dec;
+    e->food_chance = food_spawn_chance;
+    return 0;
+}
+
+static inline int wave_grid(int n) { return (n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK; }
+
+extern "C" int snk_engine_reset(snk_engine *e, const int32_t *d_slots, int n, const uint8_t *d_init_tape, void *stream)
+{
+    SNK_REQUIRE(e != nullptr, "snk_engine_reset: engine is NULL");
+    SNK_REQUIRE(n >= 0 && (d_slots || n <= e->n_slots), "snk_engine_reset: n=%d exceeds %d slots", n, e->n_slots);
+    if (n == 0) return 0;
+    const Layout L = e->L;
+    const size_t lds = (size_t)WAVES_PER_BLOCK * lds_per_wave(L);
+    const uint32_t uid_base = e->next_uid;
+    e->next_uid += (uint32_t)n;
+    DISPATCH_BOARD(L, (k_reset<BH, BW><<<wave_grid(n), BLOCK_THREADS, lds, (hipStream_t)stream>>>(
+        e->d_state, L, d_slots, n, d_init_tape, uid_base, (uint32_t)e->seed, (uint32_t)(e->seed >> 32))));
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int snk_engine_clone(const snk_engine *src, const int32_t *d_src_slots, int n, snk_engine *dst,
+                                const int32_t *d_dst_slots, int fanout, void *stream)
+{
+    SNK_REQUIRE(src && dst, "snk_engine_clone: engine is NULL");
+    SNK_REQUIRE(src->L.H == dst->L.H && src->L.W == dst->L.W && src->L.S == dst->L.S, "snk_engine_clone: geometry mismatch");
+    SNK_REQUIRE(fanout >= 1, "snk_engine_clone: fanout must be >= 1");
+    SNK_REQUIRE(n >= 0 && (d_src_slots || n <= src->n_slots), "snk_engine_clone: n=%d exceeds the source's %d slots", n, src->n_slots);
+    SNK_REQUIRE(d_dst_slots || (long long)n * fanout <= dst->n_slots, "snk_engine_clone: %lld copies exceed the destination's %d slots",
+                (long long)n * fanout, dst->n_slots);
+    if (n == 0) return 0;
+    k_clone<<<wave_grid(n), BLOCK_THREADS, 0, (hipStream_t)stream>>>(src->d_state, dst->d_state, src->L, d_src_slots, n, d_dst_slots, fanout);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int snk_engine_step(snk_engine *e, const int32_t *d_slots, int n, const uint8_t *d_moves,
+                               const int16_t *d_spawn_tape, uint8_t *d_done, int16_t *d_spawned,
+                               uint64_t *d_empty, void *stream)
+{
+    SNK_REQUIRE(e != nullptr, "snk_engine_step: engine is NULL");
+    SNK_REQUIRE(d_moves != nullptr, "snk_engine_step: d_moves is NULL");
+    SNK_REQUIRE(n >= 0 && (d_slots || n <= e->n_slots), "snk_engine_step: n=%d exceeds %d slots", n, e->n_slots);
+    if (n == 0) return 0;
+    const Layout L = e->L;
+    const size_t lds = (size_t)WAVES_PER_BLOCK * lds_per_wave(L);
+    DISPATCH_BOARD(L, (k_step<BH, BW><<<wave_grid(n), BLOCK_THREADS, lds, (hipStream_t)stream>>>(
+        e->d_state, L, d_slots, n, d_moves, d_spawn_tape, d_done, d_spawned, d_empty, e->health_dec,
+        e->food_chance, (uint32_t)e->seed, (uint32_t)(e->seed >> 32))));
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int snk_engine_alive(const snk_engine *e, const int32_t *d_slots, int n, uint8_t *d_alive,
+                                int32_t *d_n_alive, void *stream)
+{
+    SNK_REQUIRE(e != nullptr && d_alive != nullptr, "snk_engine_alive: NULL argument");
+    SNK_REQUIRE(n >= 0 && (d_slots || n <= e->n_slots), "snk_engine_alive: n=%d exceeds %d slots", n, e->n_slots);
+    if (n == 0) return 0;
+    k_alive<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(e->d_state, e->L, d_slots, n, d_alive, d_n_alive);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int snk_engine_observe(const snk_engine *e, const int32_t *d_pairs, int m, int layout,
+                                  float *d_planes, uint8_t *d_mask, uint64_t *d_key, int legacy_mask, void *stream)
+{
+    SNK_REQUIRE(e != nullptr && d_pairs != nullptr, "snk_engine_observe: NULL argument");
+    SNK_REQUIRE(layout == SNK_NHWC_F32 || layout == SNK_NCHW_F32, "snk_engine_observe: unknown layout %d", layout);
+    if (m <= 0) return 0;
+    const Layout L = e->L;
+    const size_t lds = (size_t)WAVES_PER_BLOCK * lds_per_wave(L);
+    DISPATCH_BOARD(L, (k_observe<BH, BW><<<wave_grid(m), BLOCK_THREADS, lds, (hipStream_t)stream>>>(
+        e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask)));
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- host views --------------------------------------------------------------------------
+static void raw_to_canonical(const Layout &L, const uint8_t *raw, snk_game_state *o)
+{
+    memset(o, 0, sizeof(*o));
+    o->H = L.H; o->W = L.W; o->S = L.S;
+    o->uid = *(const uint32_t *)(raw + L.uid_off);
+    const SnakeMeta *meta = (const SnakeMeta *)(raw + L.meta_off);
+    const uint64_t *food = (const uint64_t *)(raw + L.food_off);
+    const uint32_t *cnt = (const uint32_t *)(raw + L.cnt_off);
+    const int8_t *rew = (const int8_t *)(raw + L.rew_off);
+    for (int s = 0; s < SNK_MAX_SNAKES; ++s)
+        for (int k = 0; k < SNK_MAX_NODES; ++k) o->nodes[s][k] = -1;
+    for (int s = 0; s < L.S; ++s) {
+        o->alive[s] = meta[s].alive;
+        o->rewards[s] = rew[s];
+        if (!meta[s].alive) continue;
+        o->health[s] = meta[s].health;
+        o->length[s] = (int16_t)meta[s].len;
+        o->dir[s] = meta[s].dir;
+        for (int k = 0; k < meta[s].len && k < SNK_MAX_NODES; ++k) {
+            const int idx = (meta[s].tail + meta[s].len - 1 - k) & L.cap_mask;      // head first
+            const uint8_t *r = raw + s * L.ring_bytes;
+            o->nodes[s][k] = (L.cell_bytes == 1) ? (int16_t)r[idx] : (int16_t)((const uint16_t *)r)[idx];
+        }
+    }
+    for (int c = 0; c < L.NC; ++c) o->food[c] = (uint8_t)((food[c >> 6] >> (c & 63)) & 1ull);
+    for (int q = 0; q < 6; ++q) o->counters[q] = (int32_t)cnt[q];
+}
+
+static int canonical_to_raw(const Layout &L, const snk_game_state *in, uint8_t *raw)
+{
+    memset(raw, 0, (size_t)L.stride);
+    if (in->H != L.H || in->W != L.W || in->S != L.S) return -1;
+    SnakeMeta *meta = (SnakeMeta *)(raw + L.meta_off);
+    uint64_t *food = (uint64_t *)(raw + L.food_off);
+    uint32_t *cnt = (uint32_t *)(raw + L.cnt_off);
+    int8_t *rew = (int8_t *)(raw + L.rew_off);
+    *(uint32_t *)(raw + L.uid_off) = in->uid;
+    for (int s = 0; s < L.S; ++s) {
+        rew[s] = in->rewards[s];
+        if (!in->alive[s]) continue;
+        const int len = in->length[s];
+        if (len < 1 || len > L.cap || len > SNK_MAX_NODES) return -2;
+        meta[s].alive = 1; meta[s].tail = 0; meta[s].len = (uint16_t)len;
+        meta[s].health = in->health[s]; meta[s].dir = in->dir[s];
+        uint8_t *r = raw + s * L.ring_bytes;
+        for (int k = 0; k < len; ++k) {
+            const int cell = in->nodes[s][len - 1 - k];                          // ring index k counts from the tail
+            if (cell < 0 || cell >= L.NC) return -3;
+            if (L.cell_bytes == 1) r[k] = (uint8_t)cell; else ((uint16_t *)r)[k] = (uint16_t)cell;
+        }
+    }
+    for (int c = 0; c < L.NC; ++c) if (in->food[c]) food[c >> 6] |= 1ull << (c & 63);
+    for (int q = 0; q < 6; ++q) cnt[q] = (uint32_t)in->counters[q];
+    return 0;
+}
+
+extern "C" int snk_engine_export_sync(const snk_engine *e, const int32_t *h_slots, int n, snk_game_state *h_out)
+{
+    SNK_REQUIRE(e != nullptr && h_out != nullptr, "snk_engine_export_sync: NULL argument");
+    SNK_REQUIRE(n >= 0 && (h_slots || n <= e->n_slots), "snk_engine_export_sync: n=%d exceeds %d slots", n, e->n_slots);
+    const Layout &L = e->L;
+    SNK_CHECK_HIP(hipDeviceSynchronize());
+    std::vector<uint8_t> raw((size_t)L.stride);
+    if (!h_slots) {
+        std::vector<uint8_t> all((size_t)n * L.stride);
+        if (n) SNK_CHECK_HIP(hipMemcpy(all.data(), e->d_state, all.size(), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) raw_to_canonical(L, all.data() + (size_t)i * L.stride, &h_out[i]);
+        return 0;
+    }
+    for (int i = 0; i < n; ++i) {
+        SNK_REQUIRE(h_slots[i] >= 0 && h_slots[i] < e->n_slots, "snk_engine_export_sync: slot %d out of range", h_slots[i]);
+        SNK_CHECK_HIP(hipMemcpy(raw.data(), e->d_state + (size_t)h_slots[i] * L.stride, (size_t)L.stride, hipMemcpyDeviceToHost));
+        raw_to_canonical(L, raw.data(), &h_out[i]);
+    }
+    return 0;
+}
+
+extern "C" int snk_engine_import_sync(snk_engine *e, const int32_t *h_slots, int n, const snk_game_state *h_in)
+{
+    SNK_REQUIRE(e != nullptr && h_in != nullptr, "snk_engine_import_sync: NULL argument");
+    SNK_REQUIRE(n >= 0 && (h_slots || n <= e->n_slots), "snk_engine_import_sync: n=%d exceeds %d slots", n, e->n_slots);
+    const Layout &L = e->L;
+    SNK_CHECK_HIP(hipDeviceSynchronize());
+    std::vector<uint8_t> raw((size_t)L.stride);
+    for (int i = 0; i < n; ++i) {
+        const int slot = h_slots ? h_slots[i] : i;
+        SNK_REQUIRE(slot >= 0 && slot < e->n_slots, "snk_engine_import_sync: slot %d out of range", slot);
+        const int rc = canonical_to_raw(L, &h_in[i], raw.data());
+        SNK_REQUIRE(rc == 0, "snk_engine_import_sync: game %d is malformed (code %d)", i, rc);
+        SNK_CHECK_HIP(hipMemcpy(e->d_state + (size_t)slot * L.stride, raw.data(), (size_t)L.stride, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+extern "C" int snk_engine_sum_counters_sync(const snk_engine *e, const int32_t *d_slots, int n, int64_t *h_out)
+{
+    SNK_REQUIRE(e != nullptr && h_out != nullptr, "snk_engine_sum_counters_sync: NULL argument");
+    SNK_REQUIRE(n >= 0 && (d_slots || n <= e->n_slots), "snk_engine_sum_counters_sync: n=%d exceeds %d slots", n, e->n_slots);
+    SNK_CHECK_HIP(hipMemset(e->d_scratch64, 0, 8 * sizeof(unsigned long long)));
+    if (n > 0) {
+        int blocks = (n + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
+        k_sum_counters<<<blocks, 256>>>(e->d_state, e->L, d_slots, n, e->d_scratch64);
+        SNK_CHECK_HIP(hipGetLastError());
+    }
+    unsigned long long tmp[6];
+    SNK_CHECK_HIP(hipMemcpy(tmp, e->d_scratch64, sizeof(tmp), hipMemcpyDeviceToHost));
+    for (int q = 0; q < 6; ++q) h_out[q] = (int64_t)tmp[q];
+    return 0;
+}
+
+extern "C" int snk_compact_scratch_elems(int n) { return (n + CMP_TILE - 1) / CMP_TILE + 1; }
+
+extern "C" int snk_compact_flags(const uint8_t *d_flags, int n, int32_t *d_out, int32_t *d_count,
+                                 int32_t *d_scratch, void *stream)
+{
+    SNK_REQUIRE(d_flags && d_out && d_count && d_scratch, "snk_compact_flags: NULL argument");
+    SNK_REQUIRE(n >= 0, "snk_compact_flags: negative n");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) { SNK_CHECK_HIP(hipMemsetAsync(d_count, 0, sizeof(int32_t), st)); return 0; }
+    const int tiles = (n + CMP_TILE - 1) / CMP_TILE;
+    k_cmp_count<<<tiles, CMP_THREADS, 0, st>>>(d_flags, n, d_scratch);
+    k_cmp_scan<<<1, CMP_THREADS, 0, st>>>(d_scratch, tiles, d_count);
+    k_cmp_scatter<<<tiles, CMP_THREADS, 0, st>>>(d_flags, n, d_scratch, d_out);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,88 @@
+"""ctypes loader + prototypes for libsnake_engine.so (include/snake_engine.h)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsnake_engine.so")
+
+MAX_SNAKES, MAX_CELLS, MAX_NODES = 8, 361, 384
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class SnkGameState(C.Structure):
+    """mirror of snk_game_state"""
+    _fields_ = [
+        ("H", C.c_int32), ("W", C.c_int32), ("S", C.c_int32), ("uid", C.c_uint32),
+        ("alive", C.c_uint8 * MAX_SNAKES),
+        ("health", C.c_int16 * MAX_SNAKES),
+        ("length", C.c_int16 * MAX_SNAKES),
+        ("dir", C.c_uint8 * MAX_SNAKES),
+        ("nodes", (C.c_int16 * MAX_NODES) * MAX_SNAKES),
+        ("food", C.c_uint8 * MAX_CELLS),
+        ("rewards", C.c_int8 * MAX_SNAKES),
+        ("counters", C.c_int32 * 6),
+    ]
+
+
+_lib = None
+vp, i32, u64, f64 = C.c_void_p, C.c_int, C.c_uint64, C.c_double
+
+# name -> (restype, argtypes); every symbol include/snake_engine.h declares
+PROTOTYPES = {
+    "snk_last_error": (C.c_char_p, []),
+    "snk_version": (i32, []),
+    "snk_engine_create": (i32, [C.POINTER(vp), i32, i32, i32, i32, i32, f64, u64, i32]),
+    "snk_engine_destroy": (i32, [vp]),
+    "snk_engine_info": (i32, [vp] + [C.POINTER(i32)] * 5),
+    "snk_engine_raw": (i32, [vp, C.POINTER(vp), C.POINTER(i32)]),
+    "snk_engine_set_params": (i32, [vp, i32, f64]),
+    "snk_engine_reset": (i32, [vp, vp, i32, vp, vp]),
+    "snk_engine_clone": (i32, [vp, vp, i32, vp, vp, i32, vp]),
+    "snk_engine_step": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp]),
+    "snk_engine_alive": (i32, [vp, vp, i32, vp, vp, vp]),
+    "snk_engine_observe": (i32, [vp, vp, i32, i32, vp, vp, vp, i32, vp]),
+    "snk_engine_export_sync": (i32, [vp, vp, i32, vp]),
+    "snk_engine_import_sync": (i32, [vp, vp, i32, vp]),
+    "snk_engine_sum_counters_sync": (i32, [vp, vp, i32, vp]),
+    "snk_compact_scratch_elems": (i32, [i32]),
+    "snk_compact_flags": (i32, [vp, i32, vp, vp, vp, vp]),
+}
+
+
+def register(protos):
+    PROTOTYPES.update(protos)
+    if _lib is not None:
+        _bind(_lib, protos)
+
+
+def _bind(L, protos):
+    for name, (res, args) in protos.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError as exc:
+            raise EngineError(f"{LIB_PATH} does not export {name}; rebuild it (python -c 'import __graft_entry__ as g; g.build()')") from exc
+        fn.restype = res
+        fn.argtypes = args
+
+
+def lib():
+    """Loads the library or raises: there is deliberately no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        _bind(L, PROTOTYPES)
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().snk_last_error()
+        raise EngineError((msg or b"?").decode("utf-8", "replace") + f" (code {rc})")

@@ -346,8 +346,9 @@ def corner_cases():
     C.append(("draw_all_dead", H, W, [(0, 50, [(0, 3), (1, 3), (2, 3)], 0), (1, 50, [(10, 3), (9, 3), (8, 3)], 2)], [(5, 5)], [1, 1], 1, 0.0))
     # 13 plain starvation with health_dec 9
     C.append(("starve_dec9", H, W, [(0, 9, [(5, 3), (5, 2), (5, 1)], 1), (1, 10, [(7, 5), (7, 6), (7, 7)], 3)], [(0, 0)], [1, 1], 9, 0.0))
-    # 14 eat then wall: eating restores health, grows, next tick dies in wall (2 ticks)
-    C.append(("eat_then_wall", H, W, [(0, 5, [(1, 5), (2, 5), (3, 5)], 0), (1, 50, [(9, 9), (9, 8), (9, 7)], 3)], [(0, 5)], [[1, 1], [1, 1]], 1, 0.0))
+    # 14 eat then wall: eating restores health, grows, next tick dies in wall (2 ticks; two bystanders keep the game alive)
+    C.append(("eat_then_wall", H, W, [(0, 5, [(1, 5), (2, 5), (3, 5)], 0), (1, 50, [(9, 5), (9, 4), (9, 3)], 1),
+                                       (2, 50, [(5, 1), (6, 1), (7, 1)], 0)], [(0, 5)], [[1, 1, 1], [1, 1, 1]], 1, 0.0))
     # 15 body collision with a snake that dies in the same tick (its body still counts)
     C.append(("hit_dying_body", H, W, [(0, 50, [(0, 3), (1, 3), (2, 3)], 0), (1, 50, [(1, 2), (1, 1), (1, 0)], 1)], [(5, 5)], [1, 1], 1, 0.0))
     # 16 no empty cell for food: 5x5 board fully covered by two snakes with stacked tails (nothing is

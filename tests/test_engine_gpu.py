@@ -1,0 +1,374 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP engine, called through the C ABI
+(include/snake_engine.h via ctypes), against golden vectors recorded from the reference and
+against the CPU oracle on the same seeded inputs.  Everything here is integer / byte /
+float-bit work, so the bar is bit-exact."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, golden_state
+
+pytestmark = pytest.mark.gpu
+
+TIC_CFGS = ["11x11x4", "11x11x4_dec9", "7x7x2", "19x19x8"]
+KEYS = ("alive", "health", "length", "dir", "food", "rewards", "counters")
+
+
+@pytest.fixture(scope="module")
+def se():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import snake_engine
+    return snake_engine
+
+
+def assert_state_equal(got, exp, ctx=""):
+    for k in KEYS:
+        assert np.array_equal(got[k], exp[k]), f"{ctx}: field {k}: {got[k]} != {exp[k]}"
+    L = exp["nodes"].shape[1]
+    assert np.array_equal(got["nodes"][:, :L], exp["nodes"]), f"{ctx}: nodes differ\n{got['nodes'][:, :L]}\n{exp['nodes']}"
+    assert (got["nodes"][:, L:] == -1).all(), f"{ctx}: nodes beyond golden width"
+
+
+def _engine_for(se, z, n, chance=0.15):
+    H, W, S, hd = int(z["H"]), int(z["W"]), int(z["S"]), int(z["health_dec"])
+    return se.Engine(n, H, W, S, hd, chance), (H, W, S, hd)
+
+
+@pytest.mark.parametrize("cfg", TIC_CFGS)
+def test_step_every_golden_tick_in_one_launch(se, cfg):
+    """every (pre-state, moves, spawn) -> post-state triple of the golden trajectories, one slot each"""
+    import torch
+    from snake_engine.engine import state_from_compact, compact_from_state
+    z = load_golden(f"tic_{cfg}.npz")
+    ptr = z["ptr"]
+    pre_idx = np.concatenate([np.arange(ptr[g], ptr[g + 1] - 1) for g in range(len(ptr) - 1)])
+    n = len(pre_idx)
+    assert n == len(z["moves"])
+    eng, (H, W, S, hd) = _engine_for(se, z, n)
+    eng.import_states([state_from_compact(H, W, S, golden_state(z, i)) for i in pre_idx])
+    moves = torch.as_tensor(z["moves"], device="cuda")
+    tape = torch.as_tensor(z["spawn"], device="cuda")
+    done = eng.new((n,), torch.uint8, 7)
+    spawned = eng.new((n,), torch.int16, 99)
+    empty = eng.new((n, eng.FW), torch.int64, 0)
+    eng.step(moves, spawn_tape=tape, done=done, spawned=spawned, empty=empty)
+    out = eng.export()
+    done_h, empty_h = done.cpu().numpy(), empty.cpu().numpy().view(np.uint64)
+    assert np.array_equal(spawned.cpu().numpy(), z["spawn"])
+    for t in range(n):
+        assert_state_equal(compact_from_state(out[t]), golden_state(z, pre_idx[t] + 1), f"{cfg} tick {t}")
+        assert done_h[t] == z["done"][t]
+        if z["spawn_empty_valid"][t]:
+            ref = np.unpackbits(z["spawn_empty"][t])[: H * W]
+            got = np.unpackbits(empty_h[t].view(np.uint8), bitorder="little")[: H * W]
+            assert np.array_equal(got, ref), f"{cfg} tick {t}: empty set at spawn time"
+
+
+@pytest.mark.parametrize("cfg", TIC_CFGS)
+def test_step_trajectories_lockstep(se, cfg):
+    """all golden games advanced together tick by tick (ring buffers wrap, finished games idle)"""
+    import torch
+    from snake_engine.engine import state_from_compact, compact_from_state
+    z = load_golden(f"tic_{cfg}.npz")
+    ptr = z["ptr"]
+    G = len(ptr) - 1
+    eng, (H, W, S, hd) = _engine_for(se, z, G)
+    eng.import_states([state_from_compact(H, W, S, golden_state(z, ptr[g])) for g in range(G)])
+    T = [int(ptr[g + 1] - ptr[g] - 1) for g in range(G)]
+    tick0 = np.concatenate([[0], np.cumsum(T)])[:-1]
+    done = eng.new((G,), torch.uint8, 0)
+    for t in range(max(T)):
+        mv = np.full((G, S), 1, np.uint8)
+        sp = np.full(G, -1, np.int16)
+        for g in range(G):
+            if t < T[g]:
+                mv[g] = z["moves"][tick0[g] + t]
+                sp[g] = z["spawn"][tick0[g] + t]
+        mv[mv == 255] = 1
+        # a game whose golden trajectory was truncated (max_ticks) but has not ended would keep
+        # running with dummy moves; freeze it by stepping only the games still inside their tape
+        live = np.array([g for g in range(G) if t < T[g]], np.int32)
+        eng.step(torch.as_tensor(mv[live], device="cuda"), slots=live,
+                 spawn_tape=torch.as_tensor(sp[live], device="cuda"), done=done)
+        if t % 16 == 0 or t == max(T) - 1:
+            out = eng.export()
+            for g in range(G):
+                tt = min(t + 1, T[g])
+                assert_state_equal(compact_from_state(out[g]), golden_state(z, ptr[g] + tt), f"{cfg} game {g} after tick {t}")
+    out = eng.export()
+    for g in range(G):
+        assert_state_equal(compact_from_state(out[g]), golden_state(z, ptr[g + 1] - 1), f"{cfg} game {g} final")
+
+
+def test_ended_games_are_left_untouched(se):
+    import torch
+    from snake_engine.engine import state_from_compact, compact_from_state
+    z = load_golden("tic_11x11x4.npz")
+    ends = [int(z["ptr"][g + 1] - 1) for g in range(len(z["ptr"]) - 1)]
+    ends = [i for i in ends if golden_state(z, i)["alive"].sum() <= 1]
+    eng, (H, W, S, hd) = _engine_for(se, z, len(ends))
+    eng.import_states([state_from_compact(H, W, S, golden_state(z, i)) for i in ends])
+    done = eng.new((len(ends),), torch.uint8, 0)
+    eng.step(eng.new((len(ends), S), torch.uint8, 1), done=done)
+    out = eng.export()
+    assert done.cpu().numpy().all()
+    for k, i in enumerate(ends):
+        assert_state_equal(compact_from_state(out[k]), golden_state(z, i), f"ended game {k}")
+
+
+@pytest.mark.parametrize("cfg", TIC_CFGS)
+def test_reset_with_init_tape(se, cfg):
+    from snake_engine.engine import compact_from_state
+    z = load_golden(f"tic_{cfg}.npz")
+    G = len(z["ptr"]) - 1
+    eng, (H, W, S, hd) = _engine_for(se, z, G)
+    tape = np.stack([z["init_positions"], z["init_dirs"], z["init_food"]], axis=1)
+    eng.reset(init_tape=tape)
+    out = eng.export()
+    for g in range(G):
+        assert_state_equal(compact_from_state(out[g]), golden_state(z, z["ptr"][g]), f"{cfg} init {g}")
+
+
+def test_reset_random_is_a_legal_start(se):
+    from snake_engine.engine import compact_from_state
+    eng = se.Engine(4096, 11, 11, 4, 1, 0.15, seed=5)
+    eng.reset()
+    out = eng.export()
+    starts = {(1, 1), (9, 9), (9, 1), (1, 9), (1, 5), (5, 9), (9, 5), (5, 1)}
+    seen_cells, seen_dirs = set(), set()
+    for g in range(4096):
+        c = compact_from_state(out[g])
+        assert c["alive"].all() and (c["health"] == 100).all() and (c["length"] == 3).all()
+        heads = [(int(v) // 11, int(v) % 11) for v in c["nodes"][:, 0]]
+        assert len(set(heads)) == 4 and set(heads) <= starts
+        assert (c["nodes"][:, :3] == c["nodes"][:, :1]).all() and (c["nodes"][:, 3:] == -1).all()
+        food = {(int(i) // 11, int(i) % 11) for i in np.flatnonzero(c["food"])}
+        assert (5, 5) in food and len(food) <= 5
+        for (fy, fx) in food - {(5, 5)}:
+            assert any(abs(fy - hy) == 1 and abs(fx - hx) == 1 for (hy, hx) in heads)
+        for (hy, hx) in heads:
+            assert any(abs(fy - hy) == 1 and abs(fx - hx) == 1 for (fy, fx) in food)
+        seen_cells |= set(heads)
+        seen_dirs |= set(c["dir"].tolist())
+        assert (c["counters"] == 0).all() and (c["rewards"] == 0).all()
+    assert seen_cells == starts and seen_dirs == {0, 1, 2, 3}
+    assert len({out[g].uid for g in range(4096)}) == 4096
+
+
+def test_corner_cases(se):
+    import torch
+    from snake_engine.engine import state_from_compact, compact_from_state
+    z = load_golden("corner.npz")
+    for i, name in enumerate(z["names"]):
+        p = f"c{i}_"
+        H, W, S, hd = (int(v) for v in z[p + "meta"])
+        if (H, W) not in ((11, 11), (7, 7), (19, 19)):
+            continue    # the 5x5 no-empty-cell board is covered by the oracle; see test below for the engine
+        chance = float(z[p + "chance"])
+        eng = se.Engine(1, H, W, S, hd, chance)
+        eng.import_states([state_from_compact(H, W, S, golden_state(z, 0, p + "st_"))])
+        for t in range(len(z[p + "moves"])):
+            st = compact_from_state(eng.export()[0])
+            pairs = np.array([[0, s] for s in range(S) if st["alive"][s]], np.int32)
+            planes, _, _ = eng.observe_all(pairs)
+            assert planes.cpu().numpy().tobytes() == z[p + f"obs{t}"].tobytes(), f"{name}: obs before tick {t}"
+            mv = z[p + "moves"][t].copy()
+            mv[mv == 255] = 1
+            done = eng.new((1,), torch.uint8, 0)
+            eng.step(torch.as_tensor(mv[None], device="cuda"),
+                     spawn_tape=torch.as_tensor(z[p + "spawn"][t:t + 1], device="cuda"), done=done)
+            assert_state_equal(compact_from_state(eng.export()[0]), golden_state(z, t + 1, p + "st_"), f"{name} tick {t}")
+            assert int(done.item()) == int(z[p + "done"][t]), name
+
+
+def test_no_empty_cell_for_food(se, oracle):
+    """a full 7x7 board: nothing is vacated (stacked tails), no food, chance 1.0 -> no spawn (game.py:132-138)"""
+    import torch
+    from snake_engine.engine import state_from_compact, compact_from_state
+
+    def serp(i):
+        r = i // 7
+        return r * 7 + (i % 7 if r % 2 == 0 else 6 - i % 7)
+    a = [serp(i) for i in range(25)]
+    b = [serp(i) for i in range(48, 24, -1)]
+    nodes = np.full((2, 30), -1, np.int16)
+    nodes[0, :26] = a + [a[-1]]
+    nodes[1, :25] = b + [b[-1]]
+    st = dict(alive=np.ones(2, np.uint8), health=np.array([50, 50], np.int16), length=np.array([26, 25], np.int16),
+              dir=np.array([3, 3], np.uint8), nodes=nodes, food=np.zeros(49, np.uint8), rewards=np.zeros(2, np.int8),
+              counters=np.zeros(6, np.int32))
+    eng = se.Engine(1, 7, 7, 2, 1, 1.0)
+    eng.import_states([state_from_compact(7, 7, 2, st)])
+    spawned = eng.new((1,), torch.int16, 5)
+    empty = eng.new((1, 1), torch.int64, -1)
+    eng.step(eng.new((1, 2), torch.uint8, 1), spawned=spawned, empty=empty)   # device RNG path, chance 1.0
+    og = oracle.Game.from_compact(7, 7, 2, 1, 1.0, st)
+    og.tic([1, 1], draws=(0.0, 0.5), want_empty=True)
+    assert int(spawned.item()) == -1 == og.last_spawn
+    assert int(empty.item()) == 0 and og.last_empty.sum() == 0
+    assert_state_equal(compact_from_state(eng.export()[0]), og.compact(30), "full board")
+
+
+@pytest.mark.parametrize("cfg", TIC_CFGS)
+def test_observe_bytes_masks_keys(se, cfg):
+    """Game.get_states() bytes, obstacle masks (both NumPy semantics) and 128-bit keys for every golden observation"""
+    from snake_engine.engine import state_from_compact, NCHW_F32
+    z = load_golden(f"tic_{cfg}.npz")
+    s = load_golden(f"states_{cfg}.npz")
+    uniq = np.unique(s["state_index"])
+    slot_of = {int(v): k for k, v in enumerate(uniq)}
+    eng, (H, W, S, hd) = _engine_for(se, z, len(uniq))
+    eng.import_states([state_from_compact(H, W, S, golden_state(z, i)) for i in uniq])
+    pairs = np.array([[slot_of[int(si)], int(sn)] for si, sn in zip(s["state_index"], s["snake_id"])], np.int32)
+    planes, mask, key = eng.observe_all(pairs)
+    _, mask_l, _ = eng.observe_all(pairs, want_planes=False, want_key=False, legacy_mask=True)
+    planes_h = planes.cpu().numpy()
+    for j in range(len(pairs)):
+        assert hashlib.blake2b(planes_h[j].tobytes(), digest_size=16).digest() == s["digest"][j].tobytes(), f"{cfg} obs {j}"
+    assert planes_h[s["raw_index"]].tobytes() == s["raw"].tobytes()
+    assert np.array_equal(mask.cpu().numpy(), s["mask"])
+    assert np.array_equal(mask_l.cpu().numpy(), s["mask_legacy"])
+    assert np.array_equal(key.cpu().numpy().view(np.uint64), s["key"])
+    nchw, _, _ = eng.observe_all(pairs, want_mask=False, want_key=False, layout=NCHW_F32)
+    assert np.array_equal(nchw.cpu().numpy(), planes_h.transpose(0, 3, 1, 2))
+
+
+def test_observe_dead_snake_and_any_order(se):
+    from snake_engine.engine import state_from_compact
+    z = load_golden("tic_11x11x4.npz")
+    idx = next(i for i in range(len(z["st_alive"])) if 2 <= z["st_alive"][i].sum() < 4)
+    st = golden_state(z, idx)
+    dead = int(np.flatnonzero(st["alive"] == 0)[0])
+    live = [int(v) for v in np.flatnonzero(st["alive"])]
+    eng = se.Engine(2, 11, 11, 4, 1, 0.15)
+    eng.import_states([state_from_compact(11, 11, 4, st)], slots=[1])
+    pairs = np.array([[1, live[-1]], [1, dead], [1, live[0]]], np.int32)
+    planes, mask, key = eng.observe_all(pairs)
+    assert not planes[1].any().item() and mask[1].cpu().tolist() == [1, 1, 1] and key[1].cpu().tolist() == [0, 0]
+    p2, m2, k2 = eng.observe_all(np.array([[1, live[0]], [1, live[-1]]], np.int32))
+    assert (p2[0] == planes[2]).all().item() and (p2[1] == planes[0]).all().item()
+    assert (k2[0] == key[2]).all().item() and (m2[1] == mask[0]).all().item()
+
+
+def test_clone_fanout(se):
+    import torch
+    from snake_engine.engine import state_from_compact, compact_from_state
+    z = load_golden("tic_11x11x4.npz")
+    idx = [40, 300, 777, 1500]
+    root = se.Engine(8, 11, 11, 4, 1, 0.15)
+    sub = se.Engine(64, 11, 11, 4, 1, 0.0)
+    root.import_states([state_from_compact(11, 11, 4, golden_state(z, i)) for i in idx], slots=[1, 3, 4, 6])
+    src = np.array([1, 3, 4, 6], np.int32)
+    root.clone_to(sub, src_slots=src, fanout=8)
+    out = sub.export(np.arange(32, dtype=np.int32))
+    for i in range(4):
+        exp = golden_state(z, idx[i])
+        exp = dict(exp, counters=np.zeros(6, np.int32))       # fresh counters, copied rewards (game.py:268,275)
+        for j in range(8):
+            assert_state_equal(compact_from_state(out[i * 8 + j]), exp, f"clone {i}/{j}")
+    dst = torch.as_tensor(np.array([63, 62, 61, 60], np.int32), device="cuda")
+    root.clone_to(sub, src_slots=src, dst_slots=dst, fanout=1)
+    out = sub.export(np.array([63, 62, 61, 60], np.int32))
+    for i in range(4):
+        assert_state_equal(compact_from_state(out[i]), dict(golden_state(z, idx[i]), counters=np.zeros(6, np.int32)), f"clone-to {i}")
+
+
+def test_device_rng_spawn_replays_on_the_oracle(se, oracle):
+    """device-RNG food spawn: legal (inside the oracle's empty set), ~15 % rate, and the whole run replays
+    bit-exactly on the CPU oracle when the oracle is fed the device's spawn decisions as a tape"""
+    import torch
+    from snake_engine.engine import compact_from_state
+    n, T = 512, 60
+    eng = se.Engine(n, 11, 11, 4, 1, 0.15, seed=77)
+    eng.reset()
+    start = eng.export()
+    games = [oracle.Game.from_compact(11, 11, 4, 1, 0.15, compact_from_state(start[g])) for g in range(n)]
+    rng = np.random.RandomState(3)
+    spawned = eng.new((n,), torch.int16, 0)
+    done = eng.new((n,), torch.uint8, 0)
+    n_spawn = n_ticks = 0
+    for t in range(T):
+        mv = rng.randint(0, 3, size=(n, 4)).astype(np.uint8)
+        # steer away from instant wall deaths so games last: prefer straight 60 % of the time
+        mv[rng.rand(n, 4) < 0.6] = 1
+        eng.step(torch.as_tensor(mv, device="cuda"), spawned=spawned, done=done)
+        sp = spawned.cpu().numpy()
+        dn = done.cpu().numpy()
+        for g in range(n):
+            og = games[g]
+            if sum(og.g.alive[:4]) <= 1:
+                assert dn[g] == 1 and sp[g] == -1
+                continue
+            had_food = sum(og.g.food[:121]) > 0
+            d = og.tic(mv[g], spawn_cell=int(sp[g]), want_empty=True)
+            if sp[g] >= 0:
+                assert og.last_empty[sp[g]] == 1, "spawned into a non-empty cell"
+            assert d == bool(dn[g])
+            n_ticks += 1
+            n_spawn += sp[g] >= 0
+            del had_food
+    out = eng.export()
+    for g in range(n):
+        assert_state_equal(compact_from_state(out[g]), games[g].compact(), f"rng game {g}")
+    rate = n_spawn / n_ticks
+    assert 0.10 < rate < 0.22, rate     # 0.15 plus forced spawns when the board has no food
+
+
+def test_compact_flags(se):
+    import torch
+    eng = se.Engine(1, 7, 7, 2)
+    rng = np.random.RandomState(0)
+    for n in (1, 63, 2048, 2049, 70001, 1_000_003):
+        f = (rng.rand(n) < 0.37).astype(np.uint8)
+        idx, cnt = eng.compact(torch.as_tensor(f, device="cuda"))
+        c = int(cnt.item())
+        assert c == int(f.sum())
+        assert np.array_equal(idx[:c].cpu().numpy(), np.flatnonzero(f))
+    z = torch.zeros(5000, dtype=torch.uint8, device="cuda")
+    idx, cnt = eng.compact(z)
+    assert int(cnt.item()) == 0
+
+
+def test_large_batch_invariants(se):
+    """config-2/3 sized batch (32 768 games): size-independent properties of the rules"""
+    import torch
+    n, T = 32768, 40
+    eng = se.Engine(n, 11, 11, 4, 1, 0.15, seed=9)
+    eng.reset()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    prev_alive = eng.alive().clone()
+    for t in range(T):
+        mv = torch.randint(0, 3, (n, 4), device="cuda", generator=g, dtype=torch.int32).to(torch.uint8)
+        eng.step(mv)
+        alive = eng.alive()
+        assert (alive <= prev_alive).all().item(), "a dead snake came back"
+        prev_alive = alive.clone()
+    c = eng.sum_counters()
+    out_alive = prev_alive.sum().item()
+    deaths = c[0] + c[1] + c[2] + c[3]
+    assert deaths == n * 4 - out_alive, (c, out_alive)
+    assert 0 < c[5] <= n * T and c[4] > 0
+    # sampled games: board consistency on the host
+    from snake_engine.engine import compact_from_state
+    samp = np.arange(0, n, 997, dtype=np.int32)
+    for st in eng.export(samp):
+        cst = compact_from_state(st)
+        cells = []
+        for s in range(4):
+            if cst["alive"][s]:
+                L = int(cst["length"][s])
+                assert L >= 3 and (cst["nodes"][s, :L] >= 0).all() and (cst["nodes"][s, L:] == -1).all()
+                body = cst["nodes"][s, :L].tolist()
+                # distinct cells except a run of stacked nodes at the tail end
+                k = L
+                while k > 1 and body[k - 1] == body[k - 2]:
+                    k -= 1
+                assert len(set(body[:k])) == k
+                cells += list(set(body))
+                assert cst["rewards"][s] in (0, 1)
+            else:
+                assert cst["rewards"][s] == -1
+        assert len(cells) == len(set(cells)), "two snakes overlap"
+        assert not (cst["food"][cells] if cells else np.zeros(0)).any(), "food under a snake"
