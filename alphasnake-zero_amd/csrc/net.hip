@@ -1,0 +1,315 @@
+// net.hip -- the Q-net's inference path on gfx950 (reference: AlphaNNet.__init__ / .v,
+// alpha_nnet.py:19-56, 61-76).  Activations are NHWC float32 (the reference is channels-last),
+// batch-norm is folded into a per-channel scale/shift, and every layer is a hand-written kernel:
+//
+//   k_stem_conv      3x3 conv 3 -> C, + BN + ReLU            (alpha_nnet.py:21-22)      VALU
+//   k_conv3x3_f32    3x3 conv C -> C as an implicit GEMM on v_mfma_f32_32x32x2_f32,
+//                    + BN (+ residual) + ReLU                (alpha_nnet.py:25-47)      MFMA
+//   k_head           1x1 conv C -> 1 + BN + ReLU, Flatten, Dense(128) + ReLU,
+//                    Dense(3) + tanh, obstacle mask          (alpha_nnet.py:49-54, 63-73)
+//
+// Implicit GEMM of the 3x3 layer: M = pixels (batch * HW), N = C_out = 128, K = 9 taps * 128.
+// Block tile 128 (pixels) x 128 (C_out), 4 wavefronts as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles of
+// 32 x 32 (64 accumulator VGPRs).  K advances in chunks of 32 input channels of one tap; both
+// operand tiles sit in LDS K-contiguous ([row][k], rows padded to 36 floats so that 16-lane
+// ds_read_b128 groups are bank-conflict free), so one ds_read_b128 per lane delivers the lane's
+// operand for 4 consecutive MFMAs: lanes 0-31 take k = 8c+q, lanes 32-63 k = 8c+4+q, q = 0..3 --
+// the f32 MFMA's two k-slots only have to agree between A and B.  Global -> LDS staging is
+// register double-buffered: the loads of chunk c+1 are issued before the 64 MFMAs of chunk c.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CV_BM 128
+#define CV_BN 128
+#define CV_BK 32
+#define CV_LD (CV_BK + 4)
+#define CV_C 128
+
+struct ConvArgs {
+    const float *x;      // [M][128] NHWC activations
+    const float *wT;     // [9][128 cout][128 cin]
+    const float *scale;  // [128]
+    const float *shift;  // [128]
+    const float *res;    // [M][128] or NULL
+    float *out;          // [M][128]
+    int M;               // batch * HW
+    int Hd, Wd;          // image height / width (21 x 21 or 37 x 37)
+    int relu;
+};
+
+__global__ __launch_bounds__(256, 2) void k_conv3x3_f32(ConvArgs p)
+{
+    __shared__ __align__(16) float As[2][CV_BM][CV_LD];
+    __shared__ __align__(16) float Bs[2][CV_BN][CV_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv & 1, wn = wv >> 1;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.x * CV_BM;
+    const int HW = p.Hd * p.Wd;
+
+    // staging assignment: float4 number f = tid + 256 i, i < 4 -> row f >> 3, 16-byte column f & 7
+    const int c4 = tid & 7;
+    int ay[4], ax[4];
+    long abase[4];
+    bool avalid[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        const int m = m0 + row;
+        avalid[i] = m < p.M;
+        const int mm = avalid[i] ? m : 0;
+        const int rem = mm % HW;
+        ay[i] = rem / p.Wd;
+        ax[i] = rem - ay[i] * p.Wd;
+        abase[i] = (long)mm * CV_C + c4 * 4;
+    }
+
+    float4 ra[4], rb[4];
+    auto load_chunk = [&](int c) {
+        const int tap = c >> 2, cin0 = (c & 3) * CV_BK;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const long aoff = (long)(dy * p.Wd + dx) * CV_C + cin0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yy = ay[i] + dy, xx = ax[i] + dx;
+            const bool ok = avalid[i] && yy >= 0 && yy < p.Hd && xx >= 0 && xx < p.Wd;
+            ra[i] = ok ? *(const float4 *)(p.x + abase[i] + aoff) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int n = (tid >> 3) + 32 * i;
+            rb[i] = *(const float4 *)(p.wT + ((long)(tap * CV_C + n) * CV_C + cin0 + c4 * 4));
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            *(float4 *)&As[buf][row][c4 * 4] = ra[i];
+            *(float4 *)&Bs[buf][row][c4 * 4] = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+
+    constexpr int NCHUNK = 9 * (CV_C / CV_BK);
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < NCHUNK) load_chunk(c + 1);
+#pragma unroll
+        for (int k8 = 0; k8 < CV_BK / 8; ++k8) {
+            float4 a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = *(const float4 *)&As[buf][wm * 64 + t * 32 + l31][k8 * 8 + 4 * h];
+                b[t] = *(const float4 *)&Bs[buf][wn * 64 + t * 32 + l31][k8 * 8 + 4 * h];
+            }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt].x, b[ct].x, acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt].y, b[ct].y, acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt].z, b[ct].z, acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt].w, b[ct].w, acc[rt][ct], 0, 0, 0);
+                }
+        }
+        if (c + 1 < NCHUNK) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: BN scale/shift (+ residual) + ReLU.  C/D map of the 32x32 MFMA:
+    // col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int col = wn * 64 + ct * 32 + l31;
+        const float sc = p.scale[col], sh = p.shift[col];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int m = m0 + row;
+                if (m < p.M) {
+                    float v = acc[rt][ct][r] * sc + sh;
+                    if (p.res) v += p.res[(long)m * CV_C + col];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    p.out[(long)m * CV_C + col] = v;
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// stem: 3x3 conv over the 3 observation planes (NHWC), BN, ReLU.  K = 27: VALU work, weights in LDS.
+// One block = 64 pixels x 128 output channels; thread (tid & 127) owns a channel, (tid >> 7) a pixel parity.
+// ------------------------------------------------------------------------------------------
+struct StemArgs {
+    const float *x;      // [M][3]
+    const float *w;      // [3][3][3][128] (kh, kw, cin, cout) = Keras kernel layout
+    const float *scale, *shift;
+    float *out;          // [M][128]
+    int M, Hd, Wd;
+};
+
+__global__ __launch_bounds__(256) void k_stem_conv(StemArgs p)
+{
+    __shared__ float ws[27][CV_C];
+    __shared__ float patch[64][28];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 27 * CV_C; i += 256) ws[i / CV_C][i % CV_C] = p.w[i];
+    const int HW = p.Hd * p.Wd;
+    const int m0 = blockIdx.x * 64;
+    // gather the 27-value input patch of each of the 64 pixels
+    for (int i = tid; i < 64 * 27; i += 256) {
+        const int px = i / 27, q = i - px * 27;
+        const int tap = q / 3, ch = q - tap * 3;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int m = m0 + px;
+        float v = 0.f;
+        if (m < p.M) {
+            const int rem = m % HW;
+            const int y = rem / p.Wd, x = rem - y * p.Wd;
+            const int yy = y + dy, xx = x + dx;
+            if (yy >= 0 && yy < p.Hd && xx >= 0 && xx < p.Wd) v = p.x[((long)m + dy * p.Wd + dx) * 3 + ch];
+        }
+        patch[px][q] = v;
+    }
+    __syncthreads();
+    const int co = tid & 127, par = tid >> 7;
+    const float sc = p.scale[co], sh = p.shift[co];
+    for (int px = par; px < 64; px += 2) {
+        const int m = m0 + px;
+        if (m >= p.M) break;
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 27; ++q) acc = fmaf(patch[px][q], ws[q][co], acc);
+        p.out[(long)m * CV_C + co] = fmaxf(acc * sc + sh, 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// head: conv1x1 (C -> 1) + BN + ReLU -> Flatten (HW) -> Dense(128) + ReLU -> Dense(3) + tanh,
+// then AlphaNNet.v's obstacle overwrite (alpha_nnet.py:67-72).  One block per state.
+// ------------------------------------------------------------------------------------------
+struct HeadArgs {
+    const float *x;        // [n][HW][128]
+    const float *w1x1;     // [128]
+    float s1, b1;          // folded BN of the single channel
+    const float *fc1_w;    // [HW][128]  (Keras Dense kernel (in, out))
+    const float *fc1_b;    // [128]
+    const float *fc2_w;    // [128][3]
+    const float *fc2_b;    // [3]
+    const uint8_t *mask;   // [n][3] or NULL
+    float *q;              // [n][3]
+    int n, HW;
+};
+
+__global__ __launch_bounds__(256) void k_head(HeadArgs p)
+{
+    extern __shared__ float sm[];
+    float *h1 = sm;               // [HW]
+    float *h2 = sm + p.HW;        // [128]
+    float *part = h2 + 128;       // [256]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int s = blockIdx.x;
+    const float *xs = p.x + (long)s * p.HW * CV_C;
+    const float w_a = p.w1x1[lane], w_b = p.w1x1[lane + 64];
+    for (int px = wv; px < p.HW; px += 4) {
+        float v = xs[(long)px * CV_C + lane] * w_a + xs[(long)px * CV_C + lane + 64] * w_b;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) h1[px] = fmaxf(v * p.s1 + p.b1, 0.f);
+    }
+    __syncthreads();
+    // Dense(HW -> 128): two half-sums per output, combined through LDS
+    {
+        const int j = tid & 127, half = tid >> 7;
+        const int mid = (p.HW + 1) / 2;
+        const int lo = half ? mid : 0, hi = half ? p.HW : mid;
+        float acc = 0.f;
+        for (int i = lo; i < hi; ++i) acc = fmaf(h1[i], p.fc1_w[(long)i * 128 + j], acc);
+        part[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < 128) h2[tid] = fmaxf(part[tid] + part[tid + 128] + p.fc1_b[tid], 0.f);
+    __syncthreads();
+    if (wv < 3) {
+        float v = h2[lane] * p.fc2_w[lane * 3 + wv] + h2[lane + 64] * p.fc2_w[(lane + 64) * 3 + wv];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) {
+            float qv = tanhf(v + p.fc2_b[wv]);
+            if (p.mask && p.mask[(long)s * 3 + wv]) qv = -1.0f;
+            p.q[(long)s * 3 + wv] = qv;
+        }
+    }
+}
+
+// weights (kh, kw, cin, cout) -> (tap, cout, cin) so that both GEMM operands are K-contiguous
+__global__ void k_transpose_w(const float *__restrict__ w, float *__restrict__ wT)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 9 * CV_C * CV_C) return;
+    const int tap = i / (CV_C * CV_C), r = i - tap * CV_C * CV_C;
+    const int co = r / CV_C, ci = r - co * CV_C;
+    wT[i] = w[(long)(tap * CV_C + ci) * CV_C + co];
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" int snk_conv3x3_prepare_weights(const float *d_w_hwio, float *d_wT, void *stream)
+{
+    SNK_REQUIRE(d_w_hwio && d_wT, "snk_conv3x3_prepare_weights: NULL argument");
+    k_transpose_w<<<(9 * CV_C * CV_C + 255) / 256, 256, 0, (hipStream_t)stream>>>(d_w_hwio, d_wT);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int snk_conv3x3_bn_f32(const float *d_x, const float *d_wT, const float *d_scale, const float *d_shift,
+                                  const float *d_residual, float *d_out, int n_images, int height, int width,
+                                  int relu, void *stream)
+{
+    SNK_REQUIRE(d_x && d_wT && d_scale && d_shift && d_out, "snk_conv3x3_bn_f32: NULL argument");
+    SNK_REQUIRE(d_out != d_x, "snk_conv3x3_bn_f32: in-place convolution is not possible");
+    if (n_images <= 0) return 0;
+    const long M = (long)n_images * height * width;
+    SNK_REQUIRE(M < (1l << 31), "snk_conv3x3_bn_f32: batch of %d images too large for one call", n_images);
+    ConvArgs a = {d_x, d_wT, d_scale, d_shift, d_residual, d_out, (int)M, height, width, relu};
+    k_conv3x3_f32<<<(int)((M + CV_BM - 1) / CV_BM), 256, 0, (hipStream_t)stream>>>(a);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int snk_stem_conv_bn_relu_f32(const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,
+                                         float *d_out, int n_images, int height, int width, void *stream)
+{
+    SNK_REQUIRE(d_x && d_w && d_scale && d_shift && d_out, "snk_stem_conv_bn_relu_f32: NULL argument");
+    if (n_images <= 0) return 0;
+    const long M = (long)n_images * height * width;
+    SNK_REQUIRE(M < (1l << 31), "snk_stem_conv_bn_relu_f32: batch too large");
+    StemArgs a = {d_x, d_w, d_scale, d_shift, d_out, (int)M, height, width};
+    k_stem_conv<<<(int)((M + 63) / 64), 256, 0, (hipStream_t)stream>>>(a);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int snk_head_f32(const float *d_x, const float *d_w1x1, float bn_scale, float bn_shift, const float *d_fc1_w,
+                            const float *d_fc1_b, const float *d_fc2_w, const float *d_fc2_b, const uint8_t *d_mask,
+                            float *d_q, int n_images, int height, int width, void *stream)
+{
+    SNK_REQUIRE(d_x && d_w1x1 && d_fc1_w && d_fc1_b && d_fc2_w && d_fc2_b && d_q, "snk_head_f32: NULL argument");
+    if (n_images <= 0) return 0;
+    HeadArgs a = {d_x, d_w1x1, bn_scale, bn_shift, d_fc1_w, d_fc1_b, d_fc2_w, d_fc2_b, d_mask, d_q, n_images, height * width};
+    const size_t lds = (size_t)(height * width + 128 + 256) * sizeof(float);
+    k_head<<<n_images, 256, lds, (hipStream_t)stream>>>(a);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}

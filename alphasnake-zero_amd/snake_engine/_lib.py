@@ -49,6 +49,24 @@ PROTOTYPES = {
     "snk_engine_sum_counters_sync": (i32, [vp, vp, i32, vp]),
     "snk_compact_scratch_elems": (i32, [i32]),
     "snk_compact_flags": (i32, [vp, i32, vp, vp, vp, vp]),
+    "snk_conv3x3_prepare_weights": (i32, [vp, vp, vp]),
+    "snk_conv3x3_bn_f32": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "snk_stem_conv_bn_relu_f32": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "snk_tt_create": (i32, [C.POINTER(vp), u64, i32]),
+    "snk_tt_destroy": (i32, [vp]),
+    "snk_tt_clear": (i32, [vp, vp]),
+    "snk_tt_status_sync": (i32, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(i32)]),
+    "snk_tt_rebuild_sync": (i32, [vp, u64, i32, i32]),
+    "snk_tt_lookup_insert": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
+    "snk_tt_set_priors": (i32, [vp, vp, vp, i32, vp, vp]),
+    "snk_tt_read_q": (i32, [vp, vp, i32, i32, vp, vp]),
+    "snk_mcts_select": (i32, [vp, vp, i32, C.c_float, vp, vp, C.c_int64, u64, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "snk_mcts_backup": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "snk_mcts_terminal_backup": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, vp]),
+    "snk_mcts_root_moves": (i32, [vp, vp, i32, C.c_float, i32, vp, vp, C.c_int64, u64, C.c_uint32, C.c_uint32, vp, vp]),
+    "snk_softermax_argmax": (i32, [vp, i32, C.c_float, vp, vp, vp]),
+    "snk_engine_rewards": (i32, [vp, vp, i32, vp, vp]),
+    "snk_head_f32": (i32, [vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
 }
 
 

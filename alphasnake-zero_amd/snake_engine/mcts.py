@@ -1,0 +1,236 @@
+"""DeviceMCTS: the reference's randomized parallel MCTS (Agent.make_moves agent.py:25-111 and the
+rollout loop MCTSMPGameRunner.run / MCTSAgent.make_moves, mp_game_runner.py:85-115, agent.py:161-223)
+run as kernel launches over HBM-resident games.  This file only sequences C-ABI calls; torch is used
+for buffers, index plumbing (gather / cumsum) and the single host read-back per rollout tick (the
+number of cache misses, which sizes the net batch).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import lib, check, EngineError
+from .engine import Engine, _ptr, _stream
+
+PARALLEL = 8     # agent.py:32
+
+
+def _pow2_at_least(v):
+    p = 1024
+    while p < v:
+        p <<= 1
+    return p
+
+
+class TranspositionTable:
+    """cached_values / total_rewards / visit_cnts / cache_hit (agent.py:16-19) in HBM."""
+
+    def __init__(self, capacity, device=0):
+        self.L = lib()
+        h = C.c_void_p()
+        check(self.L.snk_tt_create(C.byref(h), int(capacity), device))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.snk_tt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def clear(self):
+        check(self.L.snk_tt_clear(self.h, _stream()))
+
+    def status(self):
+        cap, occ, ovf = C.c_int64(), C.c_int64(), C.c_int()
+        check(self.L.snk_tt_status_sync(self.h, C.byref(cap), C.byref(occ), C.byref(ovf)))
+        return cap.value, occ.value, ovf.value
+
+    def rebuild(self, new_capacity, now, max_age):
+        check(self.L.snk_tt_rebuild_sync(self.h, int(new_capacity), int(now), int(max_age)))
+
+
+class DeviceMCTS:
+    def __init__(self, evaluate, height, width, snake_cnt, softmax_base=100, training=False, max_depth=8,
+                 max_breadth=128, seed=1234, device=0, sequential=False, tape_u=None, tt_capacity=None,
+                 legacy_mask=False):
+        """evaluate(planes[n,h,w,3] cuda f32, mask[n,3] cuda u8) -> cuda f32 [n,3]  (= AlphaNNet.v)"""
+        if not torch.cuda.is_available():
+            raise EngineError("DeviceMCTS needs an MI355X; there is no CPU fallback")
+        self.L = lib()
+        self.evaluate = evaluate
+        self.H, self.W, self.S = height, width, snake_cnt
+        self.base, self.training = float(softmax_base), bool(training)
+        self.max_depth, self.max_breadth = int(max_depth), int(max_breadth)
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.dev_index = device
+        self.device = torch.device("cuda", device)
+        self.sequential = bool(sequential)
+        self.legacy_mask = bool(legacy_mask)
+        self.tape = None if tape_u is None else torch.as_tensor(np.asarray(tape_u, np.float64), device=self.device)
+        self.tape_pos = 0
+        self.now = 0                      # root turns seen (the clock cache_hit counts in)
+        self.draw_ctr = 0                 # Philox counter: one value per kernel that draws
+        self.tt_capacity = tt_capacity
+        self.tt = None
+        self.roll = None                  # rollout engine (sub-games; food_spawn_chance 0, game.py:268)
+        self._bufs_B = -1
+        self.stats = dict(net_evals=0, rollout_ticks=0, sim_steps=0, lookups=0)
+
+    # ---- buffers -------------------------------------------------------------------------------
+    def _ensure(self, G, health_dec):
+        par = min(PARALLEL, self.max_breadth)
+        B = G * par
+        if self.roll is None or self.roll.n_slots < B:
+            self.roll = Engine(max(B, 64), self.H, self.W, self.S, health_dec, 0.0, seed=self.seed, device=self.dev_index)
+        self.roll.set_params(health_dec=health_dec, food_spawn_chance=0.0)
+        if self.tt is None:
+            cap = self.tt_capacity
+            if cap is None:     # room for every state of ~max_depth+2 root turns at a 50 % load factor
+                per_turn = B * self.S * max(1, self.max_depth) * max(1, self.max_breadth // par)
+                cap = min(1 << 28, _pow2_at_least(2 * per_turn * (self.max_depth + 2) // 2))
+            self.tt = TranspositionTable(_pow2_at_least(cap), self.dev_index)
+        if self._bufs_B != B:
+            S, D, dev = self.S, max(1, self.max_depth), self.device
+            m = B * S
+            sub = torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(S)
+            sn = torch.arange(S, dtype=torch.int32, device=dev).repeat(B)
+            self.pairs = torch.stack([sub, sn], dim=1).contiguous()
+            self.key = torch.empty((m, 2), dtype=torch.int64, device=dev)
+            self.mask = torch.empty((m, 3), dtype=torch.uint8, device=dev)
+            self.entry = torch.empty((m,), dtype=torch.int32, device=dev)
+            self.is_new = torch.empty((m,), dtype=torch.uint8, device=dev)
+            self.moves = torch.empty((m,), dtype=torch.uint8, device=dev)
+            self.est = torch.empty((m,), dtype=torch.float32, device=dev)
+            self.pmf = torch.empty((m, 3), dtype=torch.float32, device=dev)
+            self.path_entry = torch.empty((m, D), dtype=torch.int32, device=dev)
+            self.path_move = torch.empty((m, D), dtype=torch.uint8, device=dev)
+            self.path_len = torch.zeros((m,), dtype=torch.int32, device=dev)
+            self.alive_rows = torch.empty((B, S), dtype=torch.uint8, device=dev)
+            self.done = torch.empty((B,), dtype=torch.uint8, device=dev)
+            self.rewards = torch.empty((m,), dtype=torch.int8, device=dev)
+            self.cmp_idx = torch.empty((m,), dtype=torch.int32, device=dev)
+            self.cmp_cnt = torch.empty((1,), dtype=torch.int32, device=dev)
+            self.cmp_scratch = torch.empty((self.L.snk_compact_scratch_elems(m),), dtype=torch.int32, device=dev)
+            self.planes = None
+            self._bufs_B = B
+        return par, B
+
+    def _planes(self, n):
+        if self.planes is None or self.planes.shape[0] < n:
+            cap = max(n, 1024)
+            self.planes = torch.empty((cap, 2 * self.H - 1, 2 * self.W - 1, 3), dtype=torch.float32, device=self.device)
+        return self.planes[:n]
+
+    def _next_ctr(self):
+        self.draw_ctr += 1
+        return self.draw_ctr & 0xFFFFFFFF, (self.draw_ctr >> 32) & 0xFFFFFFFF
+
+    def clear(self):
+        """Agent.clear (agent.py:140-147)"""
+        if self.tt is not None:
+            self.tt.clear()
+
+    # ---- one root turn: agent.py:25-99 -----------------------------------------------------------
+    def search(self, root, live_slots, root_alive):
+        """root: Engine holding the root games; live_slots int32 cuda [G]; root_alive uint8 cuda [G,S].
+        Returns (V [G,S,3] float32 cuda -- cached_values[first_key] per root snake, moves [G,S] uint8 cuda)."""
+        L, S, st = self.L, self.S, _stream()
+        G = int(live_slots.shape[0])
+        par, B = self._ensure(G, root.health_dec)
+        m = B * S
+        D = self.path_entry.shape[1]
+        self.now += 1                                           # "for key in cache_hit: cache_hit[key] += 1" (agent.py:30-31)
+        n_alive = root_alive.sum(dim=1, dtype=torch.int32)
+        depth = self.max_depth - 2 * (n_alive - 2)              # agent.py:45
+        sub_depth = depth.repeat_interleave(par)
+        n_ticks = max(1, int(depth.max().item()))
+        epochs = self.max_breadth // par                        # agent.py:37
+        tt = self.tt.h
+        seq = int(self.sequential)
+        for _ in range(epochs):
+            root.clone_to(self.roll, src_slots=live_slots, n=G, fanout=par)       # game.subgame (agent.py:46-50)
+            self.path_len.zero_()
+            sub_active = torch.ones((B,), dtype=torch.bool, device=self.device)
+            for tick in range(1, n_ticks + 1):
+                self.roll.alive(n=B, out=self.alive_rows)
+                row_active = (self.alive_rows.bool() & sub_active[:, None]).reshape(-1).to(torch.uint8)
+                self.roll.observe(self.pairs, m, None, self.mask, self.key, legacy_mask=self.legacy_mask)
+                check(L.snk_tt_lookup_insert(tt, _ptr(self.key), _ptr(row_active), m, self.now, self.max_depth,
+                                             _ptr(self.entry), _ptr(self.is_new), st))
+                check(L.snk_compact_flags(_ptr(self.is_new), m, _ptr(self.cmp_idx), _ptr(self.cmp_cnt),
+                                          _ptr(self.cmp_scratch), st))
+                n_eval = int(self.cmp_cnt.item())               # the one host read-back of the tick
+                if n_eval:
+                    idx = self.cmp_idx[:n_eval]
+                    eval_pairs = self.pairs.index_select(0, idx)
+                    planes = self._planes(n_eval)
+                    self.roll.observe(eval_pairs, n_eval, planes, None, None)
+                    q = self.evaluate(planes, self.mask.index_select(0, idx))   # nnet.v(all_states) (agent.py:190)
+                    check(L.snk_tt_set_priors(tt, _ptr(self.entry), _ptr(idx), n_eval, _ptr(q.contiguous()), st))
+                    self.stats["net_evals"] += n_eval
+                rank, n_rows = None, 0
+                if self.tape is not None:
+                    rank = (torch.cumsum(row_active, 0, dtype=torch.int32) - 1).contiguous()
+                    n_rows = int(row_active.sum().item())
+                c0, c1 = self._next_ctr()
+                check(L.snk_mcts_select(tt, _ptr(self.entry), m, self.base, _ptr(self.tape), _ptr(rank), self.tape_pos,
+                                        self.seed, c0, c1, _ptr(self.moves), _ptr(self.est), _ptr(self.pmf),
+                                        _ptr(self.path_entry), _ptr(self.path_move), _ptr(self.path_len), D, st))
+                self.tape_pos += n_rows
+                check(L.snk_mcts_backup(tt, _ptr(self.entry), m, _ptr(self.est), _ptr(self.pmf), _ptr(self.path_entry),
+                                        _ptr(self.path_move), _ptr(self.path_len), D, seq, st))
+                # tic every live sub-game (mp_game_runner.py:104-106); retired ones are frozen by giving them
+                # to the kernel as already-inactive slots: stepping is harmless for ended games, and
+                # depth-retired games must not move, so step only the active ones.
+                act_idx = torch.nonzero(sub_active).to(torch.int32).reshape(-1)
+                if act_idx.numel() == B:
+                    self.roll.step(self.moves, n=B, done=self.done)
+                    done = self.done.bool()
+                else:
+                    mv = self.moves.view(B, S).index_select(0, act_idx).contiguous()
+                    dn = torch.empty((act_idx.numel(),), dtype=torch.uint8, device=self.device)
+                    if act_idx.numel():
+                        self.roll.step(mv, slots=act_idx.contiguous(), done=dn)
+                    done = torch.zeros((B,), dtype=torch.bool, device=self.device)
+                    done[act_idx.long()] = dn.bool()
+                self.stats["sim_steps"] += int(act_idx.numel())
+                sub_active = sub_active & ~(done | (tick >= sub_depth))          # mp_game_runner.py:108-113
+                self.stats["rollout_ticks"] += 1
+            check(L.snk_engine_rewards(self.roll.h, None, B, _ptr(self.rewards), st))
+            check(L.snk_mcts_terminal_backup(tt, _ptr(self.rewards), m, _ptr(self.path_entry), _ptr(self.path_move),
+                                             _ptr(self.path_len), D, seq, st))   # agent.py:60-72
+        # V[i] = cached_values[first_key] (agent.py:74-87): the root observation's entry, from clone 0 of each game
+        first = self.path_entry.view(G, par, S, D)[:, 0, :, 0].contiguous().reshape(-1)
+        root_rows_alive = root_alive.reshape(-1).contiguous()
+        first = torch.where(root_rows_alive.bool(), first, torch.full_like(first, -1))
+        V = torch.empty((G * S, 3), dtype=torch.float32, device=self.device)
+        check(L.snk_tt_read_q(tt, _ptr(first), 1, G * S, _ptr(V), st))
+        moves = torch.empty((G * S,), dtype=torch.uint8, device=self.device)
+        rank, n_rows = None, 0
+        if self.tape is not None and self.training:
+            rank = (torch.cumsum(root_rows_alive, 0, dtype=torch.int32) - 1).contiguous()
+            n_rows = int(root_rows_alive.sum().item())
+        c0, c1 = self._next_ctr()
+        check(L.snk_mcts_root_moves(_ptr(V), _ptr(root_rows_alive), G * S, self.base, int(self.training),
+                                    _ptr(self.tape) if self.training else None, _ptr(rank), self.tape_pos, self.seed, c0, c1,
+                                    _ptr(moves), st))
+        self.tape_pos += n_rows
+        return V.view(G, S, 3), moves.view(G, S)
+
+    def end_of_turn(self):
+        """RAM recycle (agent.py:101-110).  Stale entries already read as misses; here they are dropped
+        physically when the table is more than half full (and the table doubles if the survivors still
+        fill more than half of it)."""
+        cap, occ, ovf = self.tt.status()
+        if ovf:
+            raise EngineError("transposition table overflowed; raise tt_capacity")
+        if occ * 2 > cap:
+            self.tt.rebuild(cap, self.now, self.max_depth)
+            cap, occ, _ = self.tt.status()
+            if occ * 2 > cap:
+                self.tt.rebuild(cap * 2, self.now, self.max_depth)

@@ -1,0 +1,130 @@
+"""QNet: the reference's Q-network (alpha_nnet.py:19-56) as a list of Keras-layout weight arrays
+plus a forward pass made of the hand-written HIP kernels of csrc/net.hip.
+
+Weight list order (= Keras ``model.get_weights()`` order of the reference graph):
+  stem kernel (3,3,3,k), stem BN gamma/beta/mean/var,
+  for each of the 2*blocks residual convs: kernel (3,3,k,k), BN gamma/beta/mean/var,
+  head kernel (1,1,k,1), head BN (4 x (1,)), dense kernel (h*w, 128), bias, dense_1 kernel (128, 3), bias.
+"""
+import math
+
+import numpy as np
+import torch
+
+from ._lib import lib, check, EngineError
+
+BN_EPS = 1e-3        # Keras BatchNormalization default epsilon (alpha_nnet.py:22)
+K_FILTERS = 128      # alpha_nnet.py:17
+
+
+def glorot_uniform_weights(input_shape, blocks=4, seed=0):
+    """Keras defaults: glorot_uniform kernels, zero biases, BN gamma 1 / beta 0 / mean 0 / var 1."""
+    g = torch.Generator().manual_seed(seed)
+    h, w, c = input_shape
+    k = K_FILTERS
+
+    def glorot(shape, fan_in, fan_out):
+        lim = math.sqrt(6.0 / (fan_in + fan_out))
+        return ((torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1) * lim).numpy()
+
+    def bn(n):
+        return [np.ones(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32), np.ones(n, np.float32)]
+    ws = [glorot((3, 3, c, k), 9 * c, 9 * k)] + bn(k)
+    for _ in range(2 * blocks):
+        ws += [glorot((3, 3, k, k), 9 * k, 9 * k)] + bn(k)
+    ws += [glorot((1, 1, k, 1), k, 1)] + bn(1)
+    ws += [glorot((h * w, 128), h * w, 128), np.zeros(128, np.float32)]
+    ws += [glorot((128, 3), 128, 3), np.zeros(3, np.float32)]
+    return ws
+
+
+def n_blocks_of(weights):
+    return (len(weights) - 14) // 10
+
+
+class QNet:
+    def __init__(self, weights, input_shape, device=0, max_chunk=4096):
+        if not torch.cuda.is_available():
+            raise EngineError("snake_engine.QNet needs an MI355X; there is no CPU fallback")
+        self.L = lib()
+        self.device = torch.device("cuda", device)
+        self.input_shape = tuple(int(v) for v in input_shape)
+        self.h, self.w, self.cin = self.input_shape
+        assert self.cin == 3
+        self.max_chunk = int(max_chunk)
+        self._ws = None
+        self.set_weights(weights)
+
+    # ---- weights -----------------------------------------------------------------------------
+    def set_weights(self, weights):
+        self.weights = [np.ascontiguousarray(w, np.float32) for w in weights]
+        self.blocks = n_blocks_of(self.weights)
+        dev = self.device
+        t = [torch.as_tensor(w, device=dev) for w in self.weights]
+
+        def fold(g, b, m, v):
+            sc = g / torch.sqrt(v + BN_EPS)
+            return sc.contiguous(), (b - m * sc).contiguous()
+        self.stem_w = t[0].contiguous()
+        self.stem_sc, self.stem_sh = fold(*t[1:5])
+        self.conv_wT, self.conv_sc, self.conv_sh = [], [], []
+        st = torch.cuda.current_stream().cuda_stream
+        for i in range(2 * self.blocks):
+            base = 5 + 5 * i
+            wT = torch.empty(9 * 128 * 128, dtype=torch.float32, device=dev)
+            check(self.L.snk_conv3x3_prepare_weights(t[base].contiguous().data_ptr(), wT.data_ptr(), st))
+            sc, sh = fold(*t[base + 1:base + 5])
+            self.conv_wT.append(wT); self.conv_sc.append(sc); self.conv_sh.append(sh)
+        base = 5 + 10 * self.blocks
+        self.head_w = t[base].reshape(128).contiguous()
+        hs, hb = fold(*t[base + 1:base + 5])
+        self.head_s, self.head_b = float(hs.item()), float(hb.item())
+        self.fc1_w, self.fc1_b = t[base + 5].contiguous(), t[base + 6].contiguous()
+        self.fc2_w, self.fc2_b = t[base + 7].contiguous(), t[base + 8].contiguous()
+        torch.cuda.current_stream().synchronize()
+
+    def get_weights(self):
+        return [w.copy() for w in self.weights]
+
+    # ---- forward -------------------------------------------------------------------------------
+    def _workspace(self, n):
+        if self._ws is None or self._ws[0].shape[0] < n:
+            shape = (n, self.h, self.w, 128)
+            self._ws = [torch.empty(shape, dtype=torch.float32, device=self.device) for _ in range(3)]
+        return self._ws
+
+    def forward(self, planes, mask=None, out=None):
+        """planes: cuda float32 [n, h, w, 3] (NHWC, contiguous); mask: optional cuda uint8 [n, 3].
+        Returns cuda float32 [n, 3] = AlphaNNet.v's output (obstacle entries -1.0 when mask is given)."""
+        assert planes.is_cuda and planes.dtype == torch.float32 and planes.is_contiguous()
+        n = planes.shape[0]
+        assert tuple(planes.shape[1:]) == self.input_shape, planes.shape
+        if out is None:
+            out = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        if n == 0:
+            return out
+        st = torch.cuda.current_stream().cuda_stream
+        L, h, w = self.L, self.h, self.w
+        a, b, c = self._workspace(min(n, self.max_chunk))
+        for s0 in range(0, n, self.max_chunk):
+            m = min(self.max_chunk, n - s0)
+            x = planes[s0:s0 + m]
+            check(L.snk_stem_conv_bn_relu_f32(x.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(),
+                                              self.stem_sh.data_ptr(), a.data_ptr(), m, h, w, st))
+            cur, t1, t2 = a, b, c
+            for blk in range(self.blocks):
+                i0, i1 = 2 * blk, 2 * blk + 1
+                check(L.snk_conv3x3_bn_f32(cur.data_ptr(), self.conv_wT[i0].data_ptr(), self.conv_sc[i0].data_ptr(),
+                                           self.conv_sh[i0].data_ptr(), None, t1.data_ptr(), m, h, w, 1, st))
+                check(L.snk_conv3x3_bn_f32(t1.data_ptr(), self.conv_wT[i1].data_ptr(), self.conv_sc[i1].data_ptr(),
+                                           self.conv_sh[i1].data_ptr(), cur.data_ptr(), t2.data_ptr(), m, h, w, 1, st))
+                cur, t2 = t2, cur
+            mk = None if mask is None else mask[s0:s0 + m]
+            check(L.snk_head_f32(cur.data_ptr(), self.head_w.data_ptr(), self.head_s, self.head_b,
+                                 self.fc1_w.data_ptr(), self.fc1_b.data_ptr(), self.fc2_w.data_ptr(), self.fc2_b.data_ptr(),
+                                 0 if mk is None else mk.data_ptr(), out[s0:s0 + m].data_ptr(), m, h, w, st))
+        return out
+
+    def flops_per_state(self):
+        hw = self.h * self.w
+        return 2 * (hw * (27 * 128 + 2 * self.blocks * 9 * 128 * 128 + 128) + hw * 128 + 128 * 3)

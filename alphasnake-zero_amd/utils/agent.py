@@ -1,0 +1,186 @@
+"""Drop-in mirror of the reference's ``utils.agent`` (agent.py).
+
+``Agent`` keeps the constructor, ``make_moves(games, ids) -> moves``, ``records`` / ``values`` /
+``clear()``, ``softermax`` and ``argmaxs`` (agent.py:9-147).  The MCTS itself (sub-game clones,
+lock-step rollouts, cache de-duplication, batched net calls, in-rollout and terminal back-ups)
+runs on the GPU: see snake_engine/mcts.py and csrc/mcts.hip.  The four cache dicts of the reference
+live in one HBM hash table; ``cached_values`` etc. are read-only views that report its size.
+"""
+from collections.abc import Sequence
+
+import numpy as np
+import torch
+
+from snake_engine import Engine, EngineError
+from snake_engine._lib import lib, check
+from snake_engine.mcts import DeviceMCTS
+
+
+class _CacheView:
+    """len() of the device transposition table (the reference's dict of the same name)"""
+
+    def __init__(self, agent):
+        self._agent = agent
+
+    def __len__(self):
+        m = self._agent._mcts
+        return 0 if m is None or m.tt is None else int(m.tt.status()[1])
+
+
+class _Records(Sequence):
+    """Agent.records (agent.py:96): every root observation, materialised on demand.  The states are
+    stored as compact game snapshots in HBM (one per game and turn) and encoded by the observe kernel
+    when read, so 10^6 records cost 0.6 GB instead of 5.3 GB."""
+
+    def __init__(self, agent):
+        self._a = agent
+
+    def __len__(self):
+        return self._a._n_records
+
+    def fetch(self, indices):
+        a = self._a
+        idx = np.asarray(indices, np.int64)
+        pairs = a._rec_pairs_host()[idx]
+        planes, _, _ = a._rec_engine.observe_all(pairs.astype(np.int32), want_mask=False, want_key=False)
+        return planes.cpu().numpy()
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return list(self.fetch(range(*i.indices(len(self)))))
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        return self.fetch([i])[0]
+
+
+class _Values(Sequence):
+    def __init__(self, agent):
+        self._a = agent
+
+    def __len__(self):
+        return self._a._n_records
+
+    def __getitem__(self, i):
+        v = self._a._values_host()
+        if isinstance(i, slice):
+            return list(v[i])
+        return v[i]
+
+
+class Agent:
+
+    def __init__(self, nnet, softmax_base=100, training=False, max_MCTS_depth=8, max_MCTS_breadth=128,
+                 seed=None, sequential=False, tape_u=None, tt_capacity=None):
+        self.nnet = nnet
+        self.softmax_base = softmax_base
+        self.training = training
+        self.max_MCTS_depth = max_MCTS_depth
+        self.max_MCTS_breadth = max_MCTS_breadth
+        self._seed = int(np.random.randint(1 << 62)) if seed is None else int(seed)
+        self._sequential, self._tape_u, self._tt_capacity = sequential, tape_u, tt_capacity
+        self._mcts = None
+        self.cached_values = _CacheView(self)
+        self.total_rewards = _CacheView(self)
+        self.visit_cnts = _CacheView(self)
+        self.cache_hit = _CacheView(self)
+        self._reset_records()
+        # record data for training
+        if training:
+            self.records = _Records(self)
+            self.values = _Values(self)
+
+    # ---- records arena -----------------------------------------------------------------------------
+    def _reset_records(self):
+        self._n_records = 0
+        self._rec_engine = None
+        self._rec_used = 0
+        self._rec_pairs = []        # per turn: int32 [k,2] (arena slot, snake id)
+        self._rec_values = []       # per turn: float32 [k,3]
+        self._rec_pairs_cat = None
+        self._rec_values_cat = None
+
+    def _rec_pairs_host(self):
+        if self._rec_pairs_cat is None or len(self._rec_pairs_cat) != self._n_records:
+            self._rec_pairs_cat = np.concatenate(self._rec_pairs) if self._rec_pairs else np.zeros((0, 2), np.int32)
+        return self._rec_pairs_cat
+
+    def _values_host(self):
+        if self._rec_values_cat is None or len(self._rec_values_cat) != self._n_records:
+            self._rec_values_cat = np.concatenate(self._rec_values) if self._rec_values else np.zeros((0, 3), np.float32)
+        return self._rec_values_cat
+
+    def _record(self, eng, d_slots, alive_h, V):
+        G = len(alive_h)
+        if self._rec_engine is None or self._rec_used + G > self._rec_engine.n_slots:
+            new_cap = max(4 * G, 2 * (self._rec_used + G), 256)
+            new = Engine(new_cap, eng.H, eng.W, eng.S, eng.health_dec, 0.0)
+            if self._rec_engine is not None and self._rec_used:
+                self._rec_engine.clone_to(new, n=self._rec_used, fanout=1)
+            self._rec_engine = new
+        dst = torch.arange(self._rec_used, self._rec_used + G, dtype=torch.int32, device=eng.device)
+        eng.clone_to(self._rec_engine, src_slots=d_slots, dst_slots=dst, fanout=1)
+        gi, si = np.nonzero(alive_h)
+        self._rec_pairs.append(np.stack([self._rec_used + gi, si], axis=1).astype(np.int32))
+        self._rec_values.append(V.cpu().numpy()[gi, si].astype(np.float32))
+        self._rec_used += G
+        self._n_records += len(gi)
+
+    # ---- the net behind the search ------------------------------------------------------------------
+    def _evaluate(self, planes, mask):
+        nnet = self.nnet
+        if hasattr(nnet, "v_device"):
+            return nnet.v_device(planes, mask)
+        V = np.asarray(nnet.v(list(planes.cpu().numpy())), np.float32)      # any object with the reference's .v(X)
+        return torch.as_tensor(V, device=planes.device)
+
+    def make_moves(self, games, ids):
+        """agent.py:25-111.  ``games``: the runner's dict of engine-backed Games; ``ids``: [(game_id, snake_id)]
+        in dict order x alive ids ascending (what MPGameRunner.run passes)."""
+        eng = getattr(games, "engine", None)
+        if eng is None:
+            engs = {id(g._engine) for g in games.values()}
+            if len(engs) != 1:
+                raise TypeError("Agent.make_moves needs games that live in one snake_engine.Engine (MPGameRunner.games)")
+            eng = next(iter(games.values()))._engine
+        if self._mcts is None:
+            self._mcts = DeviceMCTS(self._evaluate, eng.H, eng.W, eng.S, self.softmax_base, self.training,
+                                    self.max_MCTS_depth, self.max_MCTS_breadth, seed=self._seed,
+                                    device=eng.device.index or 0, sequential=self._sequential, tape_u=self._tape_u,
+                                    tt_capacity=self._tt_capacity)
+        slots = np.fromiter((g._slot for g in games.values()), np.int32, len(games))
+        d_slots = torch.as_tensor(slots, device=eng.device)
+        alive = eng.alive(slots=d_slots)
+        V, moves = self._mcts.search(eng, d_slots, alive)
+        alive_h = alive.cpu().numpy().astype(bool)
+        if self.training:
+            self._record(eng, d_slots, alive_h, V)
+        self._mcts.end_of_turn()
+        out = moves.cpu().numpy()[alive_h].tolist()
+        if len(out) != len(ids):
+            raise EngineError(f"ids has {len(ids)} entries but the engine has {len(out)} alive snakes")
+        return out
+
+    # a softmax function with customized base (agent.py:114-122), evaluated by the device kernel
+    def softermax(self, z):
+        return self._soft_arg(np.asarray(z, np.float32).reshape(1, 3))[0][0]
+
+    def argmaxs(self, Z):
+        if len(Z) == 0:
+            return []
+        return self._soft_arg(np.asarray(Z, np.float32).reshape(-1, 3))[1].tolist()
+
+    def _soft_arg(self, z):
+        zt = torch.as_tensor(np.ascontiguousarray(z), device="cuda")
+        pmf = torch.empty_like(zt)
+        am = torch.empty((zt.shape[0],), dtype=torch.uint8, device="cuda")
+        check(lib().snk_softermax_argmax(zt.data_ptr(), zt.shape[0], float(self.softmax_base), pmf.data_ptr(),
+                                         am.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        return pmf.cpu().numpy(), am.cpu().numpy().astype(int)
+
+    # clear memory (agent.py:140-147)
+    def clear(self):
+        if self._mcts is not None:
+            self._mcts.clear()
+        self._reset_records()

@@ -5,7 +5,7 @@
  * The reference (Fool-Yang/AlphaSnake-Zero) has no FFI: its hot path is a set of Python
  * classes.  This header is the drop-in boundary a binding for that path needs; every entry
  * point names the reference code it replaces (paths relative to /root/reference/code/utils/).
- * The Python mirror of the reference's class API (alphasnake-zero_amd/utils/*.py) calls
+ * The Python mirror of the reference's class API (alphasnake-zero_amd/utils/) calls
  * exactly these symbols through ctypes; INTEGRATION.md shows the stub.
  *
  * Conventions
@@ -129,6 +129,89 @@ int snk_engine_sum_counters_sync(const snk_engine *e, const int32_t *d_slots, in
 int snk_compact_scratch_elems(int n);
 int snk_compact_flags(const uint8_t *d_flags, int n, int32_t *d_out, int32_t *d_count,
                       int32_t *d_scratch, void *stream);
+
+/* ---- AlphaNNet.v (alpha_nnet.py:19-56, 61-76): the Q-net's inference layers ---------------
+ * Activations are NHWC float32: d_x[n_images][height][width][C], C = 128 (3 for the stem input).
+ * Batch-norm (inference form, alpha_nnet.py:22 ...) is folded by the caller into per-channel
+ * scale = gamma / sqrt(var + 1e-3), shift = beta - mean * scale.
+ *
+ * snk_conv3x3_prepare_weights: Keras Conv2D kernel (kh, kw, cin, cout) = (3,3,128,128) ->
+ *   the K-contiguous (tap, cout, cin) layout the MFMA kernel streams.
+ * snk_conv3x3_bn_f32: out = [relu]( conv3x3_same(x, w) * scale + shift [+ residual] ), the body of
+ *   a residual block (alpha_nnet.py:25-47) as an implicit GEMM on v_mfma_f32_32x32x2_f32.
+ * snk_stem_conv_bn_relu_f32: the first layer, 3 -> 128 channels (alpha_nnet.py:21-22); d_w is the
+ *   Keras kernel (3,3,3,128) unchanged.
+ * snk_head_f32: conv1x1 128 -> 1 + BN + ReLU, Flatten, Dense(128) + ReLU, Dense(3) + tanh
+ *   (alpha_nnet.py:49-54); d_fc1_w (height*width, 128) and d_fc2_w (128, 3) are Keras Dense kernels.
+ *   d_mask (optional) uint8[n][3]: entries set to 1 overwrite Q with -1.0 (alpha_nnet.py:67-72).  */
+int snk_conv3x3_prepare_weights(const float *d_w_hwio, float *d_wT, void *stream);
+int snk_conv3x3_bn_f32(const float *d_x, const float *d_wT, const float *d_scale, const float *d_shift,
+                       const float *d_residual, float *d_out, int n_images, int height, int width,
+                       int relu, void *stream);
+int snk_stem_conv_bn_relu_f32(const float *d_x, const float *d_w, const float *d_scale,
+                              const float *d_shift, float *d_out, int n_images, int height, int width,
+                              void *stream);
+int snk_head_f32(const float *d_x, const float *d_w1x1, float bn_scale, float bn_shift,
+                 const float *d_fc1_w, const float *d_fc1_b, const float *d_fc2_w, const float *d_fc2_b,
+                 const uint8_t *d_mask, float *d_q, int n_images, int height, int width, void *stream);
+
+/* ---- the Agent-wide transposition cache (agent.py:16-19, 151-157) ------------------------
+ * cached_values / total_rewards / visit_cnts / cache_hit as one open-addressing table in HBM keyed
+ * by the 128-bit observation digest (snk_engine_observe d_key).  capacity: power of two.
+ * An "entry" is a uint32 table slot; 0xFFFFFFFF = none (dead snake / inactive row).            */
+typedef struct snk_tt snk_tt;
+int snk_tt_create(snk_tt **out, uint64_t capacity, int device);
+int snk_tt_destroy(snk_tt *t);
+int snk_tt_clear(snk_tt *t, void *stream);                              /* Agent.clear, agent.py:140-147 */
+int snk_tt_status_sync(snk_tt *t, int64_t *capacity, int64_t *occupied, int *overflowed);
+/* eviction (agent.py:101-110): keeps entries with now_turn - last_touch <= max_age, re-hashed into a
+ * table of new_capacity.  Entry indices change: call between root turns only.                    */
+int snk_tt_rebuild_sync(snk_tt *t, uint64_t new_capacity, int now_turn, int max_age);
+/* MCTSAgent.make_moves "get states without duplicates" (agent.py:170-186): find-or-insert m keys.
+ * d_active (optional) uint8[m]: 0 rows are skipped (entry = none).  d_is_new[i] = 1 for exactly one
+ * row of every key that has no live entry (never seen, or evicted: now_turn - touch > max_age + 1):
+ * that row's observation must be evaluated by the net.  Every found entry is touched
+ * (cache_hit[key] = 0, agent.py:185).                                                            */
+int snk_tt_lookup_insert(snk_tt *t, const uint64_t *d_key, const uint8_t *d_active, int m, int now_turn,
+                         int max_age, uint32_t *d_entry, uint8_t *d_is_new, void *stream);
+/* new entries (agent.py:193-201): total = d_q[j], visit = 1,1,1 for entry d_entry[d_idx ? d_idx[j] : j] */
+int snk_tt_set_priors(snk_tt *t, const uint32_t *d_entry, const int32_t *d_idx, int n, const float *d_q,
+                      void *stream);
+/* d_q[i] = total/visit of entry d_entry[i * entry_stride]  (cached_values[first_key], agent.py:83-87) */
+int snk_tt_read_q(snk_tt *t, const uint32_t *d_entry, int entry_stride, int m, float *d_q, void *stream);
+
+/* ---- rollout tick of MCTSAgent.make_moves (agent.py:203-222) -----------------------------
+ * Paths: d_path_entry uint32[m][path_depth], d_path_move uint8[m][path_depth], d_path_len int32[m]
+ * are MCTSAgent.keys / .moves (agent.py:158-159) for row i = (subgame, snake).
+ * Randomness: d_tape_u == NULL -> counter-based Philox keyed by (seed; row, ctr0, ctr1); else row i
+ * uses the recorded uniform d_tape_u[tape_base + (d_rank ? d_rank[i] : i)] (parity runs: the draw
+ * numpy.random.choice would have consumed).
+ * snk_mcts_select: pmf = softermax(Q), move ~ pmf, est = pmf . Q, appends (entry, move) at
+ *   path[len] (len is advanced by snk_mcts_backup).  d_est / d_pmf optional outputs.
+ * snk_mcts_backup: every ancestor edge: visit += 1, total += est (agent.py:208-220).
+ *   sequential = 0: one thread per row, float atomics, est as computed by select;
+ *   sequential = 1: the reference's order (rows ascending, live Q re-read, needs d_pmf), one thread.
+ * snk_mcts_terminal_backup: rows with reward +1/-1 add it along their whole path (agent.py:60-72);
+ *   d_rewards int8[m], 0 = None.                                                                 */
+int snk_mcts_select(snk_tt *t, const uint32_t *d_entry, int m, float softmax_base, const double *d_tape_u,
+                    const int32_t *d_rank, int64_t tape_base, uint64_t seed, uint32_t ctr0, uint32_t ctr1,
+                    uint8_t *d_moves, float *d_est, float *d_pmf, uint32_t *d_path_entry,
+                    uint8_t *d_path_move, int32_t *d_path_len, int path_depth, void *stream);
+int snk_mcts_backup(snk_tt *t, const uint32_t *d_entry, int m, const float *d_est, const float *d_pmf,
+                    uint32_t *d_path_entry, uint8_t *d_path_move, int32_t *d_path_len, int path_depth,
+                    int sequential, void *stream);
+int snk_mcts_terminal_backup(snk_tt *t, const int8_t *d_rewards, int m, uint32_t *d_path_entry,
+                             uint8_t *d_path_move, int32_t *d_path_len, int path_depth, int sequential,
+                             void *stream);
+/* root decision (agent.py:89-99): training -> move ~ softermax(V), else Agent.argmaxs(V) */
+int snk_mcts_root_moves(const float *d_V, const uint8_t *d_alive, int m, float softmax_base, int training,
+                        const double *d_tape_u, const int32_t *d_rank, int64_t tape_base, uint64_t seed,
+                        uint32_t ctr0, uint32_t ctr1, uint8_t *d_moves, void *stream);
+/* Agent.softermax / Agent.argmaxs on m rows of 3 (agent.py:114-137) */
+int snk_softermax_argmax(const float *d_z, int m, float softmax_base, float *d_pmf, uint8_t *d_argmax,
+                         void *stream);
+/* Game.rewards of n games as int8[n][S]: 0 None, +1, -1 (mp_game_runner.py:110) */
+int snk_engine_rewards(const snk_engine *e, const int32_t *d_slots, int n, int8_t *d_rewards, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,251 @@
+"""GPU tests of the device MCTS (csrc/mcts.hip + snake_engine/mcts.py) and of the drop-in classes
+(utils.agent.Agent, utils.mp_game_runner.MPGameRunner) against runs recorded from the reference and
+against the CPU oracle.  Boards, masks, moves, rewards, counters, cache de-duplication counts: exact.
+MCTS statistics (float32 sums whose libm / summation order differs from NumPy's): |dQ| <= 1e-5 in the
+sequential parity mode; the production mode (atomics) is checked for closeness and invariants."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available()
+    import snake_engine
+    return torch, snake_engine
+
+
+def stub_evaluate(planes, mask):
+    """deterministic stub net (oracle/obs_key.py: stub_q) -- test infrastructure, evaluated on the host"""
+    import torch
+    from oracle.obs_key import stub_q
+    q = stub_q(planes.cpu().numpy())
+    assert np.array_equal(q == -1.0, mask.cpu().numpy().astype(bool)), "device obstacle mask != alpha_nnet.py:63-76"
+    return torch.as_tensor(q, device=planes.device)
+
+
+class StubNNet:
+    def v_device(self, planes, mask):
+        return stub_evaluate(planes, mask)
+
+
+def _golden_engine(se, z, chance=0.15):
+    from snake_engine.engine import state_from_compact
+    H, W, S, hd, n = int(z["H"]), int(z["W"]), int(z["S"]), int(z["hd"]), int(z["n_games"])
+    eng = se.Engine(n, H, W, S, hd, chance)
+    sts = []
+    for g in range(n):
+        st = {k: z["init_" + k][g] for k in ("alive", "health", "length", "dir", "nodes", "food", "rewards", "counters")}
+        sts.append(state_from_compact(H, W, S, st))
+    eng.import_states(sts)
+    return eng, (H, W, S, hd, n)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "tiny_greedybase"])
+def test_sequential_mode_replays_the_reference_run(env, tag):
+    torch, se = env
+    from snake_engine.mcts import DeviceMCTS
+    z = load_golden(f"mcts_{tag}.npz")
+    eng, (H, W, S, hd, n) = _golden_engine(se, z)
+    mcts = DeviceMCTS(stub_evaluate, H, W, S, int(z["base"]), True, int(z["depth"]), int(z["breadth"]),
+                      sequential=True, tape_u=z["tape_u"], tt_capacity=1 << 16)
+    live = np.arange(n, dtype=np.int32)
+    rec_digest = []
+    for t in range(int(z["n_turns"])):
+        d_slots = torch.as_tensor(live, device="cuda")
+        alive = eng.alive(slots=d_slots)
+        alive_h = alive.cpu().numpy().astype(bool)
+        evals0 = mcts.stats["net_evals"]
+        V, moves = mcts.search(eng, d_slots, alive)
+        gi, si = np.nonzero(alive_h)
+        ids = [[int(live[g]), int(s)] for g, s in zip(gi, si)]
+        assert ids == z[f"t{t}_ids"].tolist(), f"turn {t}: ids"
+        Vh = V.cpu().numpy()[gi, si]
+        assert np.abs(Vh - z[f"t{t}_V"]).max() <= 1e-5, (t, np.abs(Vh - z[f"t{t}_V"]).max())
+        assert moves.cpu().numpy()[gi, si].tolist() == z[f"t{t}_moves"].tolist(), f"turn {t}: moves"
+        assert mcts.stats["net_evals"] - evals0 == z["turn_evals"][t], f"turn {t}: net evaluations (cache de-duplication)"
+        assert mcts.tape_pos == z["turn_tape_pos"][t], f"turn {t}: draws consumed"
+        pairs = np.stack([live[gi], si], axis=1).astype(np.int32)
+        planes, _, _ = eng.observe_all(pairs, want_mask=False, want_key=False)
+        rec_digest += [hashlib.blake2b(p.tobytes(), digest_size=16).digest() for p in planes.cpu().numpy()]
+        mcts.end_of_turn()
+        done = eng.new((len(live),), torch.uint8, 0)
+        tape = torch.as_tensor(z["turn_spawn"][t][live].astype(np.int16), device="cuda")
+        eng.step(moves.contiguous(), slots=d_slots, spawn_tape=tape, done=done)
+        live = live[~done.cpu().numpy().astype(bool)]
+    assert rec_digest == [d.tobytes() for d in z["records_digest"]]
+    assert mcts.tape_pos == len(z["tape_u"])
+
+
+def test_production_mode_is_close_to_sequential_on_one_turn(env):
+    """same taped draws, back-ups by float atomics with pre-tick Q instead of the sequential order"""
+    torch, se = env
+    from snake_engine.mcts import DeviceMCTS
+    z = load_golden("mcts_tiny.npz")
+    res = []
+    for seq in (True, False):
+        eng, (H, W, S, hd, n) = _golden_engine(se, z)
+        mcts = DeviceMCTS(stub_evaluate, H, W, S, int(z["base"]), True, int(z["depth"]), int(z["breadth"]),
+                          sequential=seq, tape_u=z["tape_u"], tt_capacity=1 << 16)
+        d_slots = torch.arange(n, dtype=torch.int32, device="cuda")
+        V, moves = mcts.search(eng, d_slots, eng.alive(slots=d_slots))
+        res.append(V.cpu().numpy())
+    assert np.abs(res[0] - res[1]).max() < 0.05, np.abs(res[0] - res[1]).max()
+
+
+def test_transposition_table_semantics(env):
+    torch, se = env
+    from snake_engine._lib import lib, check
+    from snake_engine.mcts import TranspositionTable
+    L = lib()
+    st = torch.cuda.current_stream().cuda_stream
+    tt = TranspositionTable(1 << 12)
+    rng = np.random.RandomState(0)
+    base = rng.randint(1, 1 << 62, size=(700, 2)).astype(np.int64)
+    rows = base[rng.randint(0, 700, size=3000)]                 # many duplicates inside one batch
+    rows[5] = 0                                                  # dead-snake key
+    active = np.ones(3000, np.uint8); active[7] = 0
+    key = torch.as_tensor(rows, device="cuda"); act = torch.as_tensor(active, device="cuda")
+    entry = torch.empty(3000, dtype=torch.int32, device="cuda"); new = torch.empty(3000, dtype=torch.uint8, device="cuda")
+
+    def lookup(now):
+        check(L.snk_tt_lookup_insert(tt.h, key.data_ptr(), act.data_ptr(), 3000, now, 8, entry.data_ptr(), new.data_ptr(), st))
+        return entry.cpu().numpy(), new.cpu().numpy()
+    e, nw = lookup(1)
+    assert e[5] == -1 and e[7] == -1 and nw[5] == 0 and nw[7] == 0
+    valid = np.ones(3000, bool); valid[[5, 7]] = False
+    distinct = {tuple(r) for r in rows[valid]}
+    assert nw.sum() == len(distinct), "exactly one evaluation per distinct new key (agent.py:177-184)"
+    by_key = {}
+    for i in np.flatnonzero(valid):
+        by_key.setdefault(tuple(rows[i]), set()).add(int(e[i]))
+    assert all(len(v) == 1 for v in by_key.values()), "duplicates share one entry"
+    assert len({next(iter(v)) for v in by_key.values()}) == len(distinct), "distinct keys, distinct entries"
+    assert tt.status()[1] == len(distinct)
+    e2, nw2 = lookup(2)
+    assert nw2.sum() == 0 and np.array_equal(e2, e), "second sight: all hits"
+    q = torch.arange(3000 * 3, dtype=torch.float32, device="cuda").reshape(3000, 3)
+    check(L.snk_tt_set_priors(tt.h, entry.data_ptr(), None, 3000, q.data_ptr(), st))
+    # still present at now = touch + max_age + 1, evicted (a miss, re-created in place) one turn later
+    e3, nw3 = lookup(2 + 9)
+    assert nw3.sum() == 0
+    e4, nw4 = lookup(2 + 9 + 10)
+    assert nw4.sum() == len(distinct) and np.array_equal(e4, e)
+    # physical eviction keeps only entries with now - touch <= max_age
+    key2 = torch.as_tensor(rng.randint(1, 1 << 62, size=(100, 2)).astype(np.int64), device="cuda")
+    ent2 = torch.empty(100, dtype=torch.int32, device="cuda"); new2 = torch.empty(100, dtype=torch.uint8, device="cuda")
+    check(L.snk_tt_lookup_insert(tt.h, key2.data_ptr(), None, 100, 40, 8, ent2.data_ptr(), new2.data_ptr(), st))
+    check(L.snk_tt_set_priors(tt.h, ent2.data_ptr(), None, 100, q.data_ptr(), st))
+    assert tt.status()[1] == len(distinct) + 100
+    tt.rebuild(1 << 12, 40, 8)
+    assert tt.status()[1] == 100
+    check(L.snk_tt_lookup_insert(tt.h, key2.data_ptr(), None, 100, 41, 8, ent2.data_ptr(), new2.data_ptr(), st))
+    assert new2.sum().item() == 0
+    out = torch.empty((100, 3), dtype=torch.float32, device="cuda")
+    check(L.snk_tt_read_q(tt.h, ent2.data_ptr(), 1, 100, out.data_ptr(), st))
+    assert torch.equal(out, q[:100]), "statistics survive the rebuild"
+
+
+def test_softermax_argmax_tables(env):
+    torch, se = env
+    from utils.agent import Agent
+    z = load_golden("tables.npz")
+    for base in (2, 3, 10, 100):
+        ag = Agent(None, base)
+        pmf, _ = ag._soft_arg(z["z"])
+        ref = z[f"pmf_b{base}"]
+        assert np.array_equal(pmf == 0, ref == 0)
+        assert np.abs(pmf - ref).max() <= 2e-6, np.abs(pmf - ref).max()
+    ag = Agent(None)
+    assert ag.argmaxs(list(z["argmax_z"])) == z["argmax"].tolist()
+    assert np.abs(ag.softermax(z["z"][17]) - z["pmf_b100"][17]).max() <= 2e-6
+
+
+class TapedMoves:
+    """an agent with the reference's make_moves(games, ids) contract that replays recorded moves"""
+
+    def __init__(self, moves):
+        self.moves, self.t = moves, 0
+
+    def make_moves(self, games, ids):
+        out = [int(self.moves[self.t][gid][sid]) for (gid, sid) in ids]
+        assert all(m in (0, 1, 2) for m in out)
+        self.t += 1
+        return out
+
+
+def test_mp_game_runner_matches_reference_run(env):
+    torch, se = env
+    from utils.mp_game_runner import MPGameRunner
+    from snake_engine.engine import state_from_compact
+    z = load_golden("runner.npz")
+    H, W, S, hd, n = int(z["H"]), int(z["W"]), int(z["S"]), int(z["hd"]), int(z["n_games"])
+    MPGameRunner.verbose = False
+    gr = MPGameRunner(H, W, S, hd, n)
+    sts = []
+    for g in range(n):
+        st = {k: z["init_" + k][g] for k in ("alive", "health", "length", "dir", "nodes", "food", "rewards", "counters")}
+        sts.append(state_from_compact(H, W, S, st))
+    gr.engine.import_states(sts)
+    for g in gr.games.values():
+        g._dirty()
+    rewards = gr.run(TapedMoves(z["moves"]), spawn_tape=lambda turn: z["spawn"][turn - 1])
+    assert np.array_equal(np.array(rewards, np.float32), z["rewards"])
+    got = [gr.wall_collision, gr.body_collision, gr.head_collision, gr.starvation, gr.food_eaten, gr.game_length]
+    assert got == z["counters"].tolist()
+    assert len(gr.games) == 0 and gr.turns == len(z["moves"])
+
+
+def test_self_play_end_to_end_production_mode(env):
+    """Agent + MPGameRunner exactly as the trainer drives them (trainer.py:52-54, 63-75), stub net, device RNG"""
+    torch, se = env
+    from utils.agent import Agent
+    from utils.mp_game_runner import MPGameRunner
+    import random
+    random.seed(3); np.random.seed(3)
+    MPGameRunner.verbose = False
+    alice = Agent(StubNNet(), 2, True, 8, 16, seed=5)
+    gr = MPGameRunner(11, 11, 4, 9, 24, seed=7)
+    rewards = gr.run(alice)
+    assert len(rewards) == 24 and all(r is not None for r in rewards)
+    for r in rewards:
+        assert sorted(set(r)) in ([-1.0], [-1.0, 1.0]) and r.count(1.0) <= 1
+    assert gr.game_length > 3 and len(alice.records) == len(alice.values) > 24 * 4
+    x = alice.records[0]
+    assert x.shape == (21, 21, 3) and x.dtype == np.float32 and x[10, 10].tolist() == [-1.0, -1.0, -1.0]
+    v = np.array(alice.values[:50])
+    assert v.shape == (50, 3) and np.isfinite(v).all() and (np.abs(v) <= 1).all()
+    batch = alice.records.fetch(range(0, len(alice.records), 7))
+    assert (batch[:, 10, 10, :] == -1).all()
+    deaths = (gr.wall_collision + gr.body_collision + gr.head_collision + gr.starvation) * 24
+    assert deaths == sum(r.count(-1.0) for r in rewards)
+    alice.clear()
+    assert len(alice.records) == 0 and len(alice.cached_values) == 0
+
+
+def test_game_view_api(env):
+    """utils.game.Game standalone: the reference's per-object API over a 1-slot engine"""
+    torch, se = env
+    import random
+    from utils.game import Game
+    random.seed(11)
+    g = Game(0, 11, 11, 4, 1, 0.15)
+    assert len(g.snakes) == 4 and g.get_ids() == [(0, 0), (0, 1), (0, 2), (0, 3)]
+    sts = g.get_states()
+    assert len(sts) == 4 and sts[0].shape == (21, 21, 3)
+    s0 = g.snakes[0]
+    assert np.array_equal(g.make_state(s0, g.last_moves[0]), sts[0])
+    assert np.array_equal(g.make_state(s0, (g.last_moves[0] + 1) % 4), np.rot90(sts[0], 1))
+    sub = g.subgame(5)
+    assert sub.food_spawn_chance == 0.0 and sub.food == g.food and sub.id == 5
+    res = g.tic([1, 1, 1, 1])
+    assert res == 0 or isinstance(res, list)
+    assert g.game_length == 1 and sub.game_length == 0
+    assert len(g.empty_positions) + len(g.heads) + len(g.bodies - set(g.heads)) + len(g.food) == 121

@@ -1,0 +1,147 @@
+"""GPU tests of the Q-net inference kernels (csrc/net.hip) through the C ABI: each layer against a
+plain PyTorch reference of the same op, and the whole AlphaNNet.v against the fp32 CPU restatement
+(oracle/net_ref.py).  Tolerance: |dQ| <= 1e-5 (BASELINE.json north_star), layers 2e-5 relative to the
+activation scale (fp32 accumulation order differs between a k-ordered MFMA chain and the reference)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+TOL_Q = 1e-5
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available()
+    import snake_engine
+    from snake_engine import net
+    return torch, snake_engine, net
+
+
+def _st():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("n,hw,res,relu", [(3, 21, False, True), (5, 21, True, True), (1, 21, True, False), (2, 37, True, True)])
+def test_conv3x3_layer(env, n, hw, res, relu):
+    torch, se, _ = env
+    from snake_engine._lib import lib, check
+    g = torch.Generator().manual_seed(n * 100 + hw)
+    x = torch.randn(n, hw, hw, 128, generator=g)
+    w = torch.randn(3, 3, 128, 128, generator=g) * 0.05
+    sc = torch.rand(128, generator=g) + 0.5
+    sh = torch.randn(128, generator=g) * 0.1
+    r = torch.randn(n, hw, hw, 128, generator=g) if res else None
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1)
+    ref = ref * sc.double() + sh.double()
+    if res:
+        ref = ref + r.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    xd, wd, scd, shd = x.cuda(), w.cuda().contiguous(), sc.cuda(), sh.cuda()
+    rd = r.cuda() if res else None
+    wT = torch.empty(9 * 128 * 128, device="cuda")
+    out = torch.full((n, hw, hw, 128), float("nan"), device="cuda")
+    L = lib()
+    check(L.snk_conv3x3_prepare_weights(wd.data_ptr(), wT.data_ptr(), _st()))
+    check(L.snk_conv3x3_bn_f32(xd.data_ptr(), wT.data_ptr(), scd.data_ptr(), shd.data_ptr(), rd.data_ptr() if res else None,
+                               out.data_ptr(), n, hw, hw, int(relu), _st()))
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 2e-5 * scale, (err, scale)
+
+
+def test_stem_and_head_layers(env):
+    torch, se, _ = env
+    from snake_engine._lib import lib, check
+    L = lib()
+    g = torch.Generator().manual_seed(5)
+    n, hw = 4, 21
+    x = torch.randn(n, hw, hw, 3, generator=g)
+    w = torch.randn(3, 3, 3, 128, generator=g) * 0.2
+    sc, sh = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.1
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1)
+    ref = (ref * sc.double() + sh.double()).clamp_min(0)
+    out = torch.full((n, hw, hw, 128), float("nan"), device="cuda")
+    xd, wd, scd, shd = x.cuda(), w.cuda(), sc.cuda(), sh.cuda()     # keep the device copies alive across the launch
+    check(L.snk_stem_conv_bn_relu_f32(xd.data_ptr(), wd.data_ptr(), scd.data_ptr(), shd.data_ptr(),
+                                      out.data_ptr(), n, hw, hw, _st()))
+    assert (out.cpu().double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    # head
+    a = torch.randn(n, hw, hw, 128, generator=g)
+    w1 = torch.randn(128, generator=g) * 0.1
+    s1, b1 = 0.7, 0.05
+    f1w, f1b = torch.randn(hw * hw, 128, generator=g) * 0.05, torch.randn(128, generator=g) * 0.1
+    f2w, f2b = torch.randn(128, 3, generator=g) * 0.1, torch.randn(3, generator=g) * 0.1
+    mask = torch.tensor([[0, 0, 0], [1, 0, 0], [0, 1, 1], [1, 1, 1]], dtype=torch.uint8)
+    h1 = ((a.double().reshape(n, hw * hw, 128) @ w1.double()) * s1 + b1).clamp_min(0)
+    h2 = (h1 @ f1w.double() + f1b.double()).clamp_min(0)
+    q = torch.tanh(h2 @ f2w.double() + f2b.double())
+    q[mask.bool()] = -1.0
+    qd = torch.full((n, 3), float("nan"), device="cuda")
+    dev = [t.cuda() for t in (a, w1, f1w, f1b, f2w, f2b, mask)]
+    check(L.snk_head_f32(dev[0].data_ptr(), dev[1].data_ptr(), C.c_float(s1), C.c_float(b1), dev[2].data_ptr(),
+                         dev[3].data_ptr(), dev[4].data_ptr(), dev[5].data_ptr(), dev[6].data_ptr(),
+                         qd.data_ptr(), n, hw, hw, _st()))
+    assert (qd.cpu().double() - q).abs().max().item() <= 2e-6
+
+
+def _randomised_bn(ws, seed):
+    rng = np.random.RandomState(seed)
+    out = []
+    i = 0
+    for w in ws:
+        out.append(w.copy())
+    # BN arrays are the 1-D float arrays that follow each conv kernel: gamma, beta, mean, var
+    k = 0
+    while k < len(out):
+        if out[k].ndim == 4:
+            n = out[k].shape[3]
+            out[k + 1] = (1.0 + 0.2 * rng.randn(n)).astype(np.float32)
+            out[k + 2] = (0.1 * rng.randn(n)).astype(np.float32)
+            out[k + 3] = (0.05 * rng.randn(n)).astype(np.float32)
+            out[k + 4] = (0.5 + rng.rand(n)).astype(np.float32)
+            k += 5
+        else:
+            k += 1
+    del i
+    return out
+
+
+@pytest.mark.parametrize("bn_random", [False, True])
+def test_full_net_matches_cpu_restatement(env, bn_random):
+    torch, se, net = env
+    from oracle import net_ref
+    s = load_golden("states_11x11x4.npz")
+    states = s["raw"][:96]
+    ws = net.glorot_uniform_weights((21, 21, 3), blocks=4, seed=0)
+    if bn_random:
+        ws = _randomised_bn(ws, 3)
+    ref = net_ref.forward(ws, states)
+    qn = net.QNet(ws, (21, 21, 3), max_chunk=40)     # 3 chunks, the last one ragged
+    mask = torch.as_tensor(s["mask"][s["raw_index"][:96]], device="cuda")
+    got = qn.forward(torch.as_tensor(states, device="cuda"), mask).cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= TOL_Q, np.abs(got - ref).max()
+    assert (got[ref == -1.0] == -1.0).all()
+    assert len(np.unique(np.round(got, 4))) > 20, "net output is degenerate"
+
+
+def test_full_net_19x19_10_blocks(env):
+    """config 5's shape: (37,37,3) input, 10 residual blocks (a build-side extension of the same pattern)"""
+    torch, se, net = env
+    from oracle import net_ref
+    s = load_golden("states_19x19x8.npz")
+    states = s["raw"][:6]
+    ws = _randomised_bn(net.glorot_uniform_weights((37, 37, 3), blocks=10, seed=1), 4)
+    ref = net_ref.forward(ws, states)
+    got = net.QNet(ws, (37, 37, 3)).forward(torch.as_tensor(states, device="cuda"),
+                                            torch.as_tensor(s["mask"][s["raw_index"][:6]], device="cuda")).cpu().numpy()
+    assert np.abs(got - ref).max() <= TOL_Q, np.abs(got - ref).max()
