@@ -48,45 +48,22 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f32(ConvArgs p)
     const int m0 = blockIdx.x * CV_BM;
     const int HW = p.Hd * p.Wd;
 
-    // staging assignment: float4 number f = tid + 256 i, i < 4 -> row f >> 3, 16-byte column f & 7
-    const int c4 = tid & 7;
+    // staging assignment: float4 number f = tid + 256 i, i < 4 -> tile row (tid >> 3) + 32 i, 16-byte column tid & 7
+    const int c4 = tid & 7, srow = tid >> 3;
     int ay[4], ax[4];
-    long abase[4];
+    const float *abase[4];
     bool avalid[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int row = (tid >> 3) + 32 * i;
-        const int m = m0 + row;
+        const int m = m0 + srow + 32 * i;
         avalid[i] = m < p.M;
         const int mm = avalid[i] ? m : 0;
         const int rem = mm % HW;
         ay[i] = rem / p.Wd;
         ax[i] = rem - ay[i] * p.Wd;
-        abase[i] = (long)mm * CV_C + c4 * 4;
+        abase[i] = p.x + (long)mm * CV_C + c4 * 4;       // always a readable address (the pixel itself)
     }
-
-    float4 ra[4], rb[4];
-    auto load_chunk = [&](int c) {
-        const int tap = c >> 2, cin0 = (c & 3) * CV_BK;
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        const long aoff = (long)(dy * p.Wd + dx) * CV_C + cin0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int yy = ay[i] + dy, xx = ax[i] + dx;
-            const bool ok = avalid[i] && yy >= 0 && yy < p.Hd && xx >= 0 && xx < p.Wd;
-            ra[i] = ok ? *(const float4 *)(p.x + abase[i] + aoff) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const int n = (tid >> 3) + 32 * i;
-            rb[i] = *(const float4 *)(p.wT + ((long)(tap * CV_C + n) * CV_C + cin0 + c4 * 4));
-        }
-    };
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (tid >> 3) + 32 * i;
-            *(float4 *)&As[buf][row][c4 * 4] = ra[i];
-            *(float4 *)&Bs[buf][row][c4 * 4] = rb[i];
-        }
-    };
+    const float *bbase = p.wT + (long)srow * CV_C + c4 * 4;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -96,14 +73,48 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f32(ConvArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    load_chunk(0);
-    store_chunk(0);
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    bool ok0 = false, ok1 = false, ok2 = false, ok3 = false;
+
+    // issue the global loads of chunk c (tap c >> 2, input channels 32 (c & 3) ...): branch-free -- a tap that
+    // falls outside the image reads the pixel itself and is zeroed when the registers go to LDS
+#define CV_LOAD1(i, RA, RB, OK)                                                                 \
+    {                                                                                           \
+        const int yy_ = ay[i] + dy_, xx_ = ax[i] + dx_;                                         \
+        OK = avalid[i] && yy_ >= 0 && yy_ < p.Hd && xx_ >= 0 && xx_ < p.Wd;                     \
+        RA = *(const float4 *)(abase[i] + (OK ? aoff_ : 0l) + cin0_);                           \
+        RB = *(const float4 *)(bbase + ((long)(tap_ * CV_C + 32 * i) * CV_C + cin0_));          \
+    }
+#define CV_LOAD(c)                                                                              \
+    {                                                                                           \
+        const int tap_ = (c) >> 2, cin0_ = ((c) & 3) * CV_BK;                                   \
+        const int dy_ = tap_ / 3 - 1, dx_ = tap_ - (tap_ / 3) * 3 - 1;                          \
+        const long aoff_ = (long)(dy_ * p.Wd + dx_) * CV_C;                                     \
+        CV_LOAD1(0, ra0, rb0, ok0) CV_LOAD1(1, ra1, rb1, ok1)                                   \
+        CV_LOAD1(2, ra2, rb2, ok2) CV_LOAD1(3, ra3, rb3, ok3)                                   \
+    }
+#define CV_STORE1(buf, i, RA, RB, OK)                                                           \
+    {                                                                                           \
+        float4 v_ = RA;                                                                         \
+        if (!OK) v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                          \
+        *(float4 *)&As[buf][srow + 32 * i][c4 * 4] = v_;                                        \
+        *(float4 *)&Bs[buf][srow + 32 * i][c4 * 4] = RB;                                        \
+    }
+#define CV_STORE(buf)                                                                           \
+    {                                                                                           \
+        CV_STORE1(buf, 0, ra0, rb0, ok0) CV_STORE1(buf, 1, ra1, rb1, ok1)                       \
+        CV_STORE1(buf, 2, ra2, rb2, ok2) CV_STORE1(buf, 3, ra3, rb3, ok3)                       \
+    }
+
+    CV_LOAD(0);
+    CV_STORE(0);
     __syncthreads();
 
     constexpr int NCHUNK = 9 * (CV_C / CV_BK);
     for (int c = 0; c < NCHUNK; ++c) {
         const int buf = c & 1;
-        if (c + 1 < NCHUNK) load_chunk(c + 1);
+        if (c + 1 < NCHUNK) CV_LOAD(c + 1);
+        __builtin_amdgcn_sched_barrier(0);               // keep the loads ahead of the 64 MFMAs that hide them
 #pragma unroll
         for (int k8 = 0; k8 < CV_BK / 8; ++k8) {
             float4 a[2], b[2];
@@ -122,9 +133,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f32(ConvArgs p)
                     acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt].w, b[ct].w, acc[rt][ct], 0, 0, 0);
                 }
         }
-        if (c + 1 < NCHUNK) store_chunk(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < NCHUNK) CV_STORE(buf ^ 1);
         __syncthreads();
     }
+#undef CV_LOAD
+#undef CV_STORE
+#undef CV_LOAD1
+#undef CV_STORE1
 
     // epilogue: BN scale/shift (+ residual) + ReLU.  C/D map of the 32x32 MFMA:
     // col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)

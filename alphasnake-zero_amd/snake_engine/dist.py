@@ -1,0 +1,46 @@
+"""Multi-GPU plumbing: games shard across ranks with no communication during self-play; at iteration
+end the sampled training rows are all-gathered and the six log counters all-reduced (SURVEY.md 8e;
+the reference has no collective at all -- trainer.py:56-75 is the single-process form of this step).
+One process per GPU; backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total, rank, world):
+    """contiguous block of game ids owned by `rank` (sizes differ by at most one)"""
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def sample_share(n_local_records, total_samples, world, rng):
+    """indices of this rank's share of the `total_samples` training rows (trainer.py:63-74 draws
+    sample(range(len(records)), samples) from one pool; here every rank draws total/world from its own)"""
+    share = total_samples // world
+    if n_local_records == 0:
+        return np.zeros(0, np.int64), share
+    if n_local_records >= share:
+        return rng.choice(n_local_records, size=share, replace=False), share
+    return np.resize(rng.permutation(n_local_records), share), share
+
+
+def all_gather_samples(X, V, group=None):
+    """X [k, h, w, 3] float32, V [k, 3] float32 with the same k on every rank -> concatenation over ranks"""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return X, V
+    world = dist.get_world_size(group)
+    Xo = torch.empty((world * X.shape[0],) + tuple(X.shape[1:]), dtype=X.dtype, device=X.device)
+    Vo = torch.empty((world * V.shape[0],) + tuple(V.shape[1:]), dtype=V.dtype, device=V.device)
+    dist.all_gather_into_tensor(Xo, X.contiguous(), group=group)
+    dist.all_gather_into_tensor(Vo, V.contiguous(), group=group)
+    return Xo, Vo
+
+
+def all_reduce_counters(counters, game_cnt, device, group=None):
+    """sum of the six per-rank counter totals and of the game counts -> per-game averages (mp_game_runner.py:71-76)"""
+    t = torch.tensor(list(counters) + [game_cnt], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    t = t.cpu().numpy()
+    return (t[:6] / t[6]).tolist(), int(t[6])

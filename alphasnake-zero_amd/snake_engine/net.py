@@ -53,6 +53,7 @@ class QNet:
         assert self.cin == 3
         self.max_chunk = int(max_chunk)
         self._ws = None
+        self.conv_timing = None      # set to a list to collect (start_event, end_event, flops) per conv3x3 launch
         self.set_weights(weights)
 
     # ---- weights -----------------------------------------------------------------------------
@@ -114,16 +115,26 @@ class QNet:
             cur, t1, t2 = a, b, c
             for blk in range(self.blocks):
                 i0, i1 = 2 * blk, 2 * blk + 1
-                check(L.snk_conv3x3_bn_f32(cur.data_ptr(), self.conv_wT[i0].data_ptr(), self.conv_sc[i0].data_ptr(),
-                                           self.conv_sh[i0].data_ptr(), None, t1.data_ptr(), m, h, w, 1, st))
-                check(L.snk_conv3x3_bn_f32(t1.data_ptr(), self.conv_wT[i1].data_ptr(), self.conv_sc[i1].data_ptr(),
-                                           self.conv_sh[i1].data_ptr(), cur.data_ptr(), t2.data_ptr(), m, h, w, 1, st))
+                self._conv(i0, cur, None, t1, m, st)
+                self._conv(i1, t1, cur, t2, m, st)
                 cur, t2 = t2, cur
             mk = None if mask is None else mask[s0:s0 + m]
             check(L.snk_head_f32(cur.data_ptr(), self.head_w.data_ptr(), self.head_s, self.head_b,
                                  self.fc1_w.data_ptr(), self.fc1_b.data_ptr(), self.fc2_w.data_ptr(), self.fc2_b.data_ptr(),
                                  0 if mk is None else mk.data_ptr(), out[s0:s0 + m].data_ptr(), m, h, w, st))
         return out
+
+    def _conv(self, i, x, res, out, m, st):
+        tm = self.conv_timing
+        if tm is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        check(self.L.snk_conv3x3_bn_f32(x.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
+                                        self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),
+                                        out.data_ptr(), m, self.h, self.w, 1, st))
+        if tm is not None:
+            e1.record()
+            tm.append((e0, e1, 2.0 * m * self.h * self.w * 9 * 128 * 128))
 
     def flops_per_state(self):
         hw = self.h * self.w

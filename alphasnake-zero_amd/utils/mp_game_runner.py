@@ -64,10 +64,12 @@ class MPGameRunner:
         show = self.game_cnt == 1
         rewards = [None] * self.game_cnt
         turn = 0
+        self.env_steps = 0
         while games:
             if max_turns is not None and turn >= max_turns:
                 break
             turn += 1
+            self.env_steps += len(games)       # one root Game.tic per live game (mp_game_runner.py:52)
             if self.verbose:
                 if len(games) == 1:
                     print("Running the root game. On turn", str(turn) + "...")

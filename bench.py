@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- self-play env-steps/sec of the MI355X engine (BASELINE.json metric).
+
+Workload (config.workload): BASELINE.json configs[1] -- 11x11 board, 4 snakes, 4 096 parallel games per GPU,
+max_MCTS_breadth 50 (= 48 rollouts, agent.py:32-37), max_MCTS_depth 8, health_dec 1, softmax_base 2,
+training=True (trainer.py:52), Glorot-initialised gen-0 net (seed 0), synthetic start boards.
+One "step" = one root turn of MPGameRunner.run over all live games (mp_game_runner.py:31-68): the full
+MCTS behind every root Game.tic.  value = root env-steps of all ranks / max-over-ranks wall time.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--games G] [--breadth B] [--no-cpu-baseline]
+N > 1: launched by torch.distributed.run, one rank per GPU; games shard across ranks (weak scaling:
+G games per GPU), no collective in the self-play path; the timed region ends with the iteration-end
+exchange (all-gather of this rank's share of 10 240 sampled rows + all-reduce of the log counters).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (REPO, os.path.join(REPO, "alphasnake-zero_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(weights, breadth, budget_s=25.0):
+    """the oracle's restatement of the same loop (oracle/mcts_oracle.py over oracle/snake_oracle.c), PyTorch-CPU
+    fp32 net with identical weights, on this box's host cores: a bounded sample of the same workload"""
+    from oracle import snake_oracle as so, net_ref
+    from oracle.mcts_oracle import SelfPlayOracle, Draws
+    import random
+
+    class CpuNet:
+        def v(self, X):
+            return net_ref.forward(weights, np.array(X, np.float32))
+    rnd = random.Random(0)
+    n_games = 2
+    games = []
+    for g in range(n_games):
+        pos = rnd.sample(range(8), 4)
+        games.append(so.Game.new(11, 11, 4, 1, 0.15, pos, [rnd.randrange(4) for _ in range(4)], [rnd.randrange(4) for _ in range(4)]))
+    sp = SelfPlayOracle(CpuNet(), 2, True, 8, breadth, Draws(seed=1))
+    t0 = time.time()
+    steps = 0
+    turns = 0
+    while time.time() - t0 < budget_s and turns < 8:
+        _, s = sp.run(games, max_turns=1, rng=np.random.RandomState(turns))
+        steps += s
+        turns += 1
+        games = [g for g in games if sum(g.g.alive[:4]) > 1] or games
+    dt = time.time() - t0
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_games} games x {turns} root turns, breadth {breadth} ({sp.net_evals} net evals, "
+                      f"{sp.sim_steps} rollout tics) in {dt:.1f} s; oracle/mcts_oracle.py + PyTorch-CPU fp32 net, "
+                      f"{torch.get_num_threads()} threads of {os.cpu_count()} host cpus"}
+
+
+def engine_kernel_rooflines(se, n=32768):
+    """HBM-bound engine kernels in isolation: algorithmic bytes / measured time vs 8 TB/s"""
+    out = {}
+    eng = se.Engine(n, 11, 11, 4, 1, 0.15, seed=1234)
+    eng.reset()
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    for _ in range(32):
+        eng.step(torch.randint(0, 3, (n, 4), device="cuda", generator=g, dtype=torch.int32).to(torch.uint8))
+    snap = se.Engine(n, 11, 11, 4, 1, 0.15)
+    eng.clone_to(snap)
+    G = eng.slot_bytes
+
+    def timed(fn, iters):
+        fn(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record(); torch.cuda.synchronize()
+        return a.elapsed_time(b) * 1e-3 / iters
+    mv = torch.randint(0, 3, (n, 4), device="cuda", generator=g, dtype=torch.int32).to(torch.uint8)
+    ts = []
+    for _ in range(20):
+        snap.clone_to(eng)
+        torch.cuda.synchronize()
+        ts.append(timed(lambda: eng.step(mv), 1))
+    t = float(np.median(ts))
+    out["step"] = {"bound": "hbm", "achieved": n * 2 * G / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": n * 2 * G / t / 8e12,
+                   "bytes_per_unit": 2 * G, "units": n, "us": t * 1e6}
+    t = timed(lambda: snap.clone_to(eng), 20)
+    out["clone"] = {"bound": "hbm", "achieved": n * 2 * G / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": n * 2 * G / t / 8e12,
+                    "bytes_per_unit": 2 * G, "units": n, "us": t * 1e6}
+    alive = eng.alive()
+    pairs = torch.nonzero(alive).to(torch.int32).contiguous()
+    m = pairs.shape[0]
+    planes = torch.empty((m, 21, 21, 3), device="cuda")
+    mask = torch.empty((m, 3), dtype=torch.uint8, device="cuda")
+    key = torch.empty((m, 2), dtype=torch.int64, device="cuda")
+    t = timed(lambda: eng.observe(pairs, m, planes, mask, key), 10)
+    byts = m * (G + 5292)
+    out["observe"] = {"bound": "hbm", "achieved": byts / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": byts / t / 8e12,
+                      "bytes_per_unit": G + 5292, "units": m, "us": t * 1e6}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--games", type=int, default=4096, help="parallel root games per GPU")
+    ap.add_argument("--breadth", type=int, default=50)
+    ap.add_argument("--chunk", type=int, default=8192, help="states per net forward chunk")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-rooflines", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import snake_engine as se
+    from snake_engine import net, dist as sdist
+    from utils.agent import Agent
+    from utils.alpha_nnet import AlphaNNet
+    from utils.mp_game_runner import MPGameRunner
+
+    weights = net.glorot_uniform_weights((21, 21, 3), blocks=4, seed=0)
+    nnet = AlphaNNet(input_shape=(21, 21, 3), _weights=weights)
+    nnet._qnet.max_chunk = args.chunk
+    MPGameRunner.verbose = False
+    MPGameRunner.init = "device"
+    alice = Agent(nnet, 2, True, 8, args.breadth, seed=1234 + rank)
+    gr = MPGameRunner(11, 11, 4, 1, args.games, seed=1234 + rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t_w = time.time()
+    gr.run(alice, max_turns=args.warmup)
+    barrier()
+    log(f"[rank {rank}] warmup {args.warmup} turns in {time.time() - t_w:.1f} s")
+    m = alice._mcts
+    ev0, sim0 = m.stats["net_evals"], m.stats["sim_steps"]
+    nnet._qnet.conv_timing = []
+    barrier()
+    t0 = time.time()
+    gr.run(alice, max_turns=args.steps)
+    env_steps = gr.env_steps
+    # iteration-end exchange (trainer.py:63-75 across ranks): sampled rows all-gathered, counters all-reduced
+    rng = np.random.RandomState(rank)
+    idx, share = sdist.sample_share(len(alice.records), 5 * 2048, world, rng)
+    X = torch.as_tensor(alice.records.fetch(idx) if len(idx) else np.zeros((share, 21, 21, 3), np.float32), device="cuda")
+    if X.shape[0] < share:
+        X = torch.cat([X, X.new_zeros((share - X.shape[0], 21, 21, 3))])
+    Vs = torch.as_tensor(alice._values_host()[idx] if len(idx) else np.zeros((share, 3), np.float32), device="cuda")
+    if Vs.shape[0] < share:
+        Vs = torch.cat([Vs, Vs.new_zeros((share - Vs.shape[0], 3))])
+    Xg, Vg = sdist.all_gather_samples(X, Vs)
+    sdist.all_reduce_counters(gr.engine.sum_counters(), args.games, "cuda")
+    barrier()
+    dt = time.time() - t0
+    tt = torch.tensor([dt, float(env_steps)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, env_steps = float(tmax[0].item()), float(tsum[1].item())
+    evals = m.stats["net_evals"] - ev0
+    sims = m.stats["sim_steps"] - sim0
+
+    if rank == 0:
+        tm = nnet._qnet.conv_timing
+        nnet._qnet.conv_timing = None
+        conv_s = sum(a.elapsed_time(b) for a, b, _ in tm) * 1e-3
+        conv_flops = sum(f for _, _, f in tm)
+        achieved = conv_flops / conv_s / 1e12 if conv_s > 0 else 0.0
+        res = {
+            "metric": "self-play env-steps/sec (11x11, 4 snakes, 50 MCTS sims)",
+            "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: 11x11, 4 snakes, {args.games} parallel games per GPU, max_MCTS_breadth "
+                                   f"{args.breadth} (= {args.breadth // 8 * 8} rollouts), depth 8, health_dec 1, softmax_base 2, "
+                                   "training=True, gen-0 Glorot net (seed 0), fp32 Q-net",
+                       "games_per_gpu": args.games, "breadth": args.breadth, "parallelism": f"games sharded x{world}",
+                       "net_evals_per_env_step": evals / max(1, gr.env_steps), "sim_steps_per_env_step": sims / max(1, gr.env_steps),
+                       "net_evals_per_s_rank0": evals / dt, "sample_rows_gathered": int(Xg.shape[0])},
+            "roofline": {"bound": "mfma", "kernel": "k_conv3x3_f32", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": achieved / 157.3, "traffic": None, "launches": len(tm),
+                         "avg_launch_ms": conv_s / max(1, len(tm)) * 1e3,
+                         "share_of_step_time": conv_s / dt},
+        }
+        if not args.no_kernel_rooflines:
+            del alice, gr
+            torch.cuda.empty_cache()
+            res["engine_kernels"] = engine_kernel_rooflines(se)
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(weights, args.breadth)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
