@@ -17,13 +17,12 @@
 // the f32 MFMA's two k-slots only have to agree between A and B.  Global -> LDS staging is
 // register double-buffered: the loads of chunk c+1 are issued before the 64 MFMAs of chunk c.
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define CV_BM 128
 #define CV_BN 128
-#define CV_BK 32
-#define CV_LD (CV_BK + 4)
 #define CV_C 128
 
 struct ConvArgs {
@@ -38,24 +37,32 @@ struct ConvArgs {
     int relu;
 };
 
-__global__ __launch_bounds__(256, 2) void k_conv3x3_f32(ConvArgs p)
+// BK = input channels per K chunk.  BK 16: 40 KB of LDS per block -> 3 blocks (3 waves per SIMD) per CU, so the
+// matrix pipe always finds a wave that is not parked at the chunk barrier; BK 32: 72 KB -> 2 blocks per CU.
+template <int BK, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_conv3x3_f32(ConvArgs p)
 {
-    __shared__ __align__(16) float As[2][CV_BM][CV_LD];
-    __shared__ __align__(16) float Bs[2][CV_BN][CV_LD];
+    constexpr int LD = BK + 4;                 // padded row: 16-lane ds_read_b128 groups hit distinct banks
+    constexpr int F4 = BK / 4;                 // float4 per tile row
+    constexpr int NLD = CV_BM * F4 / 256;      // float4 loads per thread per operand per chunk (2 or 4)
+    constexpr int RSTEP = 256 / F4;            // tile rows covered by one pass of the 256 threads
+    constexpr int NCC = CV_C / BK;             // channel chunks
+    __shared__ __align__(16) float As[2][CV_BM][LD];
+    __shared__ __align__(16) float Bs[2][CV_BN][LD];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv & 1, wn = wv >> 1;
     const int h = lane >> 5, l31 = lane & 31;
     const int m0 = blockIdx.x * CV_BM;
     const int HW = p.Hd * p.Wd;
 
-    // staging assignment: float4 number f = tid + 256 i, i < 4 -> tile row (tid >> 3) + 32 i, 16-byte column tid & 7
-    const int c4 = tid & 7, srow = tid >> 3;
-    int ay[4], ax[4];
-    const float *abase[4];
-    bool avalid[4];
+    // staging assignment: float4 number f = tid + 256 i -> tile row tid / F4 + RSTEP i, 16-byte column tid % F4
+    const int c4 = tid % F4, srow = tid / F4;
+    int ay[NLD], ax[NLD];
+    const float *abase[NLD];
+    bool avalid[NLD];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + srow + 32 * i;
+    for (int i = 0; i < NLD; ++i) {
+        const int m = m0 + srow + RSTEP * i;
         avalid[i] = m < p.M;
         const int mm = avalid[i] ? m : 0;
         const int rem = mm % HW;
@@ -75,30 +82,32 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f32(ConvArgs p)
 
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
     bool ok0 = false, ok1 = false, ok2 = false, ok3 = false;
+    ra2 = ra3 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // issue the global loads of chunk c (tap c >> 2, input channels 32 (c & 3) ...): branch-free -- a tap that
-    // falls outside the image reads the pixel itself and is zeroed when the registers go to LDS
+    // issue the global loads of chunk c (tap c % 9 of input channels BK (c / 9) ...; the 9 taps of one channel
+    // chunk re-read the same quarter rows, which stay in L1/L2): branch-free -- a tap that falls outside the
+    // image reads the pixel itself and is zeroed when the registers go to LDS
 #define CV_LOAD1(i, RA, RB, OK)                                                                 \
-    {                                                                                           \
-        const int yy_ = ay[i] + dy_, xx_ = ax[i] + dx_;                                         \
-        OK = avalid[i] && yy_ >= 0 && yy_ < p.Hd && xx_ >= 0 && xx_ < p.Wd;                     \
-        RA = *(const float4 *)(abase[i] + (OK ? aoff_ : 0l) + cin0_);                           \
-        RB = *(const float4 *)(bbase + ((long)(tap_ * CV_C + 32 * i) * CV_C + cin0_));          \
+    if (i < NLD) {                                                                              \
+        const int yy_ = ay[i < NLD ? i : 0] + dy_, xx_ = ax[i < NLD ? i : 0] + dx_;             \
+        OK = avalid[i < NLD ? i : 0] && yy_ >= 0 && yy_ < p.Hd && xx_ >= 0 && xx_ < p.Wd;       \
+        RA = *(const float4 *)(abase[i < NLD ? i : 0] + (OK ? aoff_ : 0l) + cin0_);             \
+        RB = *(const float4 *)(bbase + ((long)(tap_ * CV_C + RSTEP * i) * CV_C + cin0_));       \
     }
 #define CV_LOAD(c)                                                                              \
     {                                                                                           \
-        const int tap_ = (c) >> 2, cin0_ = ((c) & 3) * CV_BK;                                   \
+        const int tap_ = (c) % 9, cin0_ = ((c) / 9) * BK;                                       \
         const int dy_ = tap_ / 3 - 1, dx_ = tap_ - (tap_ / 3) * 3 - 1;                          \
         const long aoff_ = (long)(dy_ * p.Wd + dx_) * CV_C;                                     \
         CV_LOAD1(0, ra0, rb0, ok0) CV_LOAD1(1, ra1, rb1, ok1)                                   \
         CV_LOAD1(2, ra2, rb2, ok2) CV_LOAD1(3, ra3, rb3, ok3)                                   \
     }
 #define CV_STORE1(buf, i, RA, RB, OK)                                                           \
-    {                                                                                           \
+    if (i < NLD) {                                                                              \
         float4 v_ = RA;                                                                         \
         if (!OK) v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                          \
-        *(float4 *)&As[buf][srow + 32 * i][c4 * 4] = v_;                                        \
-        *(float4 *)&Bs[buf][srow + 32 * i][c4 * 4] = RB;                                        \
+        *(float4 *)&As[buf][srow + RSTEP * i][c4 * 4] = v_;                                     \
+        *(float4 *)&Bs[buf][srow + RSTEP * i][c4 * 4] = RB;                                     \
     }
 #define CV_STORE(buf)                                                                           \
     {                                                                                           \
@@ -110,13 +119,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f32(ConvArgs p)
     CV_STORE(0);
     __syncthreads();
 
-    constexpr int NCHUNK = 9 * (CV_C / CV_BK);
+    constexpr int NCHUNK = 9 * NCC;
     for (int c = 0; c < NCHUNK; ++c) {
         const int buf = c & 1;
         if (c + 1 < NCHUNK) CV_LOAD(c + 1);
-        __builtin_amdgcn_sched_barrier(0);               // keep the loads ahead of the 64 MFMAs that hide them
+        __builtin_amdgcn_sched_barrier(0);               // keep the loads ahead of the MFMAs that hide them
 #pragma unroll
-        for (int k8 = 0; k8 < CV_BK / 8; ++k8) {
+        for (int k8 = 0; k8 < BK / 8; ++k8) {
             float4 a[2], b[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -299,7 +308,10 @@ extern "C" int snk_conv3x3_bn_f32(const float *d_x, const float *d_wT, const flo
     const long M = (long)n_images * height * width;
     SNK_REQUIRE(M < (1l << 31), "snk_conv3x3_bn_f32: batch of %d images too large for one call", n_images);
     ConvArgs a = {d_x, d_wT, d_scale, d_shift, d_residual, d_out, (int)M, height, width, relu};
-    k_conv3x3_f32<<<(int)((M + CV_BM - 1) / CV_BM), 256, 0, (hipStream_t)stream>>>(a);
+    static int variant = -1;
+    if (variant < 0) { const char *v = getenv("SNK_CONV_BK"); variant = v ? atoi(v) : 16; }
+    if (variant == 32) k_conv3x3_f32<32, 2><<<(int)((M + CV_BM - 1) / CV_BM), 256, 0, (hipStream_t)stream>>>(a);
+    else k_conv3x3_f32<16, 3><<<(int)((M + CV_BM - 1) / CV_BM), 256, 0, (hipStream_t)stream>>>(a);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
