@@ -188,6 +188,11 @@ def main():
         conv_s = sum(a.elapsed_time(b) for a, b, _ in tm) * 1e-3
         conv_flops = sum(f for _, _, f in tm)
         achieved = conv_flops / conv_s / 1e12 if conv_s > 0 else 0.0
+        traffic = None      # HBM bytes per average launch, from the committed rocprofv3 --pmc passes (profiles/)
+        tfile = os.path.join(REPO, "profiles", "r1_conv_traffic.json")
+        if os.path.exists(tfile) and tm:
+            per_state_layer = json.load(open(tfile))["hbm_bytes_per_state_layer"]
+            traffic = per_state_layer * (conv_flops / len(tm)) / (2.0 * 441 * 9 * 128 * 128)
         res = {
             "metric": "self-play env-steps/sec (11x11, 4 snakes, 50 MCTS sims)",
             "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -200,7 +205,7 @@ def main():
                        "net_evals_per_env_step": evals / max(1, gr.env_steps), "sim_steps_per_env_step": sims / max(1, gr.env_steps),
                        "net_evals_per_s_rank0": evals / dt, "sample_rows_gathered": int(Xg.shape[0])},
             "roofline": {"bound": "mfma", "kernel": "k_conv3x3_f32", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": achieved / 157.3, "traffic": None, "launches": len(tm),
+                         "frac": achieved / 157.3, "traffic": traffic, "launches": len(tm),
                          "avg_launch_ms": conv_s / max(1, len(tm)) * 1e3,
                          "share_of_step_time": conv_s / dt},
         }

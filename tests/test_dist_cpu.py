@@ -1,0 +1,76 @@
+"""CPU tests (gloo, world_size 2) of the multi-GPU plumbing: games shard with no overlap, the iteration-end
+exchange all-gathers every rank's share of the sampled rows and all-reduces the log counters."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [repo, os.path.join(repo, "alphasnake-zero_amd")]
+    from snake_engine import dist as sdist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        total_games = 11
+        lo, hi = sdist.shard_range(total_games, rank, world)
+        # each rank "self-plays" its shard: records are tagged with (rank, index)
+        n_local = 37 + 5 * rank
+        rng = np.random.RandomState(rank)
+        idx, share = sdist.sample_share(n_local, 64, world, rng)
+        assert share == 32 and len(idx) == 32 and len(set(idx.tolist())) == 32 and idx.max() < n_local
+        X = torch.zeros((share, 3, 3, 3))
+        X[:, 0, 0, 0] = rank
+        X[:, 0, 0, 1] = torch.as_tensor(idx, dtype=torch.float32)
+        V = torch.full((share, 3), float(rank))
+        Xg, Vg = sdist.all_gather_samples(X, V)
+        counters = [1.0 * (rank + 1)] * 6
+        avg, games = sdist.all_reduce_counters(counters, hi - lo, "cpu")
+        torch.save(dict(lo=lo, hi=hi, Xg=Xg, Vg=Vg, avg=avg, games=games, idx=idx), os.path.join(out_dir, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_exchange(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f"r{r}.pt", weights_only=False) for r in range(world)]
+    assert (res[0]["lo"], res[0]["hi"], res[1]["lo"], res[1]["hi"]) == (0, 6, 6, 11)
+    for r in range(world):
+        Xg, Vg = res[r]["Xg"], res[r]["Vg"]
+        assert Xg.shape == (64, 3, 3, 3) and Vg.shape == (64, 3)
+        for src in range(world):                      # rank-major concatenation, every rank sees the same rows
+            blk = Xg[src * 32:(src + 1) * 32]
+            assert (blk[:, 0, 0, 0] == src).all()
+            assert blk[:, 0, 0, 1].tolist() == [float(i) for i in res[src]["idx"]]
+            assert (Vg[src * 32:(src + 1) * 32] == src).all()
+        assert res[r]["games"] == 11 and np.allclose(res[r]["avg"], [3.0 / 11] * 6)
+    assert torch.equal(res[0]["Xg"], res[1]["Xg"])
+
+
+def test_shard_range_partitions_everything():
+    from snake_engine.dist import shard_range, sample_share
+    for total in (1, 7, 8, 4096, 262144):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+    idx, share = sample_share(5, 64, 2, np.random.RandomState(0))     # fewer local records than the share: wraps
+    assert share == 32 and len(idx) == 32 and set(idx.tolist()) == set(range(5))
+    idx, share = sample_share(0, 64, 2, np.random.RandomState(0))
+    assert share == 32 and len(idx) == 0
