@@ -174,6 +174,210 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_conv3x3_f32(ConvArgs p)
 }
 
 // ------------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) form of the same layer (fp32 throughout): Y = A^T [ (G g G^T) . (B^T d B) ] A.
+// 16 transformed positions p = (xi, nu), each a GEMM [tiles x 128 cin] x [128 cin x 128 cout] on
+// v_mfma_f32_32x32x2_f32: 16 * 121 * 128 * 128 MACs per 21x21 image instead of 441 * 9 * 128 * 128
+// (2.05x fewer).  One block = 32 consecutive 2x2-output tiles x all 16 positions x all 128 outputs,
+// 8 wavefronts, wave w owns positions 2w and 2w+1 (2 x 4 MFMA tiles = 128 accumulator VGPRs).
+//   per 16-channel chunk: every thread transforms one (tile, channel) 4x4 patch (B^T d B: 32 adds) and
+//   scatters the 16 results to LDS V[p][tile][channel]; A fragments come from LDS, B fragments (U, the
+//   pre-transformed weights, 1 MB, L2 resident) stream straight into registers one k8-step ahead;
+//   epilogue: accumulators -> LDS M[p][tile][cout] one 32-output slice at a time, A^T M A per (tile, cout),
+//   BN scale/shift (+ residual) + ReLU, 2x2 pixels written.
+// ------------------------------------------------------------------------------------------
+#define WG_TB 32          // tiles per block
+#define WG_KC 16          // input channels per chunk
+#define WG_LD 20          // padded V row (floats)
+#define WG_MLD 33         // padded M row (floats)
+
+struct WinoArgs {
+    const float *x;      // [n][Hd][Wd][128]
+    const float *U;      // [16 p][32 cin/4][128 cout][4]
+    const float *scale, *shift;
+    const float *res;    // or NULL
+    float *out;
+    int n_tiles;         // n * TY * TX
+    int Hd, Wd, TY, TX;
+    int relu;
+};
+
+__global__ __launch_bounds__(512, 2) void k_conv3x3_wino_f32(WinoArgs p)
+{
+    __shared__ __align__(16) float smem[2 * 16 * WG_TB * WG_LD];      // 81 920 B: V double buffer, reused as M
+    float(*Vs)[16][WG_TB][WG_LD] = (float(*)[16][WG_TB][WG_LD])smem;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int t0 = blockIdx.x * WG_TB;
+    const int tiles_per_img = p.TY * p.TX;
+
+    // ---- input-transform role: thread = (tile tl, channel cl of the chunk)
+    const int tl = tid >> 4, cl = tid & 15;
+    unsigned vmask = 0;                       // bit (4 i + j): patch pixel (i, j) lies inside the image
+    long pbase = 0;                           // element offset of patch pixel (0, 0), channel cl
+    {
+        const int t = t0 + tl;
+        if (t < p.n_tiles) {
+            const int img = t / tiles_per_img, r = t - img * tiles_per_img;
+            const int ty = r / p.TX, tx = r - ty * p.TX;
+            const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+            pbase = ((long)(img * p.Hd + y0) * p.Wd + x0) * CV_C + cl;
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j)
+                    if (y0 + i >= 0 && y0 + i < p.Hd && x0 + j >= 0 && x0 + j < p.Wd) vmask |= 1u << (4 * i + j);
+        }
+    }
+    float raw[16];
+#define WG_LOAD_RAW(c)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
+            const bool ok_ = (vmask >> (4 * i + j)) & 1u;                                       \
+            const long off_ = ok_ ? pbase + (long)(i * p.Wd + j) * CV_C + (c) * WG_KC : (long)cl; \
+            raw[4 * i + j] = p.x[off_];                                                         \
+        }
+#define WG_TRANSFORM_STORE(buf)                                                                 \
+    {                                                                                           \
+        float d_[16];                                                                           \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) d_[q] = ((vmask >> q) & 1u) ? raw[q] : 0.f; \
+        float r_[16];                                                                           \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
+            r_[0 + j] = d_[0 + j] - d_[8 + j];                                                  \
+            r_[4 + j] = d_[4 + j] + d_[8 + j];                                                  \
+            r_[8 + j] = d_[8 + j] - d_[4 + j];                                                  \
+            r_[12 + j] = d_[4 + j] - d_[12 + j];                                                \
+        }                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                         \
+            Vs[buf][4 * i + 0][tl][cl] = r_[4 * i + 0] - r_[4 * i + 2];                         \
+            Vs[buf][4 * i + 1][tl][cl] = r_[4 * i + 1] + r_[4 * i + 2];                         \
+            Vs[buf][4 * i + 2][tl][cl] = r_[4 * i + 2] - r_[4 * i + 1];                         \
+            Vs[buf][4 * i + 3][tl][cl] = r_[4 * i + 1] - r_[4 * i + 3];                         \
+        }                                                                                       \
+    }
+
+    // ---- GEMM role: wave wv owns positions 2 wv, 2 wv + 1
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // U fragment of (position pi, n-tile nt) for k8-step (c, s): float4 at U[p][(16 c + 8 s + 4 h) / 4][32 nt + l31][0..3]
+    const float4 *Ub = (const float4 *)p.U + ((long)(2 * wv) * 32 + h) * 128 + l31;
+#define WG_LOAD_B(dst, c, s)                                                                    \
+    _Pragma("unroll") for (int pi = 0; pi < 2; ++pi)                                            \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                        \
+            dst[pi][nt] = Ub[((long)pi * 32 + (c) * 4 + (s) * 2) * 128 + nt * 32];
+#define WG_MFMA(buf, s, B)                                                                      \
+    {                                                                                           \
+        float4 a_[2];                                                                           \
+        _Pragma("unroll") for (int pi = 0; pi < 2; ++pi)                                        \
+            a_[pi] = *(const float4 *)&Vs[buf][2 * wv + pi][l31][(s) * 8 + 4 * h];              \
+        _Pragma("unroll") for (int pi = 0; pi < 2; ++pi)                                        \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                  \
+                acc[pi][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[pi].x, B[pi][nt].x, acc[pi][nt], 0, 0, 0); \
+                acc[pi][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[pi].y, B[pi][nt].y, acc[pi][nt], 0, 0, 0); \
+                acc[pi][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[pi].z, B[pi][nt].z, acc[pi][nt], 0, 0, 0); \
+                acc[pi][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[pi].w, B[pi][nt].w, acc[pi][nt], 0, 0, 0); \
+            }                                                                                   \
+    }
+
+    float4 B0[2][4], B1[2][4];
+    WG_LOAD_RAW(0);
+    WG_LOAD_B(B0, 0, 0);
+    WG_TRANSFORM_STORE(0);
+    __syncthreads();
+
+    constexpr int NCH = CV_C / WG_KC;
+    for (int c = 0; c < NCH; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < NCH) { WG_LOAD_RAW(c + 1); }
+        WG_LOAD_B(B1, c, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        WG_MFMA(buf, 0, B0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < NCH) { WG_LOAD_B(B0, c + 1, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+        WG_MFMA(buf, 1, B1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < NCH) { WG_TRANSFORM_STORE(buf ^ 1); }
+        __syncthreads();
+    }
+#undef WG_LOAD_RAW
+#undef WG_TRANSFORM_STORE
+#undef WG_LOAD_B
+#undef WG_MFMA
+
+    // ---- epilogue: M -> LDS per 32-output slice, inverse transform, BN (+ residual) + ReLU
+    float(*Ms)[WG_TB][WG_MLD] = (float(*)[WG_TB][WG_MLD])smem;     // [16 p][32 tiles][33]
+    const int col = tid & 31, tlb = tid >> 5;                       // output role: (tile tlb / tlb + 16, cout col)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Ms[2 * wv + pi][(r & 3) + 8 * (r >> 2) + 4 * h][l31] = acc[pi][nt][r];
+        __syncthreads();
+        const int co = nt * 32 + col;
+        const float sc = p.scale[co], sh = p.shift[co];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int tq = tlb + 16 * q;
+            const int t = t0 + tq;
+            if (t < p.n_tiles) {
+                float m[16];
+#pragma unroll
+                for (int pp = 0; pp < 16; ++pp) m[pp] = Ms[pp][tq][col];
+                float s0[4], s1[4];
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu) {
+                    s0[nu] = (m[0 + nu] + m[4 + nu]) + m[8 + nu];
+                    s1[nu] = (m[4 + nu] - m[8 + nu]) - m[12 + nu];
+                }
+                float y[2][2];
+                y[0][0] = (s0[0] + s0[1]) + s0[2]; y[0][1] = (s0[1] - s0[2]) - s0[3];
+                y[1][0] = (s1[0] + s1[1]) + s1[2]; y[1][1] = (s1[1] - s1[2]) - s1[3];
+                const int img = t / tiles_per_img, r = t - img * tiles_per_img;
+                const int ty = r / p.TX, tx = r - ty * p.TX;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const int yy = 2 * ty + a, xx = 2 * tx + b;
+                        if (yy < p.Hd && xx < p.Wd) {
+                            const long o = ((long)(img * p.Hd + yy) * p.Wd + xx) * CV_C + co;
+                            float v = y[a][b] * sc + sh;
+                            if (p.res) v += p.res[o];
+                            if (p.relu) v = fmaxf(v, 0.f);
+                            p.out[o] = v;
+                        }
+                    }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// U[p = 4 xi + nu][cin / 4][cout][cin % 4] = sum_ij G[xi][i] g[i][j][cin][cout] G[nu][j], evaluated in float64
+__global__ void k_wino_weights(const float *__restrict__ w, float *__restrict__ U)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= CV_C * CV_C) return;
+    const int ci = i / CV_C, co = i - ci * CV_C;
+    const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    double g[3][3];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) g[a][b] = (double)w[((long)(a * 3 + b) * CV_C + ci) * CV_C + co];
+    for (int xi = 0; xi < 4; ++xi)
+        for (int nu = 0; nu < 4; ++nu) {
+            double s = 0;
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) s += G[xi][a] * g[a][b] * G[nu][b];
+            U[(((long)(4 * xi + nu) * 32 + ci / 4) * CV_C + co) * 4 + (ci & 3)] = (float)s;
+        }
+}
+
+// ------------------------------------------------------------------------------------------
 // stem: 3x3 conv over the 3 observation planes (NHWC), BN, ReLU.  K = 27: VALU work, weights in LDS.
 // One block = 64 pixels x 128 output channels; thread (tid & 127) owns a channel, (tid >> 7) a pixel parity.
 // ------------------------------------------------------------------------------------------
@@ -312,6 +516,31 @@ extern "C" int snk_conv3x3_bn_f32(const float *d_x, const float *d_wT, const flo
     if (variant < 0) { const char *v = getenv("SNK_CONV_BK"); variant = v ? atoi(v) : 16; }
     if (variant == 32) k_conv3x3_f32<32, 2><<<(int)((M + CV_BM - 1) / CV_BM), 256, 0, (hipStream_t)stream>>>(a);
     else k_conv3x3_f32<16, 3><<<(int)((M + CV_BM - 1) / CV_BM), 256, 0, (hipStream_t)stream>>>(a);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+
+extern "C" int snk_conv3x3_prepare_weights_winograd(const float *d_w_hwio, float *d_U, void *stream)
+{
+    SNK_REQUIRE(d_w_hwio && d_U, "snk_conv3x3_prepare_weights_winograd: NULL argument");
+    k_wino_weights<<<(CV_C * CV_C + 255) / 256, 256, 0, (hipStream_t)stream>>>(d_w_hwio, d_U);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int snk_conv3x3_bn_f32_winograd(const float *d_x, const float *d_U, const float *d_scale, const float *d_shift,
+                                           const float *d_residual, float *d_out, int n_images, int height, int width,
+                                           int relu, void *stream)
+{
+    SNK_REQUIRE(d_x && d_U && d_scale && d_shift && d_out, "snk_conv3x3_bn_f32_winograd: NULL argument");
+    SNK_REQUIRE(d_out != d_x, "snk_conv3x3_bn_f32_winograd: in-place convolution is not possible");
+    if (n_images <= 0) return 0;
+    const int TY = (height + 1) / 2, TX = (width + 1) / 2;
+    const long tiles = (long)n_images * TY * TX;
+    SNK_REQUIRE((long)n_images * height * width < (1l << 31) / 4, "snk_conv3x3_bn_f32_winograd: batch of %d images too large for one call", n_images);
+    WinoArgs a = {d_x, d_U, d_scale, d_shift, d_residual, d_out, (int)tiles, height, width, TY, TX, relu};
+    k_conv3x3_wino_f32<<<(int)((tiles + WG_TB - 1) / WG_TB), 512, 0, (hipStream_t)stream>>>(a);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -7,6 +7,7 @@ Weight list order (= Keras ``model.get_weights()`` order of the reference graph)
   head kernel (1,1,k,1), head BN (4 x (1,)), dense kernel (h*w, 128), bias, dense_1 kernel (128, 3), bias.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -54,6 +55,8 @@ class QNet:
         self.max_chunk = int(max_chunk)
         self._ws = None
         self.conv_timing = None      # set to a list to collect (start_event, end_event, flops) per conv3x3 launch
+        # "winograd": F(2x2,3x3) fp32 MFMA kernel (2.05x fewer flops); "direct": implicit-GEMM fp32 MFMA kernel
+        self.conv_algo = os.environ.get("SNK_CONV_ALGO", "winograd")
         self.set_weights(weights)
 
     # ---- weights -----------------------------------------------------------------------------
@@ -72,8 +75,12 @@ class QNet:
         st = torch.cuda.current_stream().cuda_stream
         for i in range(2 * self.blocks):
             base = 5 + 5 * i
-            wT = torch.empty(9 * 128 * 128, dtype=torch.float32, device=dev)
-            check(self.L.snk_conv3x3_prepare_weights(t[base].contiguous().data_ptr(), wT.data_ptr(), st))
+            if self.conv_algo == "winograd":
+                wT = torch.empty(16 * 128 * 128, dtype=torch.float32, device=dev)
+                check(self.L.snk_conv3x3_prepare_weights_winograd(t[base].contiguous().data_ptr(), wT.data_ptr(), st))
+            else:
+                wT = torch.empty(9 * 128 * 128, dtype=torch.float32, device=dev)
+                check(self.L.snk_conv3x3_prepare_weights(t[base].contiguous().data_ptr(), wT.data_ptr(), st))
             sc, sh = fold(*t[base + 1:base + 5])
             self.conv_wT.append(wT); self.conv_sc.append(sc); self.conv_sh.append(sh)
         base = 5 + 10 * self.blocks
@@ -129,9 +136,10 @@ class QNet:
         if tm is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        check(self.L.snk_conv3x3_bn_f32(x.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
-                                        self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),
-                                        out.data_ptr(), m, self.h, self.w, 1, st))
+        fn = self.L.snk_conv3x3_bn_f32_winograd if self.conv_algo == "winograd" else self.L.snk_conv3x3_bn_f32
+        check(fn(x.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
+                 self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),
+                 out.data_ptr(), m, self.h, self.w, 1, st))
         if tm is not None:
             e1.record()
             tm.append((e0, e1, 2.0 * m * self.h * self.w * 9 * 128 * 128))

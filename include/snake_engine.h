@@ -148,6 +148,13 @@ int snk_conv3x3_prepare_weights(const float *d_w_hwio, float *d_wT, void *stream
 int snk_conv3x3_bn_f32(const float *d_x, const float *d_wT, const float *d_scale, const float *d_shift,
                        const float *d_residual, float *d_out, int n_images, int height, int width,
                        int relu, void *stream);
+/* The same layer in Winograd F(2x2,3x3) form (fp32 throughout, 2.05x fewer MFMA flops on 21x21 images):
+ * snk_conv3x3_prepare_weights_winograd: Keras kernel (3,3,128,128) -> U = G g G^T laid out
+ *   [16 positions][cin/4][cout][4] (float[16*128*128], evaluated in float64, stored float32). */
+int snk_conv3x3_prepare_weights_winograd(const float *d_w_hwio, float *d_U, void *stream);
+int snk_conv3x3_bn_f32_winograd(const float *d_x, const float *d_U, const float *d_scale,
+                                const float *d_shift, const float *d_residual, float *d_out, int n_images,
+                                int height, int width, int relu, void *stream);
 int snk_stem_conv_bn_relu_f32(const float *d_x, const float *d_w, const float *d_scale,
                               const float *d_shift, float *d_out, int n_images, int height, int width,
                               void *stream);

@@ -27,8 +27,9 @@ def _st():
     return torch.cuda.current_stream().cuda_stream
 
 
+@pytest.mark.parametrize("algo", ["direct", "winograd"])
 @pytest.mark.parametrize("n,hw,res,relu", [(3, 21, False, True), (5, 21, True, True), (1, 21, True, False), (2, 37, True, True)])
-def test_conv3x3_layer(env, n, hw, res, relu):
+def test_conv3x3_layer(env, n, hw, res, relu, algo):
     torch, se, _ = env
     from snake_engine._lib import lib, check
     g = torch.Generator().manual_seed(n * 100 + hw)
@@ -45,12 +46,14 @@ def test_conv3x3_layer(env, n, hw, res, relu):
         ref = ref.clamp_min(0)
     xd, wd, scd, shd = x.cuda(), w.cuda().contiguous(), sc.cuda(), sh.cuda()
     rd = r.cuda() if res else None
-    wT = torch.empty(9 * 128 * 128, device="cuda")
+    wT = torch.empty(16 * 128 * 128, device="cuda")
     out = torch.full((n, hw, hw, 128), float("nan"), device="cuda")
     L = lib()
-    check(L.snk_conv3x3_prepare_weights(wd.data_ptr(), wT.data_ptr(), _st()))
-    check(L.snk_conv3x3_bn_f32(xd.data_ptr(), wT.data_ptr(), scd.data_ptr(), shd.data_ptr(), rd.data_ptr() if res else None,
-                               out.data_ptr(), n, hw, hw, int(relu), _st()))
+    prep, conv = ((L.snk_conv3x3_prepare_weights_winograd, L.snk_conv3x3_bn_f32_winograd) if algo == "winograd"
+                  else (L.snk_conv3x3_prepare_weights, L.snk_conv3x3_bn_f32))
+    check(prep(wd.data_ptr(), wT.data_ptr(), _st()))
+    check(conv(xd.data_ptr(), wT.data_ptr(), scd.data_ptr(), shd.data_ptr(), rd.data_ptr() if res else None,
+               out.data_ptr(), n, hw, hw, int(relu), _st()))
     got = out.cpu().double()
     assert torch.isfinite(got).all()
     err = (got - ref).abs().max().item()
@@ -115,9 +118,11 @@ def _randomised_bn(ws, seed):
     return out
 
 
+@pytest.mark.parametrize("algo", ["direct", "winograd"])
 @pytest.mark.parametrize("bn_random", [False, True])
-def test_full_net_matches_cpu_restatement(env, bn_random):
+def test_full_net_matches_cpu_restatement(env, bn_random, algo, monkeypatch):
     torch, se, net = env
+    monkeypatch.setenv("SNK_CONV_ALGO", algo)
     from oracle import net_ref
     s = load_golden("states_11x11x4.npz")
     states = s["raw"][:96]
