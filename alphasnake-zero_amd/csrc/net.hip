@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_conv3x3_f32(ConvArgs p)
 #define WG_TB 32          // tiles per block
 #define WG_KC 16          // input channels per chunk
 #define WG_LD 20          // padded V row (floats)
-#define WG_MLD 33         // padded M row (floats)
+#define WG_MLD 68         // M row: 64 outputs + 4 pad (floats, 16-byte aligned rows)
 
 struct WinoArgs {
     const float *x;      // [n][Hd][Wd][128]
@@ -203,7 +203,7 @@ struct WinoArgs {
 
 __global__ __launch_bounds__(512, 2) void k_conv3x3_wino_f32(WinoArgs p)
 {
-    __shared__ __align__(16) float smem[2 * 16 * WG_TB * WG_LD];      // 81 920 B: V double buffer, reused as M
+    __shared__ __align__(16) float smem[16 * WG_TB * WG_MLD];         // 139 264 B: V double buffer (first 81 920 B), reused as M
     float(*Vs)[16][WG_TB][WG_LD] = (float(*)[16][WG_TB][WG_LD])smem;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int h = lane >> 5, l31 = lane & 31;
@@ -213,27 +213,28 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino_f32(WinoArgs p)
     // ---- input-transform role: thread = (tile tl, channel cl of the chunk)
     const int tl = tid >> 4, cl = tid & 15;
     unsigned vmask = 0;                       // bit (4 i + j): patch pixel (i, j) lies inside the image
-    long pbase = 0;                           // element offset of patch pixel (0, 0), channel cl
+    unsigned rowoff[4] = {0, 0, 0, 0}, coloff[4] = {0, 0, 0, 0};   // element offsets of the (clamped, always readable) patch rows / columns
     {
         const int t = t0 + tl;
         if (t < p.n_tiles) {
             const int img = t / tiles_per_img, r = t - img * tiles_per_img;
             const int ty = r / p.TX, tx = r - ty * p.TX;
             const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
-            pbase = ((long)(img * p.Hd + y0) * p.Wd + x0) * CV_C + cl;
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
+                const int yc = min(max(y0 + i, 0), p.Hd - 1), xc = min(max(x0 + i, 0), p.Wd - 1);
+                rowoff[i] = (unsigned)((img * p.Hd + yc) * p.Wd) * CV_C;
+                coloff[i] = (unsigned)xc * CV_C;
                 for (int j = 0; j < 4; ++j)
                     if (y0 + i >= 0 && y0 + i < p.Hd && x0 + j >= 0 && x0 + j < p.Wd) vmask |= 1u << (4 * i + j);
+            }
         }
     }
     float raw[16];
+    const float *xcl = p.x + cl;
 #define WG_LOAD_RAW(c)                                                                          \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
-            const bool ok_ = (vmask >> (4 * i + j)) & 1u;                                       \
-            const long off_ = ok_ ? pbase + (long)(i * p.Wd + j) * CV_C + (c) * WG_KC : (long)cl; \
-            raw[4 * i + j] = p.x[off_];                                                         \
-        }
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
+            raw[4 * i + j] = xcl[(size_t)(rowoff[i] + coloff[j]) + (c) * WG_KC];
 #define WG_TRANSFORM_STORE(buf)                                                                 \
     {                                                                                           \
         float d_[16];                                                                           \
@@ -281,21 +282,22 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino_f32(WinoArgs p)
             }                                                                                   \
     }
 
+    constexpr int NCH = CV_C / WG_KC;
+#define WG_CH(c) (c)
     float4 B0[2][4], B1[2][4];
-    WG_LOAD_RAW(0);
-    WG_LOAD_B(B0, 0, 0);
+    WG_LOAD_RAW(WG_CH(0));
+    WG_LOAD_B(B0, WG_CH(0), 0);
     WG_TRANSFORM_STORE(0);
     __syncthreads();
 
-    constexpr int NCH = CV_C / WG_KC;
     for (int c = 0; c < NCH; ++c) {
         const int buf = c & 1;
-        if (c + 1 < NCH) { WG_LOAD_RAW(c + 1); }
-        WG_LOAD_B(B1, c, 1);
+        WG_LOAD_B(B1, WG_CH(c), 1);                       // B first: vmcnt retires in order, the raw (HBM) loads must not gate it
+        if (c + 1 < NCH) { WG_LOAD_RAW(WG_CH(c + 1)); }
         __builtin_amdgcn_sched_barrier(0);
         WG_MFMA(buf, 0, B0);
         __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < NCH) { WG_LOAD_B(B0, c + 1, 0); }
+        if (c + 1 < NCH) { WG_LOAD_B(B0, WG_CH(c + 1), 0); }
         __builtin_amdgcn_sched_barrier(0);
         WG_MFMA(buf, 1, B1);
         __builtin_amdgcn_sched_barrier(0);
@@ -303,56 +305,75 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino_f32(WinoArgs p)
         __syncthreads();
     }
 #undef WG_LOAD_RAW
+#undef WG_CH
 #undef WG_TRANSFORM_STORE
 #undef WG_LOAD_B
 #undef WG_MFMA
 
-    // ---- epilogue: M -> LDS per 32-output slice, inverse transform, BN (+ residual) + ReLU
-    float(*Ms)[WG_TB][WG_MLD] = (float(*)[WG_TB][WG_MLD])smem;     // [16 p][32 tiles][33]
-    const int col = tid & 31, tlb = tid >> 5;                       // output role: (tile tlb / tlb + 16, cout col)
+    // ---- epilogue: M -> LDS in two 64-output halves, inverse transform A^T M A on 4 outputs per thread,
+    //      BN (+ residual) + ReLU, 2x2 pixels x float4 written
+    float(*Ms)[WG_TB][WG_MLD] = (float(*)[WG_TB][WG_MLD])smem;     // [16 p][32 tiles][64 + 4]
+    const int tq = tid >> 4, quad = tid & 15;                       // output role: tile tq, outputs 4 quad .. 4 quad + 3 of the half
+    const int t = t0 + tq;
+    const bool tvalid = t < p.n_tiles;
+    int oy = 0, ox = 0;
+    long obase = 0;
+    if (tvalid) {
+        const int img = t / tiles_per_img, r = t - img * tiles_per_img;
+        const int ty = r / p.TX, tx = r - ty * p.TX;
+        oy = 2 * ty; ox = 2 * tx;
+        obase = ((long)(img * p.Hd + oy) * p.Wd + ox) * CV_C;
+    }
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int half = 0; half < 2; ++half) {
+        const int co = half * 64 + quad * 4;
+        float4 rres[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const bool ok = tvalid && p.res && oy + a < p.Hd && ox + b < p.Wd;
+                rres[a][b] = ok ? *(const float4 *)(p.res + obase + (long)(a * p.Wd + b) * CV_C + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
         for (int pi = 0; pi < 2; ++pi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                Ms[2 * wv + pi][(r & 3) + 8 * (r >> 2) + 4 * h][l31] = acc[pi][nt][r];
+            for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Ms[2 * wv + pi][(r & 3) + 8 * (r >> 2) + 4 * h][nn * 32 + l31] = acc[pi][2 * half + nn][r];
         __syncthreads();
-        const int co = nt * 32 + col;
-        const float sc = p.scale[co], sh = p.shift[co];
+        if (tvalid) {
+            const float4 sc = *(const float4 *)(p.scale + co), sh = *(const float4 *)(p.shift + co);
+            float4 m[16];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int tq = tlb + 16 * q;
-            const int t = t0 + tq;
-            if (t < p.n_tiles) {
-                float m[16];
-#pragma unroll
-                for (int pp = 0; pp < 16; ++pp) m[pp] = Ms[pp][tq][col];
-                float s0[4], s1[4];
-#pragma unroll
-                for (int nu = 0; nu < 4; ++nu) {
-                    s0[nu] = (m[0 + nu] + m[4 + nu]) + m[8 + nu];
-                    s1[nu] = (m[4 + nu] - m[8 + nu]) - m[12 + nu];
-                }
-                float y[2][2];
-                y[0][0] = (s0[0] + s0[1]) + s0[2]; y[0][1] = (s0[1] - s0[2]) - s0[3];
-                y[1][0] = (s1[0] + s1[1]) + s1[2]; y[1][1] = (s1[1] - s1[2]) - s1[3];
-                const int img = t / tiles_per_img, r = t - img * tiles_per_img;
-                const int ty = r / p.TX, tx = r - ty * p.TX;
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        const int yy = 2 * ty + a, xx = 2 * tx + b;
-                        if (yy < p.Hd && xx < p.Wd) {
-                            const long o = ((long)(img * p.Hd + yy) * p.Wd + xx) * CV_C + co;
-                            float v = y[a][b] * sc + sh;
-                            if (p.res) v += p.res[o];
-                            if (p.relu) v = fmaxf(v, 0.f);
-                            p.out[o] = v;
-                        }
-                    }
+            for (int pp = 0; pp < 16; ++pp) m[pp] = *(const float4 *)&Ms[pp][tq][quad * 4];
+            float4 y[2][2];
+#define WG_INV(F)                                                                               \
+            {                                                                                   \
+                float s0[4], s1[4];                                                             \
+                _Pragma("unroll") for (int nu = 0; nu < 4; ++nu) {                              \
+                    s0[nu] = (m[0 + nu].F + m[4 + nu].F) + m[8 + nu].F;                         \
+                    s1[nu] = (m[4 + nu].F - m[8 + nu].F) - m[12 + nu].F;                        \
+                }                                                                               \
+                y[0][0].F = (s0[0] + s0[1]) + s0[2]; y[0][1].F = (s0[1] - s0[2]) - s0[3];       \
+                y[1][0].F = (s1[0] + s1[1]) + s1[2]; y[1][1].F = (s1[1] - s1[2]) - s1[3];       \
             }
+            WG_INV(x) WG_INV(y) WG_INV(z) WG_INV(w)
+#undef WG_INV
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    if (oy + a < p.Hd && ox + b < p.Wd) {
+                        float4 v;
+                        v.x = y[a][b].x * sc.x + sh.x + rres[a][b].x;
+                        v.y = y[a][b].y * sc.y + sh.y + rres[a][b].y;
+                        v.z = y[a][b].z * sc.z + sh.z + rres[a][b].z;
+                        v.w = y[a][b].w * sc.w + sh.w + rres[a][b].w;
+                        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        *(float4 *)(p.out + obase + (long)(a * p.Wd + b) * CV_C + co) = v;
+                    }
         }
         __syncthreads();
     }

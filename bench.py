@@ -204,8 +204,14 @@ def main():
                        "games_per_gpu": args.games, "breadth": args.breadth, "parallelism": f"games sharded x{world}",
                        "net_evals_per_env_step": evals / max(1, gr.env_steps), "sim_steps_per_env_step": sims / max(1, gr.env_steps),
                        "net_evals_per_s_rank0": evals / dt, "sample_rows_gathered": int(Xg.shape[0])},
-            "roofline": {"bound": "mfma", "kernel": "k_conv3x3_f32", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "kernel": "k_conv3x3_wino_f32" if nnet._qnet.conv_algo == "winograd" else "k_conv3x3_f32",
+                         "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
                          "frac": achieved / 157.3, "traffic": traffic, "launches": len(tm),
+                         "flops_convention": "algorithmic = direct 3x3 convolution, 2*441*1152*128 per state and layer (SURVEY 8d)",
+                         "executed_frac": achieved / 157.3 * (16 * 121 / (441 * 9.0) if nnet._qnet.conv_algo == "winograd" else 1.0),
+                         "algorithm": ("Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: executes 16*121/(441*9) = 0.488 of the "
+                                       "algorithmic flops, fp32 throughout" if nnet._qnet.conv_algo == "winograd"
+                                       else "implicit GEMM on v_mfma_f32_32x32x2_f32"),
                          "avg_launch_ms": conv_s / max(1, len(tm)) * 1e3,
                          "share_of_step_time": conv_s / dt},
         }
