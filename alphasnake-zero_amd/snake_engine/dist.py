@@ -30,16 +30,21 @@ def all_gather_samples(X, V, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return X, V
     world = dist.get_world_size(group)
+    dev = X.device
+    if dist.get_backend(group) == "gloo" and X.is_cuda:      # rehearsal backend: stage through host memory
+        X, V = X.cpu(), V.cpu()
     Xo = torch.empty((world * X.shape[0],) + tuple(X.shape[1:]), dtype=X.dtype, device=X.device)
     Vo = torch.empty((world * V.shape[0],) + tuple(V.shape[1:]), dtype=V.dtype, device=V.device)
     dist.all_gather_into_tensor(Xo, X.contiguous(), group=group)
     dist.all_gather_into_tensor(Vo, V.contiguous(), group=group)
-    return Xo, Vo
+    return Xo.to(dev), Vo.to(dev)
 
 
 def all_reduce_counters(counters, game_cnt, device, group=None):
     """sum of the six per-rank counter totals and of the game counts -> per-game averages (mp_game_runner.py:71-76)"""
     t = torch.tensor(list(counters) + [game_cnt], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 and dist.get_backend(group) == "gloo":
+        t = t.cpu()
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     t = t.cpu().numpy()

@@ -23,11 +23,12 @@ def _stream():
 
 class Engine:
     def __init__(self, n_slots, height=11, width=11, snake_cnt=4, health_dec=1, food_spawn_chance=0.15,
-                 seed=1234, device=0):
+                 seed=1234, device=None):
         if not torch.cuda.is_available():
             raise EngineError("snake_engine.Engine needs an MI355X (torch.cuda.is_available() is False); "
                               "there is no CPU fallback")
         self.L = lib()
+        device = torch.cuda.current_device() if device is None else int(device)      # one process per GPU: the current device
         self.device = torch.device("cuda", device)
         self.n_slots, self.H, self.W, self.S = int(n_slots), int(height), int(width), int(snake_cnt)
         self.health_dec, self.food_spawn_chance = int(health_dec), float(food_spawn_chance)

@@ -25,8 +25,9 @@ def _pow2_at_least(v):
 class TranspositionTable:
     """cached_values / total_rewards / visit_cnts / cache_hit (agent.py:16-19) in HBM."""
 
-    def __init__(self, capacity, device=0):
+    def __init__(self, capacity, device=None):
         self.L = lib()
+        device = torch.cuda.current_device() if device is None else int(device)
         h = C.c_void_p()
         check(self.L.snk_tt_create(C.byref(h), int(capacity), device))
         self.h = h
@@ -56,7 +57,7 @@ class TranspositionTable:
 
 class DeviceMCTS:
     def __init__(self, evaluate, height, width, snake_cnt, softmax_base=100, training=False, max_depth=8,
-                 max_breadth=128, seed=1234, device=0, sequential=False, tape_u=None, tt_capacity=None,
+                 max_breadth=128, seed=1234, device=None, sequential=False, tape_u=None, tt_capacity=None,
                  legacy_mask=False):
         """evaluate(planes[n,h,w,3] cuda f32, mask[n,3] cuda u8) -> cuda f32 [n,3]  (= AlphaNNet.v)"""
         if not torch.cuda.is_available():
@@ -67,6 +68,7 @@ class DeviceMCTS:
         self.base, self.training = float(softmax_base), bool(training)
         self.max_depth, self.max_breadth = int(max_depth), int(max_breadth)
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        device = torch.cuda.current_device() if device is None else int(device)
         self.dev_index = device
         self.device = torch.device("cuda", device)
         self.sequential = bool(sequential)

@@ -44,11 +44,11 @@ def n_blocks_of(weights):
 
 
 class QNet:
-    def __init__(self, weights, input_shape, device=0, max_chunk=4096):
+    def __init__(self, weights, input_shape, device=None, max_chunk=4096):
         if not torch.cuda.is_available():
             raise EngineError("snake_engine.QNet needs an MI355X; there is no CPU fallback")
         self.L = lib()
-        self.device = torch.device("cuda", device)
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
         self.input_shape = tuple(int(v) for v in input_shape)
         self.h, self.w, self.cin = self.input_shape
         assert self.cin == 3

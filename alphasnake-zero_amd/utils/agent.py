@@ -115,7 +115,7 @@ class Agent:
         G = len(alive_h)
         if self._rec_engine is None or self._rec_used + G > self._rec_engine.n_slots:
             new_cap = max(4 * G, 2 * (self._rec_used + G), 256)
-            new = Engine(new_cap, eng.H, eng.W, eng.S, eng.health_dec, 0.0)
+            new = Engine(new_cap, eng.H, eng.W, eng.S, eng.health_dec, 0.0, device=eng.device.index)
             if self._rec_engine is not None and self._rec_used:
                 self._rec_engine.clone_to(new, n=self._rec_used, fanout=1)
             self._rec_engine = new
@@ -147,7 +147,7 @@ class Agent:
         if self._mcts is None:
             self._mcts = DeviceMCTS(self._evaluate, eng.H, eng.W, eng.S, self.softmax_base, self.training,
                                     self.max_MCTS_depth, self.max_MCTS_breadth, seed=self._seed,
-                                    device=eng.device.index or 0, sequential=self._sequential, tape_u=self._tape_u,
+                                    device=eng.device.index, sequential=self._sequential, tape_u=self._tape_u,
                                     tt_capacity=self._tt_capacity)
         slots = np.fromiter((g._slot for g in games.values()), np.int32, len(games))
         d_slots = torch.as_tensor(slots, device=eng.device)
@@ -174,7 +174,7 @@ class Agent:
     def _soft_arg(self, z):
         zt = torch.as_tensor(np.ascontiguousarray(z), device="cuda")
         pmf = torch.empty_like(zt)
-        am = torch.empty((zt.shape[0],), dtype=torch.uint8, device="cuda")
+        am = torch.empty((zt.shape[0],), dtype=torch.uint8, device=zt.device)
         check(lib().snk_softermax_argmax(zt.data_ptr(), zt.shape[0], float(self.softmax_base), pmf.data_ptr(),
                                          am.data_ptr(), torch.cuda.current_stream().cuda_stream))
         return pmf.cpu().numpy(), am.cpu().numpy().astype(int)

@@ -181,7 +181,7 @@ class Game:
 
     def subgame(self, subgame_id):
         """game.py:266-276: deep copy that never spawns food, fresh counters, copied rewards"""
-        eng = Engine(1, self.height, self.width, self.snake_cnt, self.health_dec, 0.0)
+        eng = Engine(1, self.height, self.width, self.snake_cnt, self.health_dec, 0.0, device=self._engine.device.index)
         self._engine.clone_to(eng, src_slots=np.array([self._slot], np.int32), fanout=1)
         return Game(subgame_id, self.height, self.width, self.snake_cnt, self.health_dec, 0.0, _engine=eng, _slot=0)
 

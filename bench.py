@@ -124,10 +124,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
+    backend = os.environ.get("SNK_DIST_BACKEND", "nccl")     # "gloo": rehearsal of the N > 1 path on fewer GPUs than ranks
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import snake_engine as se
@@ -149,6 +154,9 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if dev_index != 0:
+        pass
 
     t_w = time.time()
     gr.run(alice, max_turns=args.warmup)
@@ -174,7 +182,7 @@ def main():
     sdist.all_reduce_counters(gr.engine.sum_counters(), args.games, "cuda")
     barrier()
     dt = time.time() - t0
-    tt = torch.tensor([dt, float(env_steps)], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([dt, float(env_steps)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
