@@ -33,6 +33,11 @@ __device__ static inline bool food_bit(const uint64_t *food, int c) { return (fo
 
 // per-wave LDS carve-up used by step / observe
 __host__ __device__ static inline int lds_per_wave(const Layout &L) { return L.stride + 4 * L.nc_pad + 64; }
+// k_observe adds an output canvas of (2H-1)(2W-1)3 floats (+ alignment slack)
+__host__ __device__ static inline int lds_per_wave_obs(const Layout &L)
+{
+    return lds_per_wave(L) + (((2 * L.H - 1) * (2 * L.W - 1) * 3 + 8) * 4 + 15) / 16 * 16;
+}
 
 // ------------------------------------------------------------------------------------------
 // Game.tic (game.py:87-205)
@@ -60,6 +65,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
     const int slot = valid ? (slots ? slots[gi] : gi) : 0;
     uint8_t *gsrc = state + (size_t)slot * L.stride;
 
+    // the per-game inputs do not depend on the record: request them together with it (one HBM round trip, not two)
+    const int mv_in = (valid && lane < S) ? moves[(size_t)gi * S + lane] : 1;
+    const int tape_in = (valid && spawn_tape) ? spawn_tape[gi] : -1;
     if (valid)
         for (int i = lane; i < L.stride / 16; i += 64) ((uint4 *)g)[i] = ((const uint4 *)gsrc)[i];
     for (int i = lane * 4; i < 2 * L.nc_pad; i += 256) *(uint32_t *)(occ + i) = 0u;
@@ -83,8 +91,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
     int head_cell = -1;
     bool oob = false;
     if (go) {
-        const int mv = moves[(size_t)gi * S + lane];
-        const int d = (mv + m.dir + 3) & 3;            // (move + last - 1) % 4
+        const int d = (mv_in + m.dir + 3) & 3;            // (move + last - 1) % 4
         m.dir = (uint8_t)d;
         const int hi = (m.tail + m.len - 1) & mask;
         const int hc = ring[hi];
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
             n_empty += __popcll(mk);
         }
         if (spawn_tape) {
-            spawn = spawn_tape[gi];
+            spawn = tape_in;
         } else {
             const uint32_t uid = *(const uint32_t *)(g + L.uid_off);
             uint32_t r[4];
@@ -364,7 +371,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_observe(const uint8_t *__rest
     const int pi = blockIdx.x * WAVES_PER_BLOCK + wv;
     const bool valid = pi < m;
     const int S = L.S, mask = L.cap_mask;
-    uint8_t *g = smem + wv * lds_per_wave(L);
+    uint8_t *g = smem + wv * lds_per_wave_obs(L);
     uint16_t *ttl = (uint16_t *)(g + L.stride);             // max tail-distance of any node on the cell
     uint8_t *hidx = (uint8_t *)(g + L.stride + 2 * L.nc_pad);  // 1 + id of the snake whose head is here
     float *hval = (float *)(g + L.stride + 4 * L.nc_pad);   // channel-0 value per snake id (8 floats)
@@ -414,27 +421,58 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_observe(const uint8_t *__rest
     };
 
     if (planes) {
+        // The observation is the wall pattern almost everywhere (441 canvas pixels, 121 board cells): fill an LDS
+        // canvas with the pattern, scatter the board cells into their rotated positions, stream the canvas out
+        // with 16-byte stores.  The canvas is shifted by `lead` floats so that LDS and HBM addresses are congruent
+        // mod 16 bytes whatever the row's position in the output array.
         float *out = planes + (size_t)pi * NEL;
-        if (!live) {
-            if (valid) for (int e = lane; e < NEL; e += 64) out[e] = 0.0f;
-        } else {
-            for (int e = lane; e < NEL; e += 64) {
-                int p, ch;
-                if (layout == SNK_NHWC_F32) { p = e / 3; ch = e - 3 * p; }
-                else { ch = e / NPIX; p = e - ch * NPIX; }
-                const int i = p / N, j = p - i * N;
-                int si, sj;                              // numpy.rot90(grid, k): out[i][j] = grid[si][sj]
-                if (k == 0) { si = i; sj = j; }
-                else if (k == 1) { si = j; sj = N - 1 - i; }
-                else if (k == 2) { si = N - 1 - i; sj = N - 1 - j; }
-                else { si = N - 1 - j; sj = i; }
-                const int y = si - (H - 1) + hy, x = sj - (W - 1) + hx;
-                float v;
-                if (y < 0 || y >= H || x < 0 || x >= W) v = (ch == 1) ? 1.0f : 0.0f;   // WALL (game.py:4,219)
-                else v = cell_val(y * W + x, ch);
-                out[e] = v;
+        float *canvas = (float *)(g + L.stride + 4 * L.nc_pad + 64);
+        const int lead = (int)(((size_t)pi * NEL) & 3);
+        float *cv = canvas + lead;                     // cv[e] <-> out[e]
+        const int nvec = (NEL + lead + 3) / 4;
+        if (valid)
+            for (int q = lane; q < nvec; q += 64) {
+                float4 v;
+                float *pv = (float *)&v;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int e = 4 * q - lead + t;
+                    float d = 0.0f;
+                    if (live) d = (layout == SNK_NHWC_F32) ? (((e + 3) % 3 == 1) ? 1.0f : 0.0f)
+                                                           : ((e >= NPIX && e < 2 * NPIX) ? 1.0f : 0.0f);   // WALL (game.py:4,219)
+                    pv[t] = d;
+                }
+                *(float4 *)(canvas + 4 * q) = v;
             }
-        }
+        __syncthreads();
+        if (live)
+            for (int c = lane; c < NC; c += 64) {
+                const int y = c / W, x = c - y * W;
+                const int si = y - hy + (H - 1), sj = x - hx + (W - 1);
+                int i, j;                              // numpy.rot90(grid, k): out[i][j] = grid[si][sj], inverted
+                if (k == 0) { i = si; j = sj; }
+                else if (k == 1) { i = N - 1 - sj; j = si; }
+                else if (k == 2) { i = N - 1 - si; j = N - 1 - sj; }
+                else { i = sj; j = N - 1 - si; }
+                const int pp = i * N + j;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch)
+                    cv[(layout == SNK_NHWC_F32) ? 3 * pp + ch : ch * NPIX + pp] = cell_val(c, ch);
+            }
+        __syncthreads();
+        if (valid)
+            for (int q = lane; q < nvec; q += 64) {
+                const int e0 = 4 * q - lead;
+                const float4 v = *(const float4 *)(canvas + 4 * q);
+                if (e0 >= 0 && e0 + 3 < NEL) {
+                    *(float4 *)(out + e0) = v;
+                } else {
+                    const float *pv = (const float *)&v;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (e0 + t >= 0 && e0 + t < NEL) out[e0 + t] = pv[t];
+                }
+            }
     }
     if (mask_out && valid && lane < 3) {
         uint8_t b = 1;
@@ -684,7 +722,7 @@ extern "C" int snk_engine_observe(const snk_engine *e, const int32_t *d_pairs, i
     SNK_REQUIRE(layout == SNK_NHWC_F32 || layout == SNK_NCHW_F32, "snk_engine_observe: unknown layout %d", layout);
     if (m <= 0) return 0;
     const Layout L = e->L;
-    const size_t lds = (size_t)WAVES_PER_BLOCK * lds_per_wave(L);
+    const size_t lds = (size_t)WAVES_PER_BLOCK * lds_per_wave_obs(L);
     DISPATCH_BOARD(L, (k_observe<BH, BW><<<wave_grid(m), BLOCK_THREADS, lds, (hipStream_t)stream>>>(
         e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask)));
     SNK_CHECK_HIP(hipGetLastError());
