@@ -184,3 +184,77 @@ class Agent:
         if self._mcts is not None:
             self._mcts.clear()
         self._reset_records()
+
+
+class MCTSAgent(Agent):
+    """agent.py:149-223: the leaf agent of one rollout epoch -- cache de-duplication, one batched net call,
+    randomized move, in-rollout back-up -- with the reference's constructor and its ``keys`` / ``moves``
+    path dicts.  ``Agent.make_moves`` does not go through this class (its epochs run fused on the device,
+    snake_engine/mcts.py); it exists for callers that drive ``MCTSMPGameRunner`` themselves.  The four cache
+    arguments are the parent Agent's cache views (their HBM table is shared); anything else gets a private table."""
+
+    def __init__(self, nnet, softmax_base, games, cached_values, total_rewards, visit_cnts, cache_hit):
+        self.nnet = nnet
+        self.softmax_base = softmax_base
+        self.cached_values = cached_values
+        self.total_rewards = total_rewards
+        self.visit_cnts = visit_cnts
+        self.cache_hit = cache_hit
+        self.training = False
+        self.keys = {i: {s.id: [] for s in games[i].snakes} for i in games}
+        self.moves = {i: {s.id: [] for s in games[i].snakes} for i in games}
+        self._entries = {i: {sid: [] for sid in self.keys[i]} for i in games}
+        parent = getattr(cached_values, "_agent", None)
+        self._parent = parent
+        self._own_tt = None
+        self._now, self._max_age, self._ctr = 1, 8, 0
+        self._seed = int(np.random.randint(1 << 62))
+        if parent is not None and parent._mcts is not None:
+            self._now, self._max_age = max(1, parent._mcts.now), parent.max_MCTS_depth
+
+    def _table(self):
+        from snake_engine.mcts import TranspositionTable
+        if self._parent is not None and self._parent._mcts is not None and self._parent._mcts.tt is not None:
+            return self._parent._mcts.tt
+        if self._own_tt is None:
+            self._own_tt = TranspositionTable(1 << 20)
+        return self._own_tt
+
+    def make_moves(self, games, ids):
+        eng = games.engine
+        L, st, dev = lib(), torch.cuda.current_stream().cuda_stream, eng.device
+        gid_slot = {gid: g._slot for gid, g in games.items()}
+        m = len(ids)
+        pairs = torch.as_tensor(np.array([[gid_slot[g], s] for g, s in ids], np.int32).reshape(m, 2), device=dev)
+        key = torch.empty((m, 2), dtype=torch.int64, device=dev)
+        mask = torch.empty((m, 3), dtype=torch.uint8, device=dev)
+        eng.observe(pairs, m, None, mask, key)
+        tt = self._table()
+        entry = torch.empty((m,), dtype=torch.int32, device=dev)
+        new = torch.empty((m,), dtype=torch.uint8, device=dev)
+        check(L.snk_tt_lookup_insert(tt.h, key.data_ptr(), None, m, self._now, self._max_age, entry.data_ptr(), new.data_ptr(), st))
+        idx = torch.nonzero(new).to(torch.int32).reshape(-1).contiguous()      # agent.py:177-184: one evaluation per new key
+        if idx.numel():
+            planes = torch.empty((idx.numel(),) + eng.obs_shape, dtype=torch.float32, device=dev)
+            eng.observe(pairs.index_select(0, idx).contiguous(), idx.numel(), planes, None, None)
+            q = self._evaluate(planes, mask.index_select(0, idx).contiguous()).contiguous()
+            check(L.snk_tt_set_priors(tt.h, entry.data_ptr(), idx.data_ptr(), idx.numel(), q.data_ptr(), st))
+        D = max([len(self._entries[g][s]) for g, s in ids] + [0]) + 1
+        pe = np.full((m, D), -1, np.int32); pm = np.zeros((m, D), np.uint8); pl = np.zeros(m, np.int32)
+        for i, (g, s) in enumerate(ids):
+            n = len(self._entries[g][s])
+            pe[i, :n] = self._entries[g][s]; pm[i, :n] = self.moves[g][s]; pl[i] = n
+        d_pe, d_pm, d_pl = (torch.as_tensor(a, device=dev) for a in (pe, pm, pl))
+        mv = torch.empty((m,), dtype=torch.uint8, device=dev)
+        est = torch.empty((m,), dtype=torch.float32, device=dev)
+        self._ctr += 1
+        check(L.snk_mcts_select(tt.h, entry.data_ptr(), m, float(self.softmax_base), None, None, 0, self._seed, self._ctr, 0x4D41,
+                                mv.data_ptr(), est.data_ptr(), None, d_pe.data_ptr(), d_pm.data_ptr(), d_pl.data_ptr(), D, st))
+        check(L.snk_mcts_backup(tt.h, entry.data_ptr(), m, est.data_ptr(), None, d_pe.data_ptr(), d_pm.data_ptr(),
+                                d_pl.data_ptr(), D, 0, st))                       # agent.py:208-220
+        mv_h, ent_h, key_h = mv.cpu().numpy(), entry.cpu().numpy(), key.cpu().numpy()
+        for i, (g, s) in enumerate(ids):                                         # agent.py:221-222
+            self.keys[g][s].append(key_h[i].tobytes())
+            self.moves[g][s].append(int(mv_h[i]))
+            self._entries[g][s].append(int(ent_h[i]))
+        return mv_h.tolist()

@@ -249,3 +249,35 @@ def test_game_view_api(env):
     assert res == 0 or isinstance(res, list)
     assert g.game_length == 1 and sub.game_length == 0
     assert len(g.empty_positions) + len(g.heads) + len(g.bodies - set(g.heads)) + len(g.food) == 121
+
+
+def test_mcts_agent_and_mcts_runner_api(env):
+    """the reference's own epoch body (agent.py:39-72) written against MCTSAgent + MCTSMPGameRunner"""
+    torch, se = env
+    import random
+    from utils.agent import Agent, MCTSAgent
+    from utils.game import Game
+    from utils.mp_game_runner import MPGameRunner, MCTSMPGameRunner, GameDict
+    random.seed(2); np.random.seed(2)
+    MPGameRunner.verbose = False
+    alice = Agent(StubNNet(), 2, True, 4, 8, seed=1)
+    gr = MPGameRunner(11, 11, 4, 1, 3, seed=2)
+    games = gr.games
+    parallel = 8
+    sub_eng = se.Engine(len(games) * parallel, 11, 11, 4, 1, 0.0)
+    gr.engine.clone_to(sub_eng, src_slots=games.live_slots(), fanout=parallel)
+    subgames = GameDict(sub_eng, {i: Game(i, 11, 11, 4, 1, 0.0, _engine=sub_eng, _slot=i) for i in range(len(games) * parallel)})
+    depth = {i: 4 for i in subgames}
+    n_sub = len(subgames)
+    MCTSAlice = MCTSAgent(alice.nnet, alice.softmax_base, subgames, alice.cached_values, alice.total_rewards,
+                          alice.visit_cnts, alice.cache_hit)
+    rewards = MCTSMPGameRunner(subgames).run(MCTSAlice, depth)
+    assert len(rewards) == n_sub and len(subgames) == 0
+    for sid in range(n_sub):
+        assert len(rewards[sid]) == 4 and all(r in (None, 1.0, -1.0) for r in rewards[sid])
+        for snake in range(4):
+            k, mv = MCTSAlice.keys[sid][snake], MCTSAlice.moves[sid][snake]
+            assert 1 <= len(k) == len(mv) <= 4 and all(len(b) == 16 for b in k) and all(x in (0, 1, 2) for x in mv)
+    # all 8 clones of a root game start from the same observation -> same first key
+    for g in range(3):
+        assert len({MCTSAlice.keys[g * parallel + r][0][0] for r in range(parallel)}) == 1
