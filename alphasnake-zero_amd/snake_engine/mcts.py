@@ -94,7 +94,7 @@ class DeviceMCTS:
             cap = self.tt_capacity
             if cap is None:     # room for every state of ~max_depth+2 root turns at a 50 % load factor
                 per_turn = B * self.S * max(1, self.max_depth) * max(1, self.max_breadth // par)
-                cap = min(1 << 28, _pow2_at_least(2 * per_turn * (self.max_depth + 2) // 2))
+                cap = min(1 << 30, _pow2_at_least(2 * per_turn * (self.max_depth + 2) // 2))
             self.tt = TranspositionTable(_pow2_at_least(cap), self.dev_index)
         if self._bufs_B != B:
             S, D, dev = self.S, max(1, self.max_depth), self.device
@@ -154,7 +154,7 @@ class DeviceMCTS:
         epochs = self.max_breadth // par                        # agent.py:37
         tt = self.tt.h
         seq = int(self.sequential)
-        for _ in range(epochs):
+        for ep in range(epochs):
             root.clone_to(self.roll, src_slots=live_slots, n=G, fanout=par)       # game.subgame (agent.py:46-50)
             self.path_len.zero_()
             sub_active = torch.ones((B,), dtype=torch.bool, device=self.device)
@@ -206,6 +206,15 @@ class DeviceMCTS:
             check(L.snk_engine_rewards(self.roll.h, None, B, _ptr(self.rewards), st))
             check(L.snk_mcts_terminal_backup(tt, _ptr(self.rewards), m, _ptr(self.path_entry), _ptr(self.path_move),
                                              _ptr(self.path_len), D, seq, st))   # agent.py:60-72
+            if ep + 1 < epochs:
+                # paths die with the epoch, so the table may be re-hashed here: keep the load factor below 1/2 even
+                # when one root turn inserts more keys than the table was sized for (nothing is evicted: max_age = inf)
+                cap, occ, ovf = self.tt.status()
+                if ovf:
+                    raise EngineError("transposition table overflowed inside an epoch; raise tt_capacity")
+                if occ * 2 > cap:
+                    self.tt.rebuild(cap * 2, self.now, 1 << 30)
+                    tt = self.tt.h
         # V[i] = cached_values[first_key] (agent.py:74-87): the root observation's entry, from clone 0 of each game
         first = self.path_entry.view(G, par, S, D)[:, 0, :, 0].contiguous().reshape(-1)
         root_rows_alive = root_alive.reshape(-1).contiguous()
