@@ -236,21 +236,18 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino_f32(WinoArgs p)
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
             raw[4 * i + j] = xcl[(size_t)(rowoff[i] + coloff[j]) + (c) * WG_KC];
 #define WG_TRANSFORM_STORE(buf)                                                                 \
-    {                                                                                           \
-        float d_[16];                                                                           \
-        _Pragma("unroll") for (int q = 0; q < 16; ++q) d_[q] = ((vmask >> q) & 1u) ? raw[q] : 0.f; \
-        float r_[16];                                                                           \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                         \
-            r_[0 + j] = d_[0 + j] - d_[8 + j];                                                  \
-            r_[4 + j] = d_[4 + j] + d_[8 + j];                                                  \
-            r_[8 + j] = d_[8 + j] - d_[4 + j];                                                  \
-            r_[12 + j] = d_[4 + j] - d_[12 + j];                                                \
-        }                                                                                       \
+    {   /* B^T d B row by row: output row i needs only r_i[j] = (B^T d)[i][j], so 8 temporaries are live, not 32 */ \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) raw[q] = ((vmask >> q) & 1u) ? raw[q] : 0.f; \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                         \
-            Vs[buf][4 * i + 0][tl][cl] = r_[4 * i + 0] - r_[4 * i + 2];                         \
-            Vs[buf][4 * i + 1][tl][cl] = r_[4 * i + 1] + r_[4 * i + 2];                         \
-            Vs[buf][4 * i + 2][tl][cl] = r_[4 * i + 2] - r_[4 * i + 1];                         \
-            Vs[buf][4 * i + 3][tl][cl] = r_[4 * i + 1] - r_[4 * i + 3];                         \
+            float r0_, r1_, r2_, r3_;                                                           \
+            if (i == 0)      { r0_ = raw[0] - raw[8];  r1_ = raw[1] - raw[9];  r2_ = raw[2] - raw[10];  r3_ = raw[3] - raw[11]; }  \
+            else if (i == 1) { r0_ = raw[4] + raw[8];  r1_ = raw[5] + raw[9];  r2_ = raw[6] + raw[10];  r3_ = raw[7] + raw[11]; }  \
+            else if (i == 2) { r0_ = raw[8] - raw[4];  r1_ = raw[9] - raw[5];  r2_ = raw[10] - raw[6];  r3_ = raw[11] - raw[7]; }  \
+            else             { r0_ = raw[4] - raw[12]; r1_ = raw[5] - raw[13]; r2_ = raw[6] - raw[14];  r3_ = raw[7] - raw[15]; } \
+            Vs[buf][4 * i + 0][tl][cl] = r0_ - r2_;                                             \
+            Vs[buf][4 * i + 1][tl][cl] = r1_ + r2_;                                             \
+            Vs[buf][4 * i + 2][tl][cl] = r2_ - r1_;                                             \
+            Vs[buf][4 * i + 3][tl][cl] = r1_ - r3_;                                             \
         }                                                                                       \
     }
 

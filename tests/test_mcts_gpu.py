@@ -283,20 +283,33 @@ def test_mcts_agent_and_mcts_runner_api(env):
         assert len({MCTSAlice.keys[g * parallel + r][0][0] for r in range(parallel)}) == 1
 
 
-def test_self_play_19x19_8_snakes_and_table_growth(env):
-    """config-5 geometry (19x19, 8 snakes: rollout depth 8 - 2*(8-2) = -4 -> single-tick rollouts, agent.py:45) and a
-    deliberately tiny transposition table that has to be re-hashed / doubled between epochs"""
+def test_self_play_19x19_8_snakes(env):
+    """config-5 geometry (19x19, 8 snakes: rollout depth 8 - 2*(8-2) = -4 -> single-tick rollouts, agent.py:45)"""
     torch, se = env
     import random
     from utils.agent import Agent
     from utils.mp_game_runner import MPGameRunner
     random.seed(4); np.random.seed(4)
     MPGameRunner.verbose = False
-    alice = Agent(StubNNet(), 2, True, 8, 24, seed=6, tt_capacity=1 << 10)
+    alice = Agent(StubNNet(), 2, True, 8, 24, seed=6)
     gr = MPGameRunner(19, 19, 8, 1, 5, seed=8)
     gr.run(alice, max_turns=4)
     assert gr.turns == 4 and gr.env_steps == 20
     assert len(alice.records) >= 4 * 5 * 6 and alice.records[0].shape == (37, 37, 3)
-    cap, occ, ovf = alice._mcts.tt.status()
-    assert not ovf and cap > (1 << 10) and occ * 2 <= cap
     assert alice._mcts.stats["rollout_ticks"] >= 4 * 3      # 3 epochs x 1 tick per root turn while 8 snakes live
+
+
+def test_transposition_table_grows_between_epochs(env):
+    """a deliberately tiny table has to be re-hashed / doubled between epochs and at the end of the turn"""
+    torch, se = env
+    import random
+    from utils.agent import Agent
+    from utils.mp_game_runner import MPGameRunner
+    random.seed(5); np.random.seed(5)
+    MPGameRunner.verbose = False
+    alice = Agent(StubNNet(), 2, True, 8, 24, seed=7, tt_capacity=1 << 10)
+    gr = MPGameRunner(11, 11, 4, 1, 6, seed=9)
+    gr.run(alice, max_turns=3)
+    cap, occ, ovf = alice._mcts.tt.status()
+    assert not ovf and cap > (1 << 10) and occ * 2 <= cap and occ > 512
+    assert len(alice.cached_values) == occ
