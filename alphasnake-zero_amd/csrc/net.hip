@@ -188,7 +188,6 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_conv3x3_f32(ConvArgs p)
 #define WG_TB 32          // tiles per block
 #define WG_KC 16          // input channels per chunk
 #define WG_LD 20          // padded V row (floats)
-#define WG_MLD 68         // M row: 64 outputs + 4 pad (floats, 16-byte aligned rows)
 
 struct WinoArgs {
     const float *x;      // [n][Hd][Wd][128]
@@ -201,76 +200,98 @@ struct WinoArgs {
     int relu;
 };
 
-__global__ __launch_bounds__(512, 2) void k_conv3x3_wino_f32(WinoArgs p)
+// NW wavefronts per block, each owning PPW = 16 / NW positions:
+//   NW = 8: 512 threads, 2 positions per wave (128 accumulator VGPRs), 1 block per CU (2 waves per SIMD share its barriers);
+//   NW = 4: 256 threads, 4 positions per wave (256 accumulator VGPRs), 80 KB of LDS -> 2 independent blocks per CU, one
+//           wave per SIMD each, so one block's transform / barrier / epilogue hides behind the other block's MFMAs.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void k_conv3x3_wino_f32(WinoArgs p)
 {
-    __shared__ __align__(16) float smem[16 * WG_TB * WG_MLD];         // 139 264 B: V double buffer (first 81 920 B), reused as M
+    constexpr int PPW = 16 / NW;                   // positions per wave
+    constexpr int NT = 64 * NW;                    // threads
+    constexpr int ITEMS = (WG_TB * WG_KC) / NT;    // (tile, channel) patches each thread transforms per chunk
+    constexpr int EPC = (NW == 8) ? 64 : 32;       // outputs per epilogue pass
+    constexpr int MLD = EPC + 4;                   // M row (floats), 16-byte aligned
+    constexpr int SMEM_V = 2 * 16 * WG_TB * WG_LD, SMEM_M = 16 * WG_TB * MLD;
+    __shared__ __align__(16) float smem[SMEM_V > SMEM_M ? SMEM_V : SMEM_M];    // V double buffer, reused as M
     float(*Vs)[16][WG_TB][WG_LD] = (float(*)[16][WG_TB][WG_LD])smem;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int h = lane >> 5, l31 = lane & 31;
     const int t0 = blockIdx.x * WG_TB;
     const int tiles_per_img = p.TY * p.TX;
 
-    // ---- input-transform role: thread = (tile tl, channel cl of the chunk)
-    const int tl = tid >> 4, cl = tid & 15;
-    unsigned vmask = 0;                       // bit (4 i + j): patch pixel (i, j) lies inside the image
-    unsigned rowoff[4] = {0, 0, 0, 0}, coloff[4] = {0, 0, 0, 0};   // element offsets of the (clamped, always readable) patch rows / columns
-    {
+    // ---- input-transform role: item it of this thread = (tile tl[it], channel cl of the chunk)
+    const int cl = tid & 15;
+    unsigned vmask[ITEMS];                       // bit (4 i + j): patch pixel (i, j) lies inside the image
+    unsigned rowoff[ITEMS][4], coloff[ITEMS][4]; // element offsets of the (clamped, always readable) patch rows / columns
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int tl = (tid + it * NT) >> 4;
         const int t = t0 + tl;
+        vmask[it] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rowoff[it][i] = coloff[it][i] = 0;
         if (t < p.n_tiles) {
             const int img = t / tiles_per_img, r = t - img * tiles_per_img;
             const int ty = r / p.TX, tx = r - ty * p.TX;
             const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+#pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int yc = min(max(y0 + i, 0), p.Hd - 1), xc = min(max(x0 + i, 0), p.Wd - 1);
-                rowoff[i] = (unsigned)((img * p.Hd + yc) * p.Wd) * CV_C;
-                coloff[i] = (unsigned)xc * CV_C;
+                rowoff[it][i] = (unsigned)((img * p.Hd + yc) * p.Wd) * CV_C;
+                coloff[it][i] = (unsigned)xc * CV_C;
+#pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (y0 + i >= 0 && y0 + i < p.Hd && x0 + j >= 0 && x0 + j < p.Wd) vmask |= 1u << (4 * i + j);
+                    if (y0 + i >= 0 && y0 + i < p.Hd && x0 + j >= 0 && x0 + j < p.Wd) vmask[it] |= 1u << (4 * i + j);
             }
         }
     }
-    float raw[16];
+    float raw[ITEMS][16];
     const float *xcl = p.x + cl;
 #define WG_LOAD_RAW(c)                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
-            raw[4 * i + j] = xcl[(size_t)(rowoff[i] + coloff[j]) + (c) * WG_KC];
+    _Pragma("unroll") for (int it = 0; it < ITEMS; ++it)                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                       \
+                raw[it][4 * i + j] = xcl[(size_t)(rowoff[it][i] + coloff[it][j]) + (c) * WG_KC];
 #define WG_TRANSFORM_STORE(buf)                                                                 \
-    {   /* B^T d B row by row: output row i needs only r_i[j] = (B^T d)[i][j], so 8 temporaries are live, not 32 */ \
-        _Pragma("unroll") for (int q = 0; q < 16; ++q) raw[q] = ((vmask >> q) & 1u) ? raw[q] : 0.f; \
+    _Pragma("unroll") for (int it = 0; it < ITEMS; ++it) {                                      \
+        /* B^T d B row by row: output row i needs only r_i[j] = (B^T d)[i][j] */               \
+        const int tl_ = (tid + it * NT) >> 4;                                                   \
+        float *w_ = raw[it];                                                                    \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) w_[q] = ((vmask[it] >> q) & 1u) ? w_[q] : 0.f; \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                         \
             float r0_, r1_, r2_, r3_;                                                           \
-            if (i == 0)      { r0_ = raw[0] - raw[8];  r1_ = raw[1] - raw[9];  r2_ = raw[2] - raw[10];  r3_ = raw[3] - raw[11]; }  \
-            else if (i == 1) { r0_ = raw[4] + raw[8];  r1_ = raw[5] + raw[9];  r2_ = raw[6] + raw[10];  r3_ = raw[7] + raw[11]; }  \
-            else if (i == 2) { r0_ = raw[8] - raw[4];  r1_ = raw[9] - raw[5];  r2_ = raw[10] - raw[6];  r3_ = raw[11] - raw[7]; }  \
-            else             { r0_ = raw[4] - raw[12]; r1_ = raw[5] - raw[13]; r2_ = raw[6] - raw[14];  r3_ = raw[7] - raw[15]; } \
-            Vs[buf][4 * i + 0][tl][cl] = r0_ - r2_;                                             \
-            Vs[buf][4 * i + 1][tl][cl] = r1_ + r2_;                                             \
-            Vs[buf][4 * i + 2][tl][cl] = r2_ - r1_;                                             \
-            Vs[buf][4 * i + 3][tl][cl] = r1_ - r3_;                                             \
+            if (i == 0)      { r0_ = w_[0] - w_[8];  r1_ = w_[1] - w_[9];  r2_ = w_[2] - w_[10];  r3_ = w_[3] - w_[11]; }  \
+            else if (i == 1) { r0_ = w_[4] + w_[8];  r1_ = w_[5] + w_[9];  r2_ = w_[6] + w_[10];  r3_ = w_[7] + w_[11]; }  \
+            else if (i == 2) { r0_ = w_[8] - w_[4];  r1_ = w_[9] - w_[5];  r2_ = w_[10] - w_[6];  r3_ = w_[11] - w_[7]; }  \
+            else             { r0_ = w_[4] - w_[12]; r1_ = w_[5] - w_[13]; r2_ = w_[6] - w_[14];  r3_ = w_[7] - w_[15]; } \
+            Vs[buf][4 * i + 0][tl_][cl] = r0_ - r2_;                                            \
+            Vs[buf][4 * i + 1][tl_][cl] = r1_ + r2_;                                            \
+            Vs[buf][4 * i + 2][tl_][cl] = r2_ - r1_;                                            \
+            Vs[buf][4 * i + 3][tl_][cl] = r1_ - r3_;                                            \
         }                                                                                       \
     }
 
-    // ---- GEMM role: wave wv owns positions 2 wv, 2 wv + 1
-    f32x16 acc[2][4];
+    // ---- GEMM role: wave wv owns positions PPW wv .. PPW wv + PPW - 1
+    f32x16 acc[PPW][4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < PPW; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     // U fragment of (position pi, n-tile nt) for k8-step (c, s): float4 at U[p][(16 c + 8 s + 4 h) / 4][32 nt + l31][0..3]
-    const float4 *Ub = (const float4 *)p.U + ((long)(2 * wv) * 32 + h) * 128 + l31;
+    const float4 *Ub = (const float4 *)p.U + ((long)(PPW * wv) * 32 + h) * 128 + l31;
 #define WG_LOAD_B(dst, c, s)                                                                    \
-    _Pragma("unroll") for (int pi = 0; pi < 2; ++pi)                                            \
+    _Pragma("unroll") for (int pi = 0; pi < PPW; ++pi)                                          \
         _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                        \
             dst[pi][nt] = Ub[((long)pi * 32 + (c) * 4 + (s) * 2) * 128 + nt * 32];
 #define WG_MFMA(buf, s, B)                                                                      \
     {                                                                                           \
-        float4 a_[2];                                                                           \
-        _Pragma("unroll") for (int pi = 0; pi < 2; ++pi)                                        \
-            a_[pi] = *(const float4 *)&Vs[buf][2 * wv + pi][l31][(s) * 8 + 4 * h];              \
-        _Pragma("unroll") for (int pi = 0; pi < 2; ++pi)                                        \
+        float4 a_[PPW];                                                                         \
+        _Pragma("unroll") for (int pi = 0; pi < PPW; ++pi)                                      \
+            a_[pi] = *(const float4 *)&Vs[buf][PPW * wv + pi][l31][(s) * 8 + 4 * h];            \
+        _Pragma("unroll") for (int pi = 0; pi < PPW; ++pi)                                      \
             _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                  \
                 acc[pi][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[pi].x, B[pi][nt].x, acc[pi][nt], 0, 0, 0); \
                 acc[pi][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[pi].y, B[pi][nt].y, acc[pi][nt], 0, 0, 0); \
@@ -280,21 +301,19 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino_f32(WinoArgs p)
     }
 
     constexpr int NCH = CV_C / WG_KC;
-#define WG_CH(c) (c)
-    float4 B0[2][4], B1[2][4];
-    WG_LOAD_RAW(WG_CH(0));
-    WG_LOAD_B(B0, WG_CH(0), 0);
+    float4 B0[PPW][4], B1[PPW][4];
+    WG_LOAD_RAW(0);
+    WG_LOAD_B(B0, 0, 0);
     WG_TRANSFORM_STORE(0);
     __syncthreads();
 
     for (int c = 0; c < NCH; ++c) {
         const int buf = c & 1;
-        WG_LOAD_B(B1, WG_CH(c), 1);                       // B first: vmcnt retires in order, the raw (HBM) loads must not gate it
-        if (c + 1 < NCH) { WG_LOAD_RAW(WG_CH(c + 1)); }
+        WG_LOAD_B(B1, c, 1);                              // only the 8 B loads right after the barrier (all waves issue here at once)
         __builtin_amdgcn_sched_barrier(0);
         WG_MFMA(buf, 0, B0);
         __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < NCH) { WG_LOAD_B(B0, WG_CH(c + 1), 0); }
+        if (c + 1 < NCH) { WG_LOAD_B(B0, c + 1, 0); WG_LOAD_RAW(c + 1); }   // B before raw: vmcnt retires in order
         __builtin_amdgcn_sched_barrier(0);
         WG_MFMA(buf, 1, B1);
         __builtin_amdgcn_sched_barrier(0);
@@ -302,15 +321,15 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino_f32(WinoArgs p)
         __syncthreads();
     }
 #undef WG_LOAD_RAW
-#undef WG_CH
 #undef WG_TRANSFORM_STORE
 #undef WG_LOAD_B
 #undef WG_MFMA
 
-    // ---- epilogue: M -> LDS in two 64-output halves, inverse transform A^T M A on 4 outputs per thread,
+    // ---- epilogue: M -> LDS one EPC-output slice at a time, inverse transform A^T M A on 4 outputs per thread,
     //      BN (+ residual) + ReLU, 2x2 pixels x float4 written
-    float(*Ms)[WG_TB][WG_MLD] = (float(*)[WG_TB][WG_MLD])smem;     // [16 p][32 tiles][64 + 4]
-    const int tq = tid >> 4, quad = tid & 15;                       // output role: tile tq, outputs 4 quad .. 4 quad + 3 of the half
+    float(*Ms)[WG_TB][MLD] = (float(*)[WG_TB][MLD])smem;          // [16 p][32 tiles][EPC + 4]
+    constexpr int QPT = EPC / 4;                                    // output quads per tile and pass
+    const int tq = tid / QPT, quad = tid % QPT;                     // output role: tile tq, outputs 4 quad .. 4 quad + 3 of the slice
     const int t = t0 + tq;
     const bool tvalid = t < p.n_tiles;
     int oy = 0, ox = 0;
@@ -322,8 +341,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino_f32(WinoArgs p)
         obase = ((long)(img * p.Hd + oy) * p.Wd + ox) * CV_C;
     }
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int co = half * 64 + quad * 4;
+    for (int pass = 0; pass < CV_C / EPC; ++pass) {
+        const int co = pass * EPC + quad * 4;
         float4 rres[2][2];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -333,12 +352,12 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_wino_f32(WinoArgs p)
                 rres[a][b] = ok ? *(const float4 *)(p.res + obase + (long)(a * p.Wd + b) * CV_C + co) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-        for (int pi = 0; pi < 2; ++pi)
+        for (int pi = 0; pi < PPW; ++pi)
 #pragma unroll
-            for (int nn = 0; nn < 2; ++nn)
+            for (int nn = 0; nn < EPC / 32; ++nn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    Ms[2 * wv + pi][(r & 3) + 8 * (r >> 2) + 4 * h][nn * 32 + l31] = acc[pi][2 * half + nn][r];
+                    Ms[PPW * wv + pi][(r & 3) + 8 * (r >> 2) + 4 * h][nn * 32 + l31] = acc[pi][pass * (EPC / 32) + nn][r];
         __syncthreads();
         if (tvalid) {
             const float4 sc = *(const float4 *)(p.scale + co), sh = *(const float4 *)(p.shift + co);
@@ -558,7 +577,10 @@ extern "C" int snk_conv3x3_bn_f32_winograd(const float *d_x, const float *d_U, c
     const long tiles = (long)n_images * TY * TX;
     SNK_REQUIRE((long)n_images * height * width < (1l << 31) / 4, "snk_conv3x3_bn_f32_winograd: batch of %d images too large for one call", n_images);
     WinoArgs a = {d_x, d_U, d_scale, d_shift, d_residual, d_out, (int)tiles, height, width, TY, TX, relu};
-    k_conv3x3_wino_f32<<<(int)((tiles + WG_TB - 1) / WG_TB), 512, 0, (hipStream_t)stream>>>(a);
+    static int nw = -1;
+    if (nw < 0) { const char *v = getenv("SNK_WINO_WAVES"); nw = v ? atoi(v) : 8; }
+    if (nw == 8) k_conv3x3_wino_f32<8><<<(int)((tiles + WG_TB - 1) / WG_TB), 512, 0, (hipStream_t)stream>>>(a);
+    else k_conv3x3_wino_f32<4><<<(int)((tiles + WG_TB - 1) / WG_TB), 256, 0, (hipStream_t)stream>>>(a);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
