@@ -692,9 +692,9 @@ extern "C" int snk_engine_step(snk_engine *e, const int32_t *d_slots, int n, con
                                uint64_t *d_empty, void *stream)
 {
     SNK_REQUIRE(e != nullptr, "snk_engine_step: engine is NULL");
-    SNK_REQUIRE(d_moves != nullptr, "snk_engine_step: d_moves is NULL");
     SNK_REQUIRE(n >= 0 && (d_slots || n <= e->n_slots), "snk_engine_step: n=%d exceeds %d slots", n, e->n_slots);
     if (n == 0) return 0;
+    SNK_REQUIRE(d_moves != nullptr, "snk_engine_step: d_moves is NULL");
     const Layout L = e->L;
     const size_t lds = (size_t)WAVES_PER_BLOCK * lds_per_wave(L);
     DISPATCH_BOARD(L, (k_step<BH, BW><<<wave_grid(n), BLOCK_THREADS, lds, (hipStream_t)stream>>>(
@@ -718,9 +718,10 @@ extern "C" int snk_engine_alive(const snk_engine *e, const int32_t *d_slots, int
 extern "C" int snk_engine_observe(const snk_engine *e, const int32_t *d_pairs, int m, int layout,
                                   float *d_planes, uint8_t *d_mask, uint64_t *d_key, int legacy_mask, void *stream)
 {
-    SNK_REQUIRE(e != nullptr && d_pairs != nullptr, "snk_engine_observe: NULL argument");
+    SNK_REQUIRE(e != nullptr, "snk_engine_observe: engine is NULL");
     SNK_REQUIRE(layout == SNK_NHWC_F32 || layout == SNK_NCHW_F32, "snk_engine_observe: unknown layout %d", layout);
-    if (m <= 0) return 0;
+    if (m <= 0) return 0;                               // an empty request is a no-op (its buffers may be NULL)
+    SNK_REQUIRE(d_pairs != nullptr, "snk_engine_observe: d_pairs is NULL");
     const Layout L = e->L;
     const size_t lds = (size_t)WAVES_PER_BLOCK * lds_per_wave_obs(L);
     DISPATCH_BOARD(L, (k_observe<BH, BW><<<wave_grid(m), BLOCK_THREADS, lds, (hipStream_t)stream>>>(
@@ -846,10 +847,11 @@ extern "C" int snk_compact_scratch_elems(int n) { return (n + CMP_TILE - 1) / CM
 extern "C" int snk_compact_flags(const uint8_t *d_flags, int n, int32_t *d_out, int32_t *d_count,
                                  int32_t *d_scratch, void *stream)
 {
-    SNK_REQUIRE(d_flags && d_out && d_count && d_scratch, "snk_compact_flags: NULL argument");
+    SNK_REQUIRE(d_count != nullptr, "snk_compact_flags: d_count is NULL");
     SNK_REQUIRE(n >= 0, "snk_compact_flags: negative n");
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) { SNK_CHECK_HIP(hipMemsetAsync(d_count, 0, sizeof(int32_t), st)); return 0; }
+    SNK_REQUIRE(d_flags && d_out && d_scratch, "snk_compact_flags: NULL argument");
     const int tiles = (n + CMP_TILE - 1) / CMP_TILE;
     k_cmp_count<<<tiles, CMP_THREADS, 0, st>>>(d_flags, n, d_scratch);
     k_cmp_scan<<<1, CMP_THREADS, 0, st>>>(d_scratch, tiles, d_count);

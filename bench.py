@@ -155,8 +155,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if dev_index != 0:
-        pass
 
     t_w = time.time()
     gr.run(alice, max_turns=args.warmup)

@@ -372,3 +372,34 @@ def test_large_batch_invariants(se):
                 assert cst["rewards"][s] == -1
         assert len(cells) == len(set(cells)), "two snakes overlap"
         assert not (cst["food"][cells] if cells else np.zeros(0)).any(), "food under a snake"
+
+
+def test_error_codes_and_empty_inputs(se):
+    """C-ABI error behaviour: bad arguments come back as negative codes with a message (no crash); n = 0 is a no-op"""
+    import ctypes as C
+    import torch
+    from snake_engine._lib import lib, EngineError
+    L = lib()
+    h = C.c_void_p()
+    assert L.snk_engine_create(C.byref(h), 4, 12, 12, 4, 1, 0.15, 1, 0) < 0 and b"unsupported board" in L.snk_last_error()
+    assert L.snk_engine_create(C.byref(h), 4, 11, 11, 9, 1, 0.15, 1, 0) < 0 and b"snake count" in L.snk_last_error()
+    assert L.snk_engine_create(C.byref(h), 0, 11, 11, 4, 1, 0.15, 1, 0) < 0
+    with pytest.raises(EngineError):
+        se.Engine(4, 13, 13, 4)
+    eng = se.Engine(8, 11, 11, 4)
+    eng.reset()
+    mv = eng.new((16, 4), torch.uint8, 1)
+    with pytest.raises(EngineError):
+        eng.step(mv, n=9)                                  # more games than slots
+    with pytest.raises(EngineError):
+        eng.clone_to(se.Engine(4, 7, 7, 2))                # geometry mismatch
+    with pytest.raises(EngineError):
+        eng.clone_to(se.Engine(8, 11, 11, 4), fanout=2)    # 16 copies into 8 slots
+    before = [bytes(memoryview(s)) for s in eng.export()]
+    eng.step(mv, n=0)
+    eng.reset(n=0)
+    eng.observe(torch.zeros((0, 2), dtype=torch.int32, device="cuda"), 0, None, None, None)
+    assert [bytes(memoryview(s)) for s in eng.export()] == before
+    assert L.snk_tt_create(C.byref(h), 1000, 0) < 0 and b"power of two" in L.snk_last_error()
+    idx, cnt = eng.compact(torch.zeros(0, dtype=torch.uint8, device="cuda"), n=0)
+    assert int(cnt.item()) == 0
