@@ -55,7 +55,8 @@ class QNet:
         self.max_chunk = int(max_chunk)
         self._ws = None
         self.conv_timing = None      # set to a list to collect (start_event, end_event, flops) per conv3x3 launch
-        # "winograd": F(2x2,3x3) fp32 MFMA kernel (2.05x fewer flops); "direct": implicit-GEMM fp32 MFMA kernel
+        # "winograd": F(2x2,3x3) fp32 MFMA kernel (2.05x fewer flops); "direct": implicit-GEMM fp32 MFMA kernel;
+        # "bf16": bf16 MFMA with fp32 accumulation (configs[4]; does NOT meet the 1e-5 parity tolerance)
         self.conv_algo = os.environ.get("SNK_CONV_ALGO", "winograd")
         self.set_weights(weights)
 
@@ -75,7 +76,10 @@ class QNet:
         st = torch.cuda.current_stream().cuda_stream
         for i in range(2 * self.blocks):
             base = 5 + 5 * i
-            if self.conv_algo == "winograd":
+            if self.conv_algo == "bf16":
+                wT = torch.empty(9 * 128 * 128, dtype=torch.int16, device=dev)
+                check(self.L.snk_conv3x3_prepare_weights_bf16(t[base].contiguous().data_ptr(), wT.data_ptr(), st))
+            elif self.conv_algo == "winograd":
                 wT = torch.empty(16 * 128 * 128, dtype=torch.float32, device=dev)
                 check(self.L.snk_conv3x3_prepare_weights_winograd(t[base].contiguous().data_ptr(), wT.data_ptr(), st))
             else:
@@ -136,7 +140,8 @@ class QNet:
         if tm is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        fn = self.L.snk_conv3x3_bn_f32_winograd if self.conv_algo == "winograd" else self.L.snk_conv3x3_bn_f32
+        fn = {"winograd": self.L.snk_conv3x3_bn_f32_winograd, "bf16": self.L.snk_conv3x3_bn_bf16}.get(
+            self.conv_algo, self.L.snk_conv3x3_bn_f32)
         check(fn(x.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
                  self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),
                  out.data_ptr(), m, self.h, self.w, 1, st))

@@ -116,10 +116,14 @@ def main():
     ap.add_argument("--games", type=int, default=4096, help="parallel root games per GPU")
     ap.add_argument("--breadth", type=int, default=50)
     ap.add_argument("--chunk", type=int, default=8192, help="states per net forward chunk")
+    ap.add_argument("--conv-algo", choices=["winograd", "direct", "bf16"], default=None,
+                    help="default: winograd (fp32, the judged configuration); bf16 = configs[4]-style bf16 MFMA, outside the 1e-5 tolerance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rooflines", action="store_true")
     args = ap.parse_args()
 
+    if args.conv_algo:
+        os.environ["SNK_CONV_ALGO"] = args.conv_algo
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -194,6 +198,7 @@ def main():
         conv_s = sum(a.elapsed_time(b) for a, b, _ in tm) * 1e-3
         conv_flops = sum(f for _, _, f in tm)
         achieved = conv_flops / conv_s / 1e12 if conv_s > 0 else 0.0
+        peak = 2500.0 if nnet._qnet.conv_algo == "bf16" else 157.3      # dense MFMA peaks, MI355X_MICROARCH.md
         traffic = None      # HBM bytes per average launch, from the committed rocprofv3 --pmc passes (profiles/)
         tfile = os.path.join(REPO, "profiles", "r1_conv_traffic.json")
         if os.path.exists(tfile) and tm:
@@ -203,20 +208,22 @@ def main():
             "metric": "self-play env-steps/sec (11x11, 4 snakes, 50 MCTS sims)",
             "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "bf16 operands, f32 accumulate (outside the 1e-5 parity tolerance)" if nnet._qnet.conv_algo == "bf16" else "f32",
+            "data": "synthetic",
             "config": {"workload": f"configs[1]: 11x11, 4 snakes, {args.games} parallel games per GPU, max_MCTS_breadth "
                                    f"{args.breadth} (= {args.breadth // 8 * 8} rollouts), depth 8, health_dec 1, softmax_base 2, "
                                    "training=True, gen-0 Glorot net (seed 0), fp32 Q-net",
                        "games_per_gpu": args.games, "breadth": args.breadth, "parallelism": f"games sharded x{world}",
                        "net_evals_per_env_step": evals / max(1, gr.env_steps), "sim_steps_per_env_step": sims / max(1, gr.env_steps),
                        "net_evals_per_s_rank0": evals / dt, "sample_rows_gathered": int(Xg.shape[0])},
-            "roofline": {"bound": "mfma", "kernel": "k_conv3x3_wino_f32" if nnet._qnet.conv_algo == "winograd" else "k_conv3x3_f32",
-                         "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": achieved / 157.3, "traffic": traffic, "launches": len(tm),
+            "roofline": {"bound": "mfma", "kernel": {"winograd": "k_conv3x3_wino_f32", "bf16": "k_conv3x3_bf16"}.get(nnet._qnet.conv_algo, "k_conv3x3_f32"),
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic if nnet._qnet.conv_algo == "winograd" else None, "launches": len(tm),
                          "flops_convention": "algorithmic = direct 3x3 convolution, 2*441*1152*128 per state and layer (SURVEY 8d)",
-                         "executed_frac": achieved / 157.3 * (16 * 121 / (441 * 9.0) if nnet._qnet.conv_algo == "winograd" else 1.0),
+                         "executed_frac": achieved / peak * (16 * 121 / (441 * 9.0) if nnet._qnet.conv_algo == "winograd" else 1.0),
                          "algorithm": ("Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: executes 16*121/(441*9) = 0.488 of the "
                                        "algorithmic flops, fp32 throughout" if nnet._qnet.conv_algo == "winograd"
+                                       else "implicit GEMM on v_mfma_f32_32x32x16_bf16" if nnet._qnet.conv_algo == "bf16"
                                        else "implicit GEMM on v_mfma_f32_32x32x2_f32"),
                          "avg_launch_ms": conv_s / max(1, len(tm)) * 1e3,
                          "share_of_step_time": conv_s / dt},

@@ -148,6 +148,13 @@ int snk_conv3x3_prepare_weights(const float *d_w_hwio, float *d_wT, void *stream
 int snk_conv3x3_bn_f32(const float *d_x, const float *d_wT, const float *d_scale, const float *d_shift,
                        const float *d_residual, float *d_out, int n_images, int height, int width,
                        int relu, void *stream);
+/* bf16 form (BASELINE.json configs[4], "bf16 MFMA conv"; NOT the 1e-5 parity path): float32 activations in HBM,
+ * operands rounded to bf16 on the way into LDS, v_mfma_f32_32x32x16_bf16 with float32 accumulation.
+ * d_wT_bf16: uint16[9*128*128] (tap, cout, cin) from snk_conv3x3_prepare_weights_bf16. */
+int snk_conv3x3_prepare_weights_bf16(const float *d_w_hwio, void *d_wT_bf16, void *stream);
+int snk_conv3x3_bn_bf16(const float *d_x, const void *d_wT_bf16, const float *d_scale, const float *d_shift,
+                        const float *d_residual, float *d_out, int n_images, int height, int width, int relu,
+                        void *stream);
 /* The same layer in Winograd F(2x2,3x3) form (fp32 throughout, 2.05x fewer MFMA flops on 21x21 images):
  * snk_conv3x3_prepare_weights_winograd: Keras kernel (3,3,128,128) -> U = G g G^T laid out
  *   [16 positions][cin/4][cout][4] (float[16*128*128], evaluated in float64, stored float32). */

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 BN_EPS = 1e-3
 
 
-def forward(weights, states, legacy_mask=False, apply_mask=True):
+def forward(weights, states, legacy_mask=False, apply_mask=True, bf16_conv=False):
     """weights: list in Keras get_weights() order (snake_engine/net.py docstring); states (N,h,w,3) float32.
     Returns (N,3) float32 numpy: AlphaNNet.v(states)."""
     x_np = np.ascontiguousarray(states, np.float32)
@@ -22,7 +22,9 @@ def forward(weights, states, legacy_mask=False, apply_mask=True):
     blocks = (len(t) - 14) // 10
     x = torch.as_tensor(x_np).permute(0, 3, 1, 2)                      # NHWC -> NCHW
 
-    def conv(x, k):                                                     # Keras (kh,kw,cin,cout) -> torch (cout,cin,kh,kw)
+    def conv(x, k, bf16=False):                                         # Keras (kh,kw,cin,cout) -> torch (cout,cin,kh,kw)
+        if bf16:        # configs[4]: operands rounded to bf16 (round to nearest even), products and sums in float32
+            x, k = x.to(torch.bfloat16).to(torch.float32), k.to(torch.bfloat16).to(torch.float32)
         return F.conv2d(x, k.permute(3, 2, 0, 1), padding=k.shape[0] // 2)
 
     def bn(x, g, b, m, v):
@@ -32,8 +34,8 @@ def forward(weights, states, legacy_mask=False, apply_mask=True):
         for blk in range(blocks):
             b0 = 5 + 10 * blk
             sc = h
-            h = F.relu(bn(conv(h, t[b0]), *t[b0 + 1:b0 + 5]))
-            h = F.relu(bn(conv(h, t[b0 + 5]), *t[b0 + 6:b0 + 10]) + sc)
+            h = F.relu(bn(conv(h, t[b0], bf16_conv), *t[b0 + 1:b0 + 5]))
+            h = F.relu(bn(conv(h, t[b0 + 5], bf16_conv), *t[b0 + 6:b0 + 10]) + sc)
         b0 = 5 + 10 * blocks
         h = F.relu(bn(conv(h, t[b0]), *t[b0 + 1:b0 + 5]))              # (N,1,h,w)
         h = h.permute(0, 2, 3, 1).reshape(h.shape[0], -1)              # Flatten in HWC order

@@ -150,3 +150,42 @@ def test_full_net_19x19_10_blocks(env):
     got = net.QNet(ws, (37, 37, 3)).forward(torch.as_tensor(states, device="cuda"),
                                             torch.as_tensor(s["mask"][s["raw_index"][:6]], device="cuda")).cpu().numpy()
     assert np.abs(got - ref).max() <= TOL_Q, np.abs(got - ref).max()
+
+
+def test_bf16_conv_layer_and_net(env, monkeypatch):
+    """configs[4] ("bf16 MFMA conv"): operands rounded to bf16, float32 accumulation.  Against a float64 reference
+    computed from the SAME bf16-rounded operands the layer is exact to float32 rounding; the whole 10-block 19x19 net
+    is compared with the CPU restatement that rounds the conv operands the same way (tolerance 1e-3: over 20 layers bf16
+    rounding of slightly different float32 activations flips last bits) and stays within 5e-2 of the float32 net."""
+    torch, se, net = env
+    from snake_engine._lib import lib, check
+    from oracle import net_ref
+    L = lib()
+    g = torch.Generator().manual_seed(11)
+    n, hw = 3, 21
+    x = torch.randn(n, hw, hw, 128, generator=g)
+    w = torch.randn(3, 3, 128, 128, generator=g) * 0.05
+    sc, sh = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.1
+    r = torch.randn(n, hw, hw, 128, generator=g)
+    xb, wb = x.to(torch.bfloat16).double(), w.to(torch.bfloat16).double()
+    ref = torch.nn.functional.conv2d(xb.permute(0, 3, 1, 2), wb.permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1)
+    ref = (ref * sc.double() + sh.double() + r.double()).clamp_min(0)
+    dev = [t.cuda() for t in (x, w, sc, sh, r)]
+    wT = torch.empty(9 * 128 * 128, dtype=torch.int16, device="cuda")
+    out = torch.full((n, hw, hw, 128), float("nan"), device="cuda")
+    check(L.snk_conv3x3_prepare_weights_bf16(dev[1].data_ptr(), wT.data_ptr(), _st()))
+    check(L.snk_conv3x3_bn_bf16(dev[0].data_ptr(), wT.data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(),
+                                out.data_ptr(), n, hw, hw, 1, _st()))
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-5 * ref.abs().max().item(), err
+    # the 19x19 / 10-block net of configs[4]
+    monkeypatch.setenv("SNK_CONV_ALGO", "bf16")
+    s = load_golden("states_19x19x8.npz")
+    states = s["raw"][:6]
+    ws = _randomised_bn(net.glorot_uniform_weights((37, 37, 3), blocks=10, seed=1), 4)
+    mask = torch.as_tensor(s["mask"][s["raw_index"][:6]], device="cuda")
+    got = net.QNet(ws, (37, 37, 3)).forward(torch.as_tensor(states, device="cuda"), mask).cpu().numpy()
+    ref16 = net_ref.forward(ws, states, bf16_conv=True)
+    ref32 = net_ref.forward(ws, states)
+    assert np.abs(got - ref16).max() <= 1e-3, np.abs(got - ref16).max()
+    assert np.abs(got - ref32).max() <= 5e-2, np.abs(got - ref32).max()
