@@ -313,3 +313,35 @@ def test_transposition_table_grows_between_epochs(env):
     cap, occ, ovf = alice._mcts.tt.status()
     assert not ovf and cap > (1 << 10) and occ * 2 <= cap and occ > 512
     assert len(alice.cached_values) == occ
+
+
+def test_production_mode_is_distribution_equivalent_to_the_oracle(env, oracle):
+    """Self-play to completion with the deterministic stub net: the production device MCTS (float atomics, pre-tick Q
+    in the in-rollout back-up, Philox draws, device food spawns) against the sequential CPU restatement of the
+    reference (its own RNG).  Different random streams, so the comparison is statistical: per-game averages of game
+    length, food eaten and death causes agree within 4 combined standard errors."""
+    torch, se = env
+    import random
+    from oracle.mcts_oracle import SelfPlayOracle, Draws
+    from oracle.obs_key import StubNet
+    from utils.agent import Agent
+    from utils.mp_game_runner import MPGameRunner
+    rnd = random.Random(5)
+    n_cpu, n_gpu = 40, 400
+    games = [oracle.Game.new(11, 11, 4, 3, 0.15, rnd.sample(range(8), 4), [rnd.randrange(4) for _ in range(4)],
+                             [rnd.randrange(4) for _ in range(4)]) for _ in range(n_cpu)]
+    sp = SelfPlayOracle(StubNet(), 2, True, 8, 16, Draws(seed=3))
+    sp.run(games, rng=np.random.RandomState(9))
+    cpu = np.array([[g.g.counters[i] for i in range(6)] for g in games], float)
+    random.seed(6); np.random.seed(6)
+    MPGameRunner.verbose = False
+    alice = Agent(StubNNet(), 2, True, 8, 16, seed=12)
+    gr = MPGameRunner(11, 11, 4, 3, n_gpu, seed=13)
+    slots = np.arange(n_gpu, dtype=np.int32)
+    gr.run(alice)
+    from snake_engine.engine import compact_from_state
+    gpu = np.array([compact_from_state(s)["counters"] for s in gr.engine.export(slots)], float)
+    for k, name in enumerate(["wall", "body", "head", "starvation", "food_eaten", "game_length"]):
+        mc, mg = cpu[:, k].mean(), gpu[:, k].mean()
+        se_ = np.sqrt(cpu[:, k].var() / n_cpu + gpu[:, k].var() / n_gpu)
+        assert abs(mc - mg) <= 4 * se_ + 0.05, f"{name}: oracle {mc:.3f} vs device {mg:.3f} (combined s.e. {se_:.3f})"
