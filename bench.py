@@ -228,11 +228,11 @@ def main():
                          "avg_launch_ms": conv_s / max(1, len(tm)) * 1e3,
                          "share_of_step_time": conv_s / dt},
         }
-        if not args.no_kernel_rooflines:
+        if not args.no_kernel_rooflines and world == 1:
             del alice, gr
             torch.cuda.empty_cache()
             res["engine_kernels"] = engine_kernel_rooflines(se)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only
             res["cpu_baseline"] = cpu_baseline(weights, args.breadth)
         print(json.dumps(res), flush=True)
     if world > 1:
