@@ -762,7 +762,8 @@ extern "C" int snk_conv3x3_bn_f32_winograd(const float *d_x, const float *d_U, c
     if (n_images <= 0) return 0;
     const int TY = (height + 1) / 2, TX = (width + 1) / 2;
     const long tiles = (long)n_images * TY * TX;
-    SNK_REQUIRE((long)n_images * height * width < (1l << 31) / 4, "snk_conv3x3_bn_f32_winograd: batch of %d images too large for one call", n_images);
+    SNK_REQUIRE((long)n_images * height * width * CV_C < (1l << 32),      // 32-bit element offsets inside the kernel
+                "snk_conv3x3_bn_f32_winograd: batch of %d images too large for one call (chunk it)", n_images);
     WinoArgs a = {d_x, d_U, d_scale, d_shift, d_residual, d_out, (int)tiles, height, width, TY, TX, relu};
     static int nw = -1;
     if (nw < 0) { const char *v = getenv("SNK_WINO_WAVES"); nw = v ? atoi(v) : 8; }
