@@ -44,6 +44,11 @@ def main():
         t = timeit(lambda: check(L.snk_conv3x3_bn_bf16(x.data_ptr(), wb.data_ptr(), sc.data_ptr(), sh.data_ptr(), x.data_ptr(), o.data_ptr(), n, 21, 21, 1, st)))
         fl = 2 * n * 441 * 1152 * 128
         print(f"conv3x3 bf16 n={n}: {t*1e3:.3f} ms  {fl/t/1e12:.1f} TFLOP/s")
+    for n in (8192,):
+        xs = torch.randn(n, 21, 21, 3, device="cuda"); o = torch.empty(n, 21, 21, 128, device="cuda")
+        w3 = torch.randn(3, 3, 3, 128, device="cuda"); sc = torch.ones(128, device="cuda"); sh = torch.zeros(128, device="cuda")
+        t = timeit(lambda: check(L.snk_stem_conv_bn_relu_f32(xs.data_ptr(), w3.data_ptr(), sc.data_ptr(), sh.data_ptr(), o.data_ptr(), n, 21, 21, st)))
+        print(f"stem conv n={n}: {t*1e3:.3f} ms  {n*441*128*4/t/1e9:.0f} GB/s written")
     ws = net.glorot_uniform_weights((21, 21, 3))
     qn = net.QNet(ws, (21, 21, 3), max_chunk=4096)
     for n in (4096, 16384):
