@@ -5,6 +5,7 @@ for buffers, index plumbing (gather / cumsum) and the single host read-back per 
 number of cache misses, which sizes the net batch).
 """
 import ctypes as C
+from time import time
 
 import numpy as np
 import torch
@@ -81,6 +82,7 @@ class DeviceMCTS:
         self.tt = None
         self.roll = None                  # rollout engine (sub-games; food_spawn_chance 0, game.py:268)
         self._bufs_B = -1
+        self.verbose = False              # print the reference's per-epoch line (agent.py:57-58)
         self.stats = dict(net_evals=0, rollout_ticks=0, sim_steps=0, lookups=0)
 
     # ---- buffers -------------------------------------------------------------------------------
@@ -155,6 +157,7 @@ class DeviceMCTS:
         tt = self.tt.h
         seq = int(self.sequential)
         for ep in range(epochs):
+            t_epoch = time()
             root.clone_to(self.roll, src_slots=live_slots, n=G, fanout=par)       # game.subgame (agent.py:46-50)
             self.path_len.zero_()
             sub_active = torch.ones((B,), dtype=torch.bool, device=self.device)
@@ -206,6 +209,8 @@ class DeviceMCTS:
             check(L.snk_engine_rewards(self.roll.h, None, B, _ptr(self.rewards), st))
             check(L.snk_mcts_terminal_backup(tt, _ptr(self.rewards), m, _ptr(self.path_entry), _ptr(self.path_move),
                                              _ptr(self.path_len), D, seq, st))   # agent.py:60-72
+            if self.verbose and self.training:
+                print("MCTS epoch finished. Time spent:", time() - t_epoch)
             if ep + 1 < epochs:
                 # paths die with the epoch, so the table may be re-hashed here: keep the load factor below 1/2 even
                 # when one root turn inserts more keys than the table was sized for (nothing is evicted: max_age = inf)

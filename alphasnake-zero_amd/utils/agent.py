@@ -70,6 +70,7 @@ class _Values(Sequence):
 
 
 class Agent:
+    verbose = None        # None: follow MPGameRunner.verbose; the reference prints one line per MCTS epoch (agent.py:57-58)
 
     def __init__(self, nnet, softmax_base=100, training=False, max_MCTS_depth=8, max_MCTS_breadth=128,
                  seed=None, sequential=False, tape_u=None, tt_capacity=None):
@@ -149,6 +150,11 @@ class Agent:
                                     self.max_MCTS_depth, self.max_MCTS_breadth, seed=self._seed,
                                     device=eng.device.index, sequential=self._sequential, tape_u=self._tape_u,
                                     tt_capacity=self._tt_capacity)
+        if self.verbose is None:
+            from utils.mp_game_runner import MPGameRunner
+            self._mcts.verbose = bool(MPGameRunner.verbose)
+        else:
+            self._mcts.verbose = bool(self.verbose)
         slots = np.fromiter((g._slot for g in games.values()), np.int32, len(games))
         d_slots = torch.as_tensor(slots, device=eng.device)
         alive = eng.alive(slots=d_slots)

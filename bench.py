@@ -165,7 +165,7 @@ def main():
     barrier()
     log(f"[rank {rank}] warmup {args.warmup} turns in {time.time() - t_w:.1f} s")
     m = alice._mcts
-    ev0, sim0 = m.stats["net_evals"], m.stats["sim_steps"]
+    ev0, sim0 = (m.stats["net_evals"], m.stats["sim_steps"]) if m is not None else (0, 0)     # --warmup 0: nothing ran yet
     nnet._qnet.conv_timing = []
     barrier()
     t0 = time.time()
@@ -189,6 +189,7 @@ def main():
         tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt, env_steps = float(tmax[0].item()), float(tsum[1].item())
+    m = alice._mcts
     evals = m.stats["net_evals"] - ev0
     sims = m.stats["sim_steps"] - sim0
 
