@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from snake_engine import Engine
+from snake_engine._lib import check
 from utils.game import Game, draw_init_tape
 
 
@@ -106,7 +107,6 @@ class MPGameRunner:
                 self.food_eaten += c[4]
                 self.game_length += c[5]
                 rw = torch.empty((len(fin), S), dtype=torch.int8, device=eng.device)
-                from snake_engine._lib import check
                 check(eng.L.snk_engine_rewards(eng.h, torch.as_tensor(slots[fin], device=eng.device).data_ptr(), len(fin),
                                                rw.data_ptr(), torch.cuda.current_stream().cuda_stream))
                 rw = rw.cpu().numpy()
