@@ -15,6 +15,9 @@ from snake_engine._lib import check
 from utils.game import Game, draw_init_tape
 
 
+LOG_FIELDS = ("wall_collision", "body_collision", "head_collision", "starvation", "food_eaten", "game_length")
+
+
 class GameDict(dict):
     """``{game_id: Game}`` whose games are slots of one engine (what Agent.make_moves works on)."""
 
@@ -46,15 +49,9 @@ class MPGameRunner:
             self.engine.reset()
         self.games = GameDict(self.engine, {ID: Game(ID, height, width, snake_cnt, health_dec, 0.15,
                                                       _engine=self.engine, _slot=ID) for ID in range(game_cnt)})
-        # log
-        self.wall_collision = 0
-        self.body_collision = 0
-        self.head_collision = 0
-        self.starvation = 0
-        self.food_eaten = 0
-        self.game_length = 0
+        for name in LOG_FIELDS:              # the six log counters the trainer reads (mp_game_runner.py:14-20)
+            setattr(self, name, 0)
 
-    # Alice is the agent
     def run(self, Alice, spawn_tape=None, max_turns=None):
         """mp_game_runner.py:23-77.  ``spawn_tape`` (optional, parity runs): callable turn -> int16[game_cnt]
         giving the recorded food-spawn cell (-1 none) of every game for that turn."""
@@ -71,11 +68,9 @@ class MPGameRunner:
                 break
             turn += 1
             self.env_steps += len(games)       # one root Game.tic per live game (mp_game_runner.py:52)
-            if self.verbose:
-                if len(games) == 1:
-                    print("Running the root game. On turn", str(turn) + "...")
-                else:
-                    print("Concurrently running", len(games), "root games. On turn", str(turn) + "...")
+            if self.verbose:                 # same lines as the reference prints (mp_game_runner.py:34-37)
+                what = "Running the root game." if len(games) == 1 else f"Concurrently running {len(games)} root games."
+                print(f"{what} On turn {turn}...")
             gids = list(games.keys())
             slots = games.live_slots()
             d_slots = torch.as_tensor(slots, device=eng.device)
@@ -99,13 +94,8 @@ class MPGameRunner:
             done_h = done.cpu().numpy().astype(bool)
             if done_h.any():
                 fin = np.flatnonzero(done_h)
-                c = eng.sum_counters(slots=slots[fin])
-                self.wall_collision += c[0]
-                self.body_collision += c[1]
-                self.head_collision += c[2]
-                self.starvation += c[3]
-                self.food_eaten += c[4]
-                self.game_length += c[5]
+                for name, v in zip(LOG_FIELDS, eng.sum_counters(slots=slots[fin])):      # mp_game_runner.py:54-60
+                    setattr(self, name, getattr(self, name) + v)
                 rw = torch.empty((len(fin), S), dtype=torch.int8, device=eng.device)
                 check(eng.L.snk_engine_rewards(eng.h, torch.as_tensor(slots[fin], device=eng.device).data_ptr(), len(fin),
                                                rw.data_ptr(), torch.cuda.current_stream().cuda_stream))
@@ -114,15 +104,10 @@ class MPGameRunner:
                     rewards[gids[j]] = [None if r == 0 else float(r) for r in rw[k]]
                     del games[gids[j]]
             if self.verbose:
-                print("Root game turn", str(turn), "finished. Total time spent:", time() - t0, end="\n\n")
+                print(f"Root game turn {turn} finished. Total time spent: {time() - t0}", end="\n\n")
         self.turns = turn
-        # log
-        self.wall_collision /= self.game_cnt
-        self.body_collision /= self.game_cnt
-        self.head_collision /= self.game_cnt
-        self.starvation /= self.game_cnt
-        self.food_eaten /= self.game_cnt
-        self.game_length /= self.game_cnt
+        for name in LOG_FIELDS:              # per-game averages (mp_game_runner.py:71-76)
+            setattr(self, name, getattr(self, name) / self.game_cnt)
         return rewards
 
 

@@ -15,11 +15,8 @@ from utils.mp_game_runner import GameDict
 class MPGameRunner:
 
     def __init__(self, height=11, width=11, snake_cnt=4, health_dec=1, game_cnt=1, seed=None):
-        self.height = height
-        self.width = width
-        self.snake_cnt = snake_cnt
-        self.health_dec = health_dec
-        self.game_cnt = game_cnt
+        self.height, self.width, self.snake_cnt = height, width, snake_cnt
+        self.health_dec, self.game_cnt = health_dec, game_cnt
         if seed is None:
             seed = int(np.random.randint(1 << 62))
         self.engine = Engine(game_cnt, height, width, snake_cnt, health_dec, 0.15, seed=seed)
