@@ -842,6 +842,39 @@ extern "C" int snk_engine_sum_counters_sync(const snk_engine *e, const int32_t *
     return 0;
 }
 
+extern "C" int snk_compact_scratch_elems(int n);
+
+// (slot, snake id) of every alive snake, games in the given order, ids ascending: Game.get_ids over a batch
+__global__ void k_ids_from_index(const int32_t *__restrict__ idx, const int32_t *__restrict__ count, const int32_t *__restrict__ slots,
+                                 int S, int32_t *__restrict__ pairs)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *count) return;
+    const int f = idx[i], gi = f / S;
+    pairs[2 * i] = slots ? slots[gi] : gi;
+    pairs[2 * i + 1] = f - gi * S;
+}
+
+extern "C" int snk_engine_ids(const snk_engine *e, const int32_t *d_slots, int n, int32_t *d_pairs, int32_t *d_count,
+                              uint8_t *d_alive_scratch, int32_t *d_scratch, void *stream)
+{
+    SNK_REQUIRE(e && d_count, "snk_engine_ids: NULL argument");
+    SNK_REQUIRE(n >= 0 && (d_slots || n <= e->n_slots), "snk_engine_ids: n=%d exceeds %d slots", n, e->n_slots);
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) { SNK_CHECK_HIP(hipMemsetAsync(d_count, 0, sizeof(int32_t), st)); return 0; }
+    SNK_REQUIRE(d_pairs && d_alive_scratch && d_scratch, "snk_engine_ids: NULL argument");
+    const int m = n * e->L.S;
+    k_alive<<<(n + 255) / 256, 256, 0, st>>>(e->d_state, e->L, d_slots, n, d_alive_scratch, nullptr);
+    int32_t *idx = d_scratch + snk_compact_scratch_elems(m);           // scratch: [tile sums | index list]
+    const int tiles = (m + CMP_TILE - 1) / CMP_TILE;
+    k_cmp_count<<<tiles, CMP_THREADS, 0, st>>>(d_alive_scratch, m, d_scratch);
+    k_cmp_scan<<<1, CMP_THREADS, 0, st>>>(d_scratch, tiles, d_count);
+    k_cmp_scatter<<<tiles, CMP_THREADS, 0, st>>>(d_alive_scratch, m, d_scratch, idx);
+    k_ids_from_index<<<(m + 255) / 256, 256, 0, st>>>(idx, d_count, d_slots, e->L.S, d_pairs);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" int snk_compact_scratch_elems(int n) { return (n + CMP_TILE - 1) / CMP_TILE + 1; }
 
 extern "C" int snk_compact_flags(const uint8_t *d_flags, int n, int32_t *d_out, int32_t *d_count,

@@ -109,6 +109,18 @@ class Engine:
         check(self.L.snk_engine_alive(self.h, _ptr(slots), n, _ptr(out), _ptr(n_alive), _stream()))
         return out
 
+    def ids(self, slots=None, n=None):
+        """(slot, snake id) pairs of every alive snake (games in the given order, ids ascending) and their count"""
+        slots = self._i32(slots)
+        n = (len(slots) if slots is not None else self.n_slots) if n is None else n
+        m = max(1, n * self.S)
+        pairs = self.new((m, 2), torch.int32)
+        cnt = self.new((1,), torch.int32)
+        alive = self.new((m,), torch.uint8)
+        scratch = self.new((self.L.snk_compact_scratch_elems(m) + m,), torch.int32)
+        check(self.L.snk_engine_ids(self.h, _ptr(slots), n, _ptr(pairs), _ptr(cnt), _ptr(alive), _ptr(scratch), _stream()))
+        return pairs, cnt
+
     # ---- Game.get_states + obstacle mask + transposition key ----------------------------------
     def observe(self, pairs, m=None, planes=None, mask=None, key=None, layout=NHWC_F32, legacy_mask=False):
         pairs = self._i32(pairs)

@@ -99,6 +99,12 @@ int snk_engine_step(snk_engine *e, const int32_t *d_slots, int n, const uint8_t 
 int snk_engine_alive(const snk_engine *e, const int32_t *d_slots, int n, uint8_t *d_alive,
                      int32_t *d_n_alive, void *stream);
 
+/* ids of a batch (mp_game_runner.py:40-42): d_pairs int32[<= n*S][2] = (slot, snake id) of every alive snake, games in the
+ * given order, snake ids ascending; *d_count = how many.  Scratch: d_alive_scratch uint8[n*S],
+ * d_scratch int32[snk_compact_scratch_elems(n*S) + n*S].                                           */
+int snk_engine_ids(const snk_engine *e, const int32_t *d_slots, int n, int32_t *d_pairs, int32_t *d_count,
+                   uint8_t *d_alive_scratch, int32_t *d_scratch, void *stream);
+
 /* ---- Game.make_state / get_states (game.py:215-257, 68-69) + AlphaNNet.v's obstacle test
  *      (alpha_nnet.py:63-76) + the transposition key (agent.py:175) -------------------------
  * d_pairs: int32[m][2] = (slot, snake id) of the observations wanted, any order.

@@ -403,3 +403,19 @@ def test_error_codes_and_empty_inputs(se):
     assert L.snk_tt_create(C.byref(h), 1000, 0) < 0 and b"power of two" in L.snk_last_error()
     idx, cnt = eng.compact(torch.zeros(0, dtype=torch.uint8, device="cuda"), n=0)
     assert int(cnt.item()) == 0
+
+
+def test_engine_ids_order(se):
+    """snk_engine_ids = concatenated Game.get_ids(): games in the given order, alive snake ids ascending"""
+    import torch
+    from snake_engine.engine import state_from_compact
+    z = load_golden("tic_11x11x4.npz")
+    idx = [5, 400, 900, 1300, 1700, 1979]
+    eng = se.Engine(8, 11, 11, 4, 1, 0.15)
+    eng.import_states([state_from_compact(11, 11, 4, golden_state(z, i)) for i in idx], slots=[7, 0, 3, 2, 5, 6])
+    order = np.array([5, 7, 0, 2, 3, 6], np.int32)
+    pairs, cnt = eng.ids(slots=order)
+    slot_state = dict(zip([7, 0, 3, 2, 5, 6], idx))
+    exp = [(int(sl), int(s)) for sl in order for s in np.flatnonzero(golden_state(z, slot_state[int(sl)])["alive"])]
+    c = int(cnt.item())
+    assert c == len(exp) and [tuple(r) for r in pairs[:c].cpu().tolist()] == exp
