@@ -345,3 +345,24 @@ def test_production_mode_is_distribution_equivalent_to_the_oracle(env, oracle):
         mc, mg = cpu[:, k].mean(), gpu[:, k].mean()
         se_ = np.sqrt(cpu[:, k].var() / n_cpu + gpu[:, k].var() / n_gpu)
         assert abs(mc - mg) <= 4 * se_ + 0.05, f"{name}: oracle {mc:.3f} vs device {mg:.3f} (combined s.e. {se_:.3f})"
+
+
+def test_agent_accepts_a_net_with_only_the_reference_v_method(env):
+    """Agent(nnet) where nnet is any object with the reference's nnet.v(list_of_states) -> (N,3) (alpha_nnet.py:61)"""
+    torch, se = env
+    from oracle.obs_key import stub_q
+    from utils.agent import Agent
+    from utils.mp_game_runner import MPGameRunner
+
+    class VOnly:
+        calls = 0
+
+        def v(self, X):
+            assert isinstance(X, list) and X[0].shape == (21, 21, 3) and X[0].dtype == np.float32
+            VOnly.calls += 1
+            return stub_q(np.array(X))
+    MPGameRunner.verbose = False
+    alice = Agent(VOnly(), 10, False, 4, 8, seed=3)
+    gr = MPGameRunner(11, 11, 4, 1, 2, seed=4)
+    gr.run(alice, max_turns=2)
+    assert VOnly.calls > 0 and gr.env_steps == 4 and not hasattr(alice, "records")
