@@ -58,6 +58,9 @@ class QNet:
         # "winograd": F(2x2,3x3) fp32 MFMA kernel (2.05x fewer flops); "direct": implicit-GEMM fp32 MFMA kernel;
         # "bf16": bf16 MFMA with fp32 accumulation (configs[4]; does NOT meet the 1e-5 parity tolerance)
         self.conv_algo = os.environ.get("SNK_CONV_ALGO", "winograd")
+        self.n_streams = int(os.environ.get("SNK_NET_STREAMS", "1"))   # 2: chunks alternate between two streams (+0.8 % end to end,
+        #    but per-launch HIP-event timings then overlap, so bench.py keeps the single-stream default)
+        self._side = None
         self.set_weights(weights)
 
     # ---- weights -----------------------------------------------------------------------------
@@ -99,15 +102,20 @@ class QNet:
         return [w.copy() for w in self.weights]
 
     # ---- forward -------------------------------------------------------------------------------
-    def _workspace(self, n):
-        if self._ws is None or self._ws[0].shape[0] < n:
+    def _workspace(self, n, k=0):
+        if self._ws is None:
+            self._ws = {}
+        if k not in self._ws or self._ws[k][0].shape[0] < n:
             shape = (n, self.h, self.w, 128)
-            self._ws = [torch.empty(shape, dtype=torch.float32, device=self.device) for _ in range(3)]
-        return self._ws
+            self._ws[k] = [torch.empty(shape, dtype=torch.float32, device=self.device) for _ in range(3)]
+        return self._ws[k]
 
     def forward(self, planes, mask=None, out=None):
         """planes: cuda float32 [n, h, w, 3] (NHWC, contiguous); mask: optional cuda uint8 [n, 3].
-        Returns cuda float32 [n, 3] = AlphaNNet.v's output (obstacle entries -1.0 when mask is given)."""
+        Returns cuda float32 [n, 3] = AlphaNNet.v's output (obstacle entries -1.0 when mask is given).
+        Batches larger than max_chunk are cut into chunks; with SNK_NET_STREAMS=2 the chunks alternate between two HIP
+        streams (each with its own activation workspace), so the memory-bound stem / head kernels of one chunk run
+        under the other chunk's MFMA-bound convolutions."""
         assert planes.is_cuda and planes.dtype == torch.float32 and planes.is_contiguous()
         n = planes.shape[0]
         assert tuple(planes.shape[1:]) == self.input_shape, planes.shape
@@ -115,38 +123,53 @@ class QNet:
             out = torch.empty((n, 3), dtype=torch.float32, device=self.device)
         if n == 0:
             return out
+        n_chunks = (n + self.max_chunk - 1) // self.max_chunk
+        if n_chunks == 1 or self.n_streams < 2:
+            for s0 in range(0, n, self.max_chunk):
+                self._forward_chunk(planes, mask, out, s0, min(self.max_chunk, n - s0), 0)
+            return out
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = [torch.cuda.Stream(device=self.device) for _ in range(2)]
+        for sd in self._side:
+            sd.wait_stream(main)
+        for ci, s0 in enumerate(range(0, n, self.max_chunk)):
+            with torch.cuda.stream(self._side[ci & 1]):
+                self._forward_chunk(planes, mask, out, s0, min(self.max_chunk, n - s0), ci & 1)
+        for sd in self._side:
+            main.wait_stream(sd)
+        return out
+
+    def _forward_chunk(self, planes, mask, out, s0, m, k):
         st = torch.cuda.current_stream().cuda_stream
         L, h, w = self.L, self.h, self.w
-        a, b, c = self._workspace(min(n, self.max_chunk))
-        for s0 in range(0, n, self.max_chunk):
-            m = min(self.max_chunk, n - s0)
-            x = planes[s0:s0 + m]
-            check(L.snk_stem_conv_bn_relu_f32(x.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(),
-                                              self.stem_sh.data_ptr(), a.data_ptr(), m, h, w, st))
-            cur, t1, t2 = a, b, c
-            for blk in range(self.blocks):
-                i0, i1 = 2 * blk, 2 * blk + 1
-                self._conv(i0, cur, None, t1, m, st)
-                self._conv(i1, t1, cur, t2, m, st)
-                cur, t2 = t2, cur
-            mk = None if mask is None else mask[s0:s0 + m]
-            check(L.snk_head_f32(cur.data_ptr(), self.head_w.data_ptr(), self.head_s, self.head_b,
-                                 self.fc1_w.data_ptr(), self.fc1_b.data_ptr(), self.fc2_w.data_ptr(), self.fc2_b.data_ptr(),
-                                 0 if mk is None else mk.data_ptr(), out[s0:s0 + m].data_ptr(), m, h, w, st))
-        return out
+        a, b, c = self._workspace(m, k)
+        x = planes[s0:s0 + m]
+        check(L.snk_stem_conv_bn_relu_f32(x.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(),
+                                          self.stem_sh.data_ptr(), a.data_ptr(), m, h, w, st))
+        cur, t1, t2 = a, b, c
+        for blk in range(self.blocks):
+            i0, i1 = 2 * blk, 2 * blk + 1
+            self._conv(i0, cur, None, t1, m, st)
+            self._conv(i1, t1, cur, t2, m, st)
+            cur, t2 = t2, cur
+        mk = None if mask is None else mask[s0:s0 + m]
+        check(L.snk_head_f32(cur.data_ptr(), self.head_w.data_ptr(), self.head_s, self.head_b,
+                             self.fc1_w.data_ptr(), self.fc1_b.data_ptr(), self.fc2_w.data_ptr(), self.fc2_b.data_ptr(),
+                             0 if mk is None else mk.data_ptr(), out[s0:s0 + m].data_ptr(), m, h, w, st))
 
     def _conv(self, i, x, res, out, m, st):
         tm = self.conv_timing
         if tm is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            e0.record(torch.cuda.current_stream())
         fn = {"winograd": self.L.snk_conv3x3_bn_f32_winograd, "bf16": self.L.snk_conv3x3_bn_bf16}.get(
             self.conv_algo, self.L.snk_conv3x3_bn_f32)
         check(fn(x.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
                  self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),
                  out.data_ptr(), m, self.h, self.w, 1, st))
         if tm is not None:
-            e1.record()
+            e1.record(torch.cuda.current_stream())
             tm.append((e0, e1, 2.0 * m * self.h * self.w * 9 * 128 * 128))
 
     def flops_per_state(self):
