@@ -16,6 +16,7 @@ from ._lib import lib, check, EngineError
 
 BN_EPS = 1e-3        # Keras BatchNormalization default epsilon (alpha_nnet.py:22)
 K_FILTERS = 128      # alpha_nnet.py:17
+F16S_WEIGHT_BYTES = 9 * 128 * 128 * 4 + 16     # SNK_CONV_F16S_WEIGHT_BYTES (include/snake_engine.h)
 
 
 def glorot_uniform_weights(input_shape, blocks=4, seed=0):
@@ -82,6 +83,9 @@ class QNet:
             if self.conv_algo == "bf16":
                 wT = torch.empty(9 * 128 * 128, dtype=torch.int16, device=dev)
                 check(self.L.snk_conv3x3_prepare_weights_bf16(t[base].contiguous().data_ptr(), wT.data_ptr(), st))
+            elif self.conv_algo == "f16s":
+                wT = torch.empty(F16S_WEIGHT_BYTES, dtype=torch.uint8, device=dev)
+                check(self.L.snk_conv3x3_prepare_weights_f16s(t[base].contiguous().data_ptr(), wT.data_ptr(), st))
             elif self.conv_algo == "winograd":
                 wT = torch.empty(16 * 128 * 128, dtype=torch.float32, device=dev)
                 check(self.L.snk_conv3x3_prepare_weights_winograd(t[base].contiguous().data_ptr(), wT.data_ptr(), st))
@@ -163,7 +167,8 @@ class QNet:
         if tm is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream())
-        fn = {"winograd": self.L.snk_conv3x3_bn_f32_winograd, "bf16": self.L.snk_conv3x3_bn_bf16}.get(
+        fn = {"winograd": self.L.snk_conv3x3_bn_f32_winograd, "bf16": self.L.snk_conv3x3_bn_bf16,
+              "f16s": self.L.snk_conv3x3_bn_f16s}.get(
             self.conv_algo, self.L.snk_conv3x3_bn_f32)
         check(fn(x.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
                  self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),

@@ -27,8 +27,9 @@ def _st():
     return torch.cuda.current_stream().cuda_stream
 
 
-@pytest.mark.parametrize("algo", ["direct", "winograd"])
-@pytest.mark.parametrize("n,hw,res,relu", [(3, 21, False, True), (5, 21, True, True), (1, 21, True, False), (2, 37, True, True)])
+@pytest.mark.parametrize("algo", ["direct", "winograd", "f16s"])
+@pytest.mark.parametrize("n,hw,res,relu", [(3, 21, False, True), (5, 21, True, True), (1, 21, True, False), (2, 37, True, True),
+                                           (3, 13, True, True), (2, 5, False, True)])
 def test_conv3x3_layer(env, n, hw, res, relu, algo):
     torch, se, _ = env
     from snake_engine._lib import lib, check
@@ -49,8 +50,9 @@ def test_conv3x3_layer(env, n, hw, res, relu, algo):
     wT = torch.empty(16 * 128 * 128, device="cuda")
     out = torch.full((n, hw, hw, 128), float("nan"), device="cuda")
     L = lib()
-    prep, conv = ((L.snk_conv3x3_prepare_weights_winograd, L.snk_conv3x3_bn_f32_winograd) if algo == "winograd"
-                  else (L.snk_conv3x3_prepare_weights, L.snk_conv3x3_bn_f32))
+    prep, conv = {"winograd": (L.snk_conv3x3_prepare_weights_winograd, L.snk_conv3x3_bn_f32_winograd),
+                  "f16s": (L.snk_conv3x3_prepare_weights_f16s, L.snk_conv3x3_bn_f16s),
+                  "direct": (L.snk_conv3x3_prepare_weights, L.snk_conv3x3_bn_f32)}[algo]
     check(prep(wd.data_ptr(), wT.data_ptr(), _st()))
     check(conv(xd.data_ptr(), wT.data_ptr(), scd.data_ptr(), shd.data_ptr(), rd.data_ptr() if res else None,
                out.data_ptr(), n, hw, hw, int(relu), _st()))
@@ -118,7 +120,7 @@ def _randomised_bn(ws, seed):
     return out
 
 
-@pytest.mark.parametrize("algo", ["direct", "winograd"])
+@pytest.mark.parametrize("algo", ["direct", "winograd", "f16s"])
 @pytest.mark.parametrize("bn_random", [False, True])
 def test_full_net_matches_cpu_restatement(env, bn_random, algo, monkeypatch):
     torch, se, net = env
@@ -139,9 +141,11 @@ def test_full_net_matches_cpu_restatement(env, bn_random, algo, monkeypatch):
     assert len(np.unique(np.round(got, 4))) > 20, "net output is degenerate"
 
 
-def test_full_net_19x19_10_blocks(env):
+@pytest.mark.parametrize("algo", ["winograd", "f16s"])
+def test_full_net_19x19_10_blocks(env, algo, monkeypatch):
     """config 5's shape: (37,37,3) input, 10 residual blocks (a build-side extension of the same pattern)"""
     torch, se, net = env
+    monkeypatch.setenv("SNK_CONV_ALGO", algo)
     from oracle import net_ref
     s = load_golden("states_19x19x8.npz")
     states = s["raw"][:6]
