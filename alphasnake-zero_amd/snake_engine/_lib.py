@@ -56,7 +56,7 @@ PROTOTYPES = {
     "snk_conv3x3_bn_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "snk_conv3x3_prepare_weights_winograd": (i32, [vp, vp, vp]),
     "snk_conv3x3_bn_f32_winograd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
-    "snk_conv3x3_prepare_weights_f16s": (i32, [vp, vp, vp]),
+    "snk_conv3x3_prepare_weights_f16s": (i32, [vp, vp, C.c_float, vp]),
     "snk_conv3x3_bn_f16s": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "snk_stem_conv_bn_relu_f32": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "snk_tt_create": (i32, [C.POINTER(vp), u64, i32]),

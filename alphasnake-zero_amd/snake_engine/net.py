@@ -56,9 +56,12 @@ class QNet:
         self.max_chunk = int(max_chunk)
         self._ws = None
         self.conv_timing = None      # set to a list to collect (start_event, end_event, flops) per conv3x3 launch
-        # "winograd": F(2x2,3x3) fp32 MFMA kernel (2.05x fewer flops); "direct": implicit-GEMM fp32 MFMA kernel;
-        # "bf16": bf16 MFMA with fp32 accumulation (configs[4]; does NOT meet the 1e-5 parity tolerance)
-        self.conv_algo = os.environ.get("SNK_CONV_ALGO", "winograd")
+        # "f16s" (default): float32-accurate split-f16 MFMA kernel (csrc/conv_split.hip); "winograd": F(2x2,3x3) fp32 MFMA
+        # kernel; "direct": implicit-GEMM fp32 MFMA kernel; "bf16": bf16 MFMA with fp32 accumulation (configs[4]; does NOT
+        # meet the 1e-5 parity tolerance)
+        self.conv_algo = os.environ.get("SNK_CONV_ALGO", "f16s")
+        if self.conv_algo not in ("f16s", "winograd", "direct", "bf16"):
+            raise EngineError(f"SNK_CONV_ALGO={self.conv_algo!r}: expected f16s, winograd, direct or bf16")
         self.n_streams = int(os.environ.get("SNK_NET_STREAMS", "1"))   # 2: chunks alternate between two streams (+0.8 % end to end,
         #    but per-launch HIP-event timings then overlap, so bench.py keeps the single-stream default)
         self._side = None
@@ -78,14 +81,27 @@ class QNet:
         self.stem_sc, self.stem_sh = fold(*t[1:5])
         self.conv_wT, self.conv_sc, self.conv_sh = [], [], []
         st = torch.cuda.current_stream().cuda_stream
+        # "f16s": a bound on each tower layer's input from the producing batch-norm (|beta| + 8 |gamma|: eight standard
+        # deviations of a normalised pre-activation; the shortcut adds its own bound) picks the power of two that brings the
+        # inputs to <= 2^11 before they are split into f16 hi + lo (16x headroom to the f16 range, lo parts normal numbers)
+        def bn_bound(g, b):
+            return float((b.abs() + 8.0 * g.abs()).max().item())
+        bound_in = bn_bound(t[1], t[2])              # stem output
+        self.conv_x_scale = []
         for i in range(2 * self.blocks):
             base = 5 + 5 * i
+            self.conv_x_scale.append(2.0 ** (11 - math.ceil(math.log2(max(bound_in, 2.0 ** -100)))))
+            if i % 2 == 0:
+                bound_block_in, bound_in = bound_in, bn_bound(t[base + 1], t[base + 2])
+            else:
+                bound_in = bound_block_in + bn_bound(t[base + 1], t[base + 2])       # relu(bn(conv) + shortcut)
             if self.conv_algo == "bf16":
                 wT = torch.empty(9 * 128 * 128, dtype=torch.int16, device=dev)
                 check(self.L.snk_conv3x3_prepare_weights_bf16(t[base].contiguous().data_ptr(), wT.data_ptr(), st))
             elif self.conv_algo == "f16s":
                 wT = torch.empty(F16S_WEIGHT_BYTES, dtype=torch.uint8, device=dev)
-                check(self.L.snk_conv3x3_prepare_weights_f16s(t[base].contiguous().data_ptr(), wT.data_ptr(), st))
+                check(self.L.snk_conv3x3_prepare_weights_f16s(t[base].contiguous().data_ptr(), wT.data_ptr(),
+                                                              self.conv_x_scale[i], st))
             elif self.conv_algo == "winograd":
                 wT = torch.empty(16 * 128 * 128, dtype=torch.float32, device=dev)
                 check(self.L.snk_conv3x3_prepare_weights_winograd(t[base].contiguous().data_ptr(), wT.data_ptr(), st))

@@ -199,9 +199,12 @@ def main():
         conv_s = sum(a.elapsed_time(b) for a, b, _ in tm) * 1e-3
         conv_flops = sum(f for _, _, f in tm)
         achieved = conv_flops / conv_s / 1e12 if conv_s > 0 else 0.0
-        peak = 2500.0 if nnet._qnet.conv_algo == "bf16" else 157.3      # dense MFMA peaks, MI355X_MICROARCH.md
+        algo = nnet._qnet.conv_algo
+        peak = 2500.0 if algo in ("bf16", "f16s") else 157.3      # dense MFMA peaks (bf16 / f16, f32), MI355X_MICROARCH.md
+        # MFMA flops the kernel executes per algorithmic (direct-convolution) flop
+        executed = {"f16s": 3.0 * 480 / 441, "winograd": 16 * 121 / (441 * 9.0)}.get(algo, 1.0)
         traffic = None      # HBM bytes per average launch, from the committed rocprofv3 --pmc passes (profiles/)
-        tfile = os.path.join(REPO, "profiles", "r1_conv_traffic.json")
+        tfile = os.path.join(REPO, "profiles", {"f16s": "r1_conv_f16s_traffic.json", "winograd": "r1_conv_traffic.json"}.get(algo, "none"))
         if os.path.exists(tfile) and tm:
             per_state_layer = json.load(open(tfile))["hbm_bytes_per_state_layer"]
             traffic = per_state_layer * (conv_flops / len(tm)) / (2.0 * 441 * 9 * 128 * 128)
@@ -209,7 +212,8 @@ def main():
             "metric": "self-play env-steps/sec (11x11, 4 snakes, 50 MCTS sims)",
             "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 operands, f32 accumulate (outside the 1e-5 parity tolerance)" if nnet._qnet.conv_algo == "bf16" else "f32",
+            "dtype": {"bf16": "bf16 operands, f32 accumulate (outside the 1e-5 parity tolerance)",
+                      "f16s": "f32 (tower convolutions: each f32 operand split into f16 hi + lo, 3 f16 MFMAs per product, f32 accumulate)"}.get(algo, "f32"),
             "data": "synthetic",
             "config": {"workload": f"configs[1]: 11x11, 4 snakes, {args.games} parallel games per GPU, max_MCTS_breadth "
                                    f"{args.breadth} (= {args.breadth // 8 * 8} rollouts), depth 8, health_dec 1, softmax_base 2, "
@@ -217,15 +221,19 @@ def main():
                        "games_per_gpu": args.games, "breadth": args.breadth, "parallelism": f"games sharded x{world}",
                        "net_evals_per_env_step": evals / max(1, gr.env_steps), "sim_steps_per_env_step": sims / max(1, gr.env_steps),
                        "net_evals_per_s_rank0": evals / dt, "sample_rows_gathered": int(Xg.shape[0])},
-            "roofline": {"bound": "mfma", "kernel": {"winograd": "k_conv3x3_wino_f32", "bf16": "k_conv3x3_bf16"}.get(nnet._qnet.conv_algo, "k_conv3x3_f32"),
+            "roofline": {"bound": "mfma",
+                         "kernel": {"winograd": "k_conv3x3_wino_f32", "bf16": "k_conv3x3_bf16", "f16s": "k_conv3x3_f16s"}.get(algo, "k_conv3x3_f32"),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic if nnet._qnet.conv_algo == "winograd" else None, "launches": len(tm),
+                         "frac": achieved / peak, "traffic": traffic, "launches": len(tm),
                          "flops_convention": "algorithmic = direct 3x3 convolution, 2*441*1152*128 per state and layer (SURVEY 8d)",
-                         "executed_frac": achieved / peak * (16 * 121 / (441 * 9.0) if nnet._qnet.conv_algo == "winograd" else 1.0),
-                         "algorithm": ("Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: executes 16*121/(441*9) = 0.488 of the "
-                                       "algorithmic flops, fp32 throughout" if nnet._qnet.conv_algo == "winograd"
-                                       else "implicit GEMM on v_mfma_f32_32x32x16_bf16" if nnet._qnet.conv_algo == "bf16"
-                                       else "implicit GEMM on v_mfma_f32_32x32x2_f32"),
+                         "executed_frac": achieved / peak * executed,
+                         "algorithm": {"winograd": "Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: executes 16*121/(441*9) = 0.488 of the "
+                                                   "algorithmic flops, fp32 throughout",
+                                       "bf16": "implicit GEMM on v_mfma_f32_32x32x16_bf16",
+                                       "f16s": "implicit GEMM on v_mfma_f32_32x32x16_f16 with split operands: executes 3 (hi*hi, hi*lo, lo*hi) "
+                                               "x 480/441 (border positions) = 3.27 MFMA flops per algorithmic flop; peak = dense f16 MFMA "
+                                               "at 2.4 GHz, the chip holds ~1.55 GHz in this loop on random data (DESIGN.md section 4)"}.get(
+                                                   algo, "implicit GEMM on v_mfma_f32_32x32x2_f32"),
                          "avg_launch_ms": conv_s / max(1, len(tm)) * 1e3,
                          "share_of_step_time": conv_s / dt},
         }

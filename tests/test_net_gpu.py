@@ -53,7 +53,10 @@ def test_conv3x3_layer(env, n, hw, res, relu, algo):
     prep, conv = {"winograd": (L.snk_conv3x3_prepare_weights_winograd, L.snk_conv3x3_bn_f32_winograd),
                   "f16s": (L.snk_conv3x3_prepare_weights_f16s, L.snk_conv3x3_bn_f16s),
                   "direct": (L.snk_conv3x3_prepare_weights, L.snk_conv3x3_bn_f32)}[algo]
-    check(prep(wd.data_ptr(), wT.data_ptr(), _st()))
+    if algo == "f16s":
+        check(prep(wd.data_ptr(), wT.data_ptr(), C.c_float(256.0), _st()))     # |x| up to ~5: 5 * 256 << 65504
+    else:
+        check(prep(wd.data_ptr(), wT.data_ptr(), _st()))
     check(conv(xd.data_ptr(), wT.data_ptr(), scd.data_ptr(), shd.data_ptr(), rd.data_ptr() if res else None,
                out.data_ptr(), n, hw, hw, int(relu), _st()))
     got = out.cpu().double()
@@ -61,6 +64,38 @@ def test_conv3x3_layer(env, n, hw, res, relu, algo):
     err = (got - ref).abs().max().item()
     scale = ref.abs().max().item()
     assert err <= 2e-5 * scale, (err, scale)
+
+
+def test_f16s_activation_scale(env):
+    """the split-f16 layer keeps float32-level accuracy for small activations when the caller passes the matching power
+    of two (hi + lo f16 carry 22 significand bits only while lo is a normal f16 number), and rejects other scales"""
+    torch, se, _ = env
+    from snake_engine._lib import lib, check, EngineError
+    from snake_engine.net import F16S_WEIGHT_BYTES
+    L = lib()
+    g = torch.Generator().manual_seed(77)
+    n, hw = 2, 21
+    w = torch.randn(3, 3, 128, 128, generator=g) * 0.05
+    sc, sh0 = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g)
+    wd, scd = w.cuda(), sc.cuda()
+    wS = torch.empty(F16S_WEIGHT_BYTES, dtype=torch.uint8, device="cuda")
+    for mag, x_scale in ((1e-4, 2.0 ** 21), (1.0, 256.0), (300.0, 1.0)):
+        x = torch.randn(n, hw, hw, 128, generator=g) * mag
+        sh = sh0 * mag
+        ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1)
+        ref = (ref * sc.double() + sh.double() + x.double()).clamp_min(0)
+        xd, shd = x.cuda(), sh.cuda()
+        out = torch.full((n, hw, hw, 128), float("nan"), device="cuda")
+        check(L.snk_conv3x3_prepare_weights_f16s(wd.data_ptr(), wS.data_ptr(), C.c_float(x_scale), _st()))
+        check(L.snk_conv3x3_bn_f16s(xd.data_ptr(), wS.data_ptr(), scd.data_ptr(), shd.data_ptr(), xd.data_ptr(),
+                                    out.data_ptr(), n, hw, hw, 1, _st()))
+        err = (out.cpu().double() - ref).abs().max().item()
+        assert err <= 5e-6 * ref.abs().max().item(), (mag, err, ref.abs().max().item())
+    with pytest.raises(EngineError):
+        check(L.snk_conv3x3_prepare_weights_f16s(wd.data_ptr(), wS.data_ptr(), C.c_float(3.0), _st()))
+    with pytest.raises(EngineError):
+        check(L.snk_conv3x3_bn_f16s(xd.data_ptr(), wS.data_ptr(), scd.data_ptr(), shd.data_ptr(), None,
+                                    out.data_ptr(), n, 70, 70, 1, _st()))
 
 
 def test_stem_and_head_layers(env):

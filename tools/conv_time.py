@@ -19,7 +19,11 @@ for n in sizes:
         x = torch.randn(n, H, H, 128, device="cuda") * mag; o = torch.full_like(x, float("nan"))
         w = torch.randn(3, 3, 128, 128, device="cuda") * 0.05; U = torch.empty(wbytes, dtype=torch.uint8, device="cuda")
         sc = torch.rand(128, device="cuda") + 0.5; sh = torch.randn(128, device="cuda") * mag
-        check(prep(w.data_ptr(), U.data_ptr(), st))
+        if algo == "f16s":      # the activation scale the net wrapper would pick: inputs up to ~8 |x| -> 2^11
+            import math
+            check(prep(w.data_ptr(), U.data_ptr(), 2.0 ** (11 - math.ceil(math.log2(8 * mag))), st))
+        else:
+            check(prep(w.data_ptr(), U.data_ptr(), st))
         f = lambda: check(conv(x.data_ptr(), U.data_ptr(), sc.data_ptr(), sh.data_ptr(), x.data_ptr(), o.data_ptr(), n, H, H, 1, st))
         for _ in range(3): f()
         torch.cuda.synchronize()
