@@ -9,14 +9,15 @@
 // numbers; the inverse goes into the batch-norm scale (exact).  Activations are multiplied by a caller-chosen power
 // of two on the way into LDS (so that their lo parts are normal numbers too) and clamped to +-65504 after it.
 //
-// One block = one row strip of one image (11 + 10 rows at 21x21) x all 128 outputs, 4 wavefronts, at most 8 M tiles
-// = 128 accumulator registers per wave, so TWO blocks share a CU (2 waves per SIMD, 68 KB of LDS each): while one is
-// in its prologue or epilogue the other one's MFMAs keep the matrix pipe busy.
-// The strip sits in LDS with a zero border, rows pitched W + 1 so that the right border of a row is the left border
-// of the next: the output of padded position q needs input position q + dy (W+1) + dx, so all nine taps of an MFMA
-// A-fragment are the SAME LDS image at nine constant offsets -- the strip is staged (and split into hi/lo) once per
-// 16-channel chunk, not once per tap.  GEMM rows are consecutive padded positions (border positions are computed and
-// dropped).  Wave wn owns outputs 32 wn .. 32 wn + 31 for all M tiles; per (chunk, tap) and M tile it reads two
+// GEMM rows are the image's pixels in row-major order, 32 per M tile (14 tiles at 21x21, 7 junk rows).  One block =
+// up to 8 consecutive M tiles of one image (7 + 7 at 21x21) x all 128 outputs, 4 wavefronts, at most 128 accumulator
+// registers per wave, so TWO blocks share a CU (2 waves per SIMD, 68 KB of LDS each): while one is in its prologue or
+// epilogue the other one's MFMAs keep the matrix pipe busy.
+// The image rows a block needs (those of its pixels, one above, one below) sit in LDS with a zero border, rows pitched
+// W + 1 so that the right border of a row is the left border of the next: the input of output pixel (y, x) for tap
+// (dy, dx) is at LDS position of (y, x) + dy (W+1) + dx, so all nine taps of an MFMA A-fragment are the SAME LDS image
+// at nine constant offsets from the lane's pixel address -- the rows are staged (and split into hi/lo) once per
+// 16-channel chunk, not once per tap.  Wave wn owns outputs 32 wn .. 32 wn + 31 for all M tiles; per (chunk, tap) and M tile it reads two
 // ds_read_b128 (hi, lo) for three MFMAs, two tiles ahead of their use.  B fragments (the pre-split weights, 576 KB,
 // L2 resident, stored in fragment order so that a wave's load is 1 KB contiguous) stream straight into a 3-deep
 // register ring two taps ahead; the next chunk's strip is loaded at the chunk's first tap, split and written to the
@@ -32,10 +33,9 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #define HS_C 128
 #define HS_KC 16                                         // input channels per chunk = one MFMA k step
 #define HS_LDP 80                                        // bytes per LDS pixel: [hi k0-15 | lo k0-15] + 16 (16 x odd: conflict-free b128)
-#define HS_NPB 320                                       // pixels per LDS buffer
-#define HS_SLACK 72                                      // pixels behind the second buffer that junk GEMM rows may read
+#define HS_NPB 352                                       // pixels per LDS buffer
 #define HS_MLD 132                                       // epilogue row (floats): 528 bytes = 16 x 33
-#define HS_SMEM_STAGE ((2 * HS_NPB + HS_SLACK) * HS_LDP) // 56 960 bytes
+#define HS_SMEM_STAGE (2 * HS_NPB * HS_LDP)              // 56 320 bytes
 #define HS_SMEM_EPI (2 * 64 * HS_MLD * 4)                // 67 584 bytes
 #define HS_SMEM (HS_SMEM_EPI > HS_SMEM_STAGE ? HS_SMEM_EPI : HS_SMEM_STAGE)
 #define HS_WS_ELEMS (9 * HS_C * HS_C * 2)                // f16 numbers in the split weight image; four floats follow it
@@ -50,7 +50,7 @@ struct ConvHsArgs {
     const float *scale, *shift;
     const float *res;          // or NULL
     float *out;
-    int Hd, Wd, n_strips, rows_base, rows_rem, relu;     // strip s has rows_base + (s < rows_rem) image rows
+    int Hd, Wd, n_blk, tiles_base, tiles_rem, relu;      // block b of an image has tiles_base + (b < tiles_rem) M tiles
 };
 
 #ifdef HS_STAMPS       // development build only (tools/conv_stamps.py): s_memtime at the phase boundaries of every block
@@ -73,16 +73,20 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
     __shared__ __align__(16) unsigned char smem[HS_SMEM];
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;        // wave wn owns outputs 32 wn .. 32 wn + 31
     const int h = lane >> 5, l31 = lane & 31;
-    const int img = blockIdx.x / p.n_strips, strip = blockIdx.x - img * p.n_strips;
-    const int y0 = strip * p.rows_base + min(strip, p.rows_rem), rows = p.rows_base + (strip < p.rows_rem ? 1 : 0);
-    const int P = p.Wd + 1, q0 = P + 1;                    // padded pitch; position of the strip's first pixel
+    const int img = blockIdx.x / p.n_blk, blk = blockIdx.x - img * p.n_blk;
+    const int HW = p.Hd * p.Wd;
+    const int tile0 = blk * p.tiles_base + min(blk, p.tiles_rem), ntile = p.tiles_base + (blk < p.tiles_rem ? 1 : 0);
+    const int m0 = 32 * tile0, m1 = min(32 * (tile0 + ntile), HW);      // the block's GEMM rows = pixels m0 .. m1 - 1 of the image
+    const int P = p.Wd + 1;                                // padded pitch
+    const float invW = 1.0f / (float)p.Wd;
+    const int y_first = (int)(((float)m0 + 0.5f) * invW), y_last = (int)(((float)(m1 - 1) + 0.5f) * invW);
+    // LDS row r holds image row y_first - 1 + r (zero when outside the image), LDS column x + 1 image column x
 
     // ---- staging role: item k of this thread = pixel (tid / 4 + 64 k) of the rows the strip needs, float4 (tid % 4) of the chunk
-    const int ry_lo = y0 == 0 ? 1 : 0, ry_hi = min(rows + 1, p.Hd - y0);     // padded rows that exist in the image
+    const int ry_lo = y_first == 0 ? 1 : 0, ry_hi = min(y_last + 1, p.Hd - 1) - (y_first - 1);   // LDS rows that exist in the image
     const int npx = (ry_hi - ry_lo + 1) * p.Wd;
-    const float *xrow = p.x + ((long)img * p.Hd + (y0 + ry_lo - 1)) * p.Wd * HS_C + 4 * (tid & 3);
+    const float *xrow = p.x + ((long)img * p.Hd + (y_first - 1 + ry_lo)) * p.Wd * HS_C + 4 * (tid & 3);
     const int pix0 = tid >> 2;
-    const float invW = 1.0f / (float)p.Wd;
     const float xs = p.wscale_inv[2];                      // activations are multiplied by this power of two before the split
     unsigned ldo[HS_NST];                                  // LDS byte offset (inside a buffer) of the thread's items
     unsigned gof[HS_NST];                                  // element offset of the items in x (chunk 0)
@@ -141,7 +145,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
     for (int k = 0; k < HS_NST; ++k) { HS_SPLIT_A(st[k]) HS_SPLIT_B(k, 0) }
     __syncthreads();
 
-    const unsigned lane_base = (unsigned)(q0 + l31) * HS_LDP + 16 * h;
+    unsigned la[NI];                                       // LDS byte address (buffer 0, centre tap) of the lane's pixel in M tile i
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int m_ = min(m0 + 32 * i + l31, HW - 1);     // rows past the image repeat its last pixel (computed, never stored)
+        const int y_ = (int)(((float)m_ + 0.5f) * invW), x_ = m_ - y_ * p.Wd;
+        la[i] = (unsigned)((y_ - (y_first - 1)) * P + x_ + 1) * HS_LDP + 16 * h;
+    }
 #define HS_LDS(off) (*(const f16x8 *)(smem + (off)))
 #define HS_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 // One tap of a chunk = NI fenced regions, each = { the ds_reads of the tile two ahead; a share of the staging work;
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
 // sinks the reads to the MFMAs that consume them and the wave eats the LDS latency once per tile).  The tile sequence
 // runs across taps: tile t of the chunk is (tap t / NI, M tile t % NI).  Staging of the next chunk: HS_NST global
 // loads at tap 0, their split halves (A, B) in the chunk's last 2 HS_NST regions.
-#define HS_AOFF(t) (rb + (unsigned)((((t) / NI) / 3 - 1) * P + (((t) / NI) % 3 - 1)) * HS_LDP + ((t) % NI) * (32 * HS_LDP))
+#define HS_AOFF(t) (la[(t) % NI] + rb + (unsigned)((((t) / NI) / 3 - 1) * P + (((t) / NI) % 3 - 1)) * HS_LDP)
 #define HS_TAP(s, MORE)                                                                         \
         {                                                                                       \
             _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                    \
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
                 }                                                                               \
                 {                                                                               \
                     const int tl_ = (s) * NI + i - (9 * NI - 2 * HS_NST);                       \
-                    if (MORE && tl_ >= 0) {                                                     \
+                    if (MORE && 9 * NI >= 2 * HS_NST && tl_ >= 0) {                             \
                         if ((tl_ & 1) == 0) { HS_SPLIT_A(st[tl_ < 0 ? 0 : tl_ >> 1]) }          \
                         else { HS_SPLIT_B((tl_ < 0 ? 0 : tl_ >> 1), wb) }                       \
                     }                                                                           \
@@ -177,13 +187,16 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
         }
 #define HS_CHUNK(MORE)                                                                          \
     {                                                                                           \
-        const unsigned rb = lane_base + (unsigned)(c & 1) * (HS_NPB * HS_LDP);                  \
+        const unsigned rb = (unsigned)(c & 1) * (HS_NPB * HS_LDP);                              \
         const unsigned wb = (unsigned)((c & 1) ^ 1) * (HS_NPB * HS_LDP);                        \
         const int gnext = c * 9 + HS_AHEAD;             /* global step the first prefetch of this chunk fetches */ \
         f16x8 a0h = HS_LDS(HS_AOFF(0)), a0l = HS_LDS(HS_AOFF(0) + 32);                          \
         f16x8 a1h = HS_LDS(HS_AOFF(1)), a1l = HS_LDS(HS_AOFF(1) + 32);                          \
         HS_TAP(0, MORE) HS_TAP(1, MORE) HS_TAP(2, MORE) HS_TAP(3, MORE) HS_TAP(4, MORE)         \
         HS_TAP(5, MORE) HS_TAP(6, MORE) HS_TAP(7, MORE) HS_TAP(8, MORE)                         \
+        if (MORE && 9 * NI < 2 * HS_NST) {              /* too few regions to spread the split over: do it here */ \
+            _Pragma("unroll") for (int k = 0; k < HS_NST; ++k) { HS_SPLIT_A(st[k]) HS_SPLIT_B(k, wb) } \
+        }                                                                                       \
         __syncthreads();                                                                        \
     }
     int c = 0;
@@ -215,21 +228,16 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
     const float4 sh4 = *(const float4 *)(p.shift + 4 * cq);
     sc4.x *= winv; sc4.y *= winv; sc4.z *= winv; sc4.w *= winv;
     float *Ms = (float *)smem;                                      // [2][64 rows][HS_MLD]
-    const float invP = 1.0f / (float)P;
-    const long obase = ((long)img * p.Hd + y0) * p.Wd * HS_C + 4 * cq;
+    const long obase = (long)img * HW * HS_C + 4 * cq;
     constexpr int NPASS = (NI + 1) / 2;
     float4 rv[2][8];
     int off[2][8];
 #define HS_ROWS(pass) (((pass) + 1 < NPASS ? 2 : NI - 2 * (NPASS - 1)) * 32)
-#define HS_EPI_PREP(pass)                 /* element offsets of this thread's rows (-1: border position) + residual loads */ \
+#define HS_EPI_PREP(pass)                 /* element offsets of this thread's rows (-1: past the block's pixels) + residual loads */ \
     {                                                                                           \
-        const int q_ = q0 + 64 * (pass) + rr0;                                                  \
-        int py_ = (int)(((float)q_ + 0.5f) * invP), px_ = q_ - py_ * P;                         \
         _Pragma("unroll") for (int j = 0; j < HS_ROWS(pass) / 8; ++j) {                         \
-            off[(pass) & 1][j] = (px_ >= 1 && py_ <= rows) ? ((py_ - 1) * p.Wd + (px_ - 1)) * HS_C : -1; \
-            px_ += 8;                                                                           \
-            if (px_ >= P) { px_ -= P; ++py_; }                                                  \
-            if (px_ >= P) { px_ -= P; ++py_; }                                                  \
+            const int m_ = m0 + 64 * (pass) + rr0 + 8 * j;                                      \
+            off[(pass) & 1][j] = m_ < m1 ? m_ * HS_C : -1;                                      \
         }                                                                                       \
         if (p.res) {                                                                            \
             _Pragma("unroll") for (int j = 0; j < HS_ROWS(pass) / 8; ++j)                       \
@@ -331,24 +339,31 @@ extern "C" int snk_conv3x3_bn_f16s(const float *d_x, const void *d_wS, const flo
     SNK_REQUIRE(d_x && d_wS && d_scale && d_shift && d_out, "snk_conv3x3_bn_f16s: NULL argument");
     SNK_REQUIRE(n_images >= 0 && height >= 1 && width >= 3, "snk_conv3x3_bn_f16s: bad shape %d x %d x %d", n_images, height, width);
     if (n_images == 0) return 0;
-    const int P = width + 1;
-    // rows per strip R: (R - 1) P + W GEMM rows <= 256 (8 M tiles), (R + 2) P + 1 staged pixels <= HS_NPB, and the junk
-    // GEMM rows of the last tile (up to position 2 P + 257) stay inside the slack behind the second buffer
-    const int Rmax = min((256 - width) / P + 1, (HS_NPB - 1) / P - 2);
-    SNK_REQUIRE(Rmax >= 1 && 2 * P + 257 <= HS_NPB + HS_SLACK - 1,
-                "snk_conv3x3_bn_f16s: observation width %d not supported (max 66)", width);
-    const int n_strips = (height + Rmax - 1) / Rmax;
-    const int rows_base = height / n_strips, rows_rem = height % n_strips;
-    const int R = rows_base + (rows_rem ? 1 : 0);
-    const int gemm_rows = (R - 1) * P + width;
-    SNK_REQUIRE((long)n_images * n_strips < (1l << 31) && (long)(R + 2) * width * HS_C < (1l << 31), "snk_conv3x3_bn_f16s: batch too large");
+    const int P = width + 1, HW = height * width;
+    // GEMM rows = the image's pixels in row-major order, 32 per M tile; an image is cut into n_blk blocks of at most 8 M
+    // tiles whose input rows (those of its pixels + one above and below) fit the LDS buffer and the staging items
+    const int T = (HW + 31) / 32;
+    int n_blk = (T + 7) / 8, tiles_max = 0;
+    bool fits = false;
+    for (;; ++n_blk) {
+        tiles_max = (T + n_blk - 1) / n_blk;
+        const int rows_out = min((tiles_max * 32 + width - 2) / width + 1, height);       // worst alignment of 32 tiles_max pixels
+        fits = (rows_out + 2) * P + 1 <= HS_NPB && min(rows_out + 2, height) * width <= 64 * HS_NST;
+        if (fits || tiles_max == 1) break;
+    }
+    SNK_REQUIRE(fits, "snk_conv3x3_bn_f16s: observation width %d not supported (max 80)", width);
+    const int tiles_base = T / n_blk, tiles_rem = T % n_blk;
+    SNK_REQUIRE((long)n_images * n_blk < (1l << 31) && (long)HW * HS_C < (1l << 31), "snk_conv3x3_bn_f16s: batch too large");
     ConvHsArgs a = {d_x, (const f16x8 *)d_wS, (const float *)((const _Float16 *)d_wS + HS_WS_ELEMS), d_scale, d_shift,
-                    d_residual, d_out, height, width, n_strips, rows_base, rows_rem, relu};
-    const int n_mt = (gemm_rows + 31) / 32, grid = n_images * n_strips;
+                    d_residual, d_out, height, width, n_blk, tiles_base, tiles_rem, relu};
+    const int n_mt = tiles_max, grid = n_images * n_blk;
     hipStream_t st = (hipStream_t)stream;
-    if (n_mt <= 2) k_conv3x3_f16s<2><<<grid, 256, 0, st>>>(a);
-    else if (n_mt <= 4) k_conv3x3_f16s<4><<<grid, 256, 0, st>>>(a);
-    else if (n_mt <= 6) k_conv3x3_f16s<6><<<grid, 256, 0, st>>>(a);
+    if (n_mt == 1) k_conv3x3_f16s<1><<<grid, 256, 0, st>>>(a);
+    else if (n_mt == 2) k_conv3x3_f16s<2><<<grid, 256, 0, st>>>(a);
+    else if (n_mt == 3) k_conv3x3_f16s<3><<<grid, 256, 0, st>>>(a);
+    else if (n_mt == 4) k_conv3x3_f16s<4><<<grid, 256, 0, st>>>(a);
+    else if (n_mt == 5) k_conv3x3_f16s<5><<<grid, 256, 0, st>>>(a);
+    else if (n_mt == 6) k_conv3x3_f16s<6><<<grid, 256, 0, st>>>(a);
     else if (n_mt == 7) k_conv3x3_f16s<7><<<grid, 256, 0, st>>>(a);
     else k_conv3x3_f16s<8><<<grid, 256, 0, st>>>(a);
     SNK_CHECK_HIP(hipGetLastError());

@@ -202,7 +202,7 @@ def main():
         algo = nnet._qnet.conv_algo
         peak = 2500.0 if algo in ("bf16", "f16s") else 157.3      # dense MFMA peaks (bf16 / f16, f32), MI355X_MICROARCH.md
         # MFMA flops the kernel executes per algorithmic (direct-convolution) flop
-        executed = {"f16s": 3.0 * 480 / 441, "winograd": 16 * 121 / (441 * 9.0)}.get(algo, 1.0)
+        executed = {"f16s": 3.0 * 448 / 441, "winograd": 16 * 121 / (441 * 9.0)}.get(algo, 1.0)
         traffic = None      # HBM bytes per average launch, from the committed rocprofv3 --pmc passes (profiles/)
         tfile = os.path.join(REPO, "profiles", {"f16s": "r1_conv_f16s_traffic.json", "winograd": "r1_conv_traffic.json"}.get(algo, "none"))
         if os.path.exists(tfile) and tm:
@@ -231,7 +231,7 @@ def main():
                                                    "algorithmic flops, fp32 throughout",
                                        "bf16": "implicit GEMM on v_mfma_f32_32x32x16_bf16",
                                        "f16s": "implicit GEMM on v_mfma_f32_32x32x16_f16 with split operands: executes 3 (hi*hi, hi*lo, lo*hi) "
-                                               "x 480/441 (border positions) = 3.27 MFMA flops per algorithmic flop; peak = dense f16 MFMA "
+                                               "x 448/441 (M-tile padding) = 3.05 MFMA flops per algorithmic flop; peak = dense f16 MFMA "
                                                "at 2.4 GHz, the chip holds ~1.55 GHz in this loop on random data (DESIGN.md section 4)"}.get(
                                                    algo, "implicit GEMM on v_mfma_f32_32x32x2_f32"),
                          "avg_launch_ms": conv_s / max(1, len(tm)) * 1e3,

@@ -176,7 +176,7 @@ int snk_conv3x3_bn_f32_winograd(const float *d_x, const float *d_U, const float 
  *   x_scale: a power of two the layer's INPUT activations are multiplied by before the split (undone exactly in
  *   the epilogue); choose it so that the largest |activation| * x_scale stays well below 65504 (1.0f is always
  *   valid; the net wrapper derives it from the producing layer's batch-norm parameters).
- * 3 <= width <= 66. */
+ * 3 <= width <= 80. */
 #define SNK_CONV_F16S_WEIGHT_BYTES (9 * 128 * 128 * 4 + 16)
 int snk_conv3x3_prepare_weights_f16s(const float *d_w_hwio, void *d_wS, float x_scale, void *stream);
 int snk_conv3x3_bn_f16s(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,

@@ -95,7 +95,10 @@ def test_f16s_activation_scale(env):
         check(L.snk_conv3x3_prepare_weights_f16s(wd.data_ptr(), wS.data_ptr(), C.c_float(3.0), _st()))
     with pytest.raises(EngineError):
         check(L.snk_conv3x3_bn_f16s(xd.data_ptr(), wS.data_ptr(), scd.data_ptr(), shd.data_ptr(), None,
-                                    out.data_ptr(), n, 70, 70, 1, _st()))
+                                    out.data_ptr(), 1, 4, 200, 1, _st()))      # wider than the LDS staging allows: refused, no launch
+    with pytest.raises(EngineError):
+        check(L.snk_conv3x3_bn_f16s(xd.data_ptr(), wS.data_ptr(), scd.data_ptr(), shd.data_ptr(), None,
+                                    out.data_ptr(), 1, 4, 2, 1, _st()))
 
 
 def test_stem_and_head_layers(env):
