@@ -589,16 +589,18 @@ struct StemArgs {
     int M, Hd, Wd;
 };
 
+// 256 pixels per block; thread (pg = tid / 32, cq = tid % 32) computes outputs 4 cq .. 4 cq + 3 of pixels pg + 8 k with its
+// 27 x 4 weights in registers: per pixel 7 broadcast ds_read_b128 of the gathered 27-value patch feed 108 FMAs, and the
+// 32 lanes of a pixel write its whole 512-byte row.
+#define ST_PX 256
 __global__ __launch_bounds__(256) void k_stem_conv(StemArgs p)
 {
-    __shared__ float ws[27][CV_C];
-    __shared__ float patch[64][28];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < 27 * CV_C; i += 256) ws[i / CV_C][i % CV_C] = p.w[i];
+    __shared__ __align__(16) float patch[ST_PX][28];
+    const int tid = threadIdx.x, cq = tid & 31, pg = tid >> 5;
     const int HW = p.Hd * p.Wd;
-    const int m0 = blockIdx.x * 64;
-    // gather the 27-value input patch of each of the 64 pixels
-    for (int i = tid; i < 64 * 27; i += 256) {
+    const int m0 = blockIdx.x * ST_PX;
+    // gather the 27-value input patch (tap-major, channel-minor = the Keras kernel's row order) of each pixel
+    for (int i = tid; i < ST_PX * 27; i += 256) {
         const int px = i / 27, q = i - px * 27;
         const int tap = q / 3, ch = q - tap * 3;
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
@@ -612,16 +614,31 @@ __global__ __launch_bounds__(256) void k_stem_conv(StemArgs p)
         }
         patch[px][q] = v;
     }
+    if (tid < ST_PX) patch[tid][27] = 0.f;
+    float4 w4[28];
+#pragma unroll
+    for (int q = 0; q < 27; ++q) w4[q] = *(const float4 *)(p.w + q * CV_C + 4 * cq);
+    w4[27] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 sc = *(const float4 *)(p.scale + 4 * cq), sh = *(const float4 *)(p.shift + 4 * cq);
     __syncthreads();
-    const int co = tid & 127, par = tid >> 7;
-    const float sc = p.scale[co], sh = p.shift[co];
-    for (int px = par; px < 64; px += 2) {
+#pragma unroll 2
+    for (int k = 0; k < ST_PX / 8; ++k) {
+        const int px = pg + 8 * k;
         const int m = m0 + px;
         if (m >= p.M) break;
-        float acc = 0.f;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int q = 0; q < 27; ++q) acc = fmaf(patch[px][q], ws[q][co], acc);
-        p.out[(long)m * CV_C + co] = fmaxf(acc * sc + sh, 0.f);
+        for (int j = 0; j < 7; ++j) {
+            const float4 pv = *(const float4 *)&patch[px][4 * j];
+#define ST_FMA(PV, W) a.x = fmaf(PV, W.x, a.x); a.y = fmaf(PV, W.y, a.y); a.z = fmaf(PV, W.z, a.z); a.w = fmaf(PV, W.w, a.w);
+            ST_FMA(pv.x, w4[4 * j + 0]) ST_FMA(pv.y, w4[4 * j + 1]) ST_FMA(pv.z, w4[4 * j + 2])
+            if (j < 6) { ST_FMA(pv.w, w4[4 * j + 3]) }
+#undef ST_FMA
+        }
+        float4 v;
+        v.x = fmaxf(a.x * sc.x + sh.x, 0.f); v.y = fmaxf(a.y * sc.y + sh.y, 0.f);
+        v.z = fmaxf(a.z * sc.z + sh.z, 0.f); v.w = fmaxf(a.w * sc.w + sh.w, 0.f);
+        *(float4 *)(p.out + (long)m * CV_C + 4 * cq) = v;
     }
 }
 
@@ -781,7 +798,7 @@ extern "C" int snk_stem_conv_bn_relu_f32(const float *d_x, const float *d_w, con
     const long M = (long)n_images * height * width;
     SNK_REQUIRE(M < (1l << 31), "snk_stem_conv_bn_relu_f32: batch too large");
     StemArgs a = {d_x, d_w, d_scale, d_shift, d_out, (int)M, height, width};
-    k_stem_conv<<<(int)((M + 63) / 64), 256, 0, (hipStream_t)stream>>>(a);
+    k_stem_conv<<<(int)((M + ST_PX - 1) / ST_PX), 256, 0, (hipStream_t)stream>>>(a);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
