@@ -49,7 +49,10 @@ struct ConvHsArgs {
     const float *wscale_inv;   // tail of the weight image: {2^-k (weights), 2^k, activation scale s (a power of two), 1 / s}
     const float *scale, *shift;
     const float *res;          // or NULL
-    float *out;
+    float *out;                // or NULL when only the fused 1x1 head output is wanted
+    const float *w1x1;         // optional fused head (alpha_nnet.py:49-50): h1[pixel] = relu(dot(out[pixel][:], w1x1) * s1 + b1)
+    float *h1;                 // [n][Hd * Wd], written when w1x1 is given
+    float s1, b1;
     int Hd, Wd, n_blk, tiles_base, tiles_rem, relu;      // block b of an image has tiles_base + (b < tiles_rem) M tiles
 };
 
@@ -229,6 +232,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
     sc4.x *= winv; sc4.y *= winv; sc4.z *= winv; sc4.w *= winv;
     float *Ms = (float *)smem;                                      // [2][64 rows][HS_MLD]
     const long obase = (long)img * HW * HS_C + 4 * cq;
+    float4 wh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.w1x1) wh = *(const float4 *)(p.w1x1 + 4 * cq);
     constexpr int NPASS = (NI + 1) / 2;
     float4 rv[2][8];
     int off[2][8];
@@ -269,7 +274,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
                 v.x += r_.x; v.y += r_.y; v.z += r_.z; v.w += r_.w;
             }
             if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (off[pass & 1][j] >= 0) *(float4 *)(p.out + obase + off[pass & 1][j]) = v;
+            if (p.out && off[pass & 1][j] >= 0) *(float4 *)(p.out + obase + off[pass & 1][j]) = v;
+            if (p.w1x1) {                   // the 32 lanes of this row hold its 128 outputs: reduce their dot product with w1x1
+                float d_ = (v.x * wh.x + v.y * wh.y) + (v.z * wh.z + v.w * wh.w);
+#pragma unroll
+                for (int o_ = 16; o_ >= 1; o_ >>= 1) d_ += __shfl_xor(d_, o_, 64);
+                if (cq == 0 && off[pass & 1][j] >= 0)
+                    p.h1[(long)img * HW + off[pass & 1][j] / HS_C] = fmaxf(d_ * p.s1 + p.b1, 0.f);
+            }
         }
     }
 #undef HS_ROWS
@@ -332,11 +344,10 @@ extern "C" int snk_conv3x3_prepare_weights_f16s(const float *d_w_hwio, void *d_w
     return 0;
 }
 
-extern "C" int snk_conv3x3_bn_f16s(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
-                                   const float *d_residual, float *d_out, int n_images, int height, int width, int relu,
-                                   void *stream)
+static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
+                            const float *d_residual, float *d_out, const float *d_w1x1, float s1, float b1, float *d_h1,
+                            int n_images, int height, int width, int relu, void *stream)
 {
-    SNK_REQUIRE(d_x && d_wS && d_scale && d_shift && d_out, "snk_conv3x3_bn_f16s: NULL argument");
     SNK_REQUIRE(n_images >= 0 && height >= 1 && width >= 3, "snk_conv3x3_bn_f16s: bad shape %d x %d x %d", n_images, height, width);
     if (n_images == 0) return 0;
     const int P = width + 1, HW = height * width;
@@ -355,7 +366,7 @@ extern "C" int snk_conv3x3_bn_f16s(const float *d_x, const void *d_wS, const flo
     const int tiles_base = T / n_blk, tiles_rem = T % n_blk;
     SNK_REQUIRE((long)n_images * n_blk < (1l << 31) && (long)HW * HS_C < (1l << 31), "snk_conv3x3_bn_f16s: batch too large");
     ConvHsArgs a = {d_x, (const f16x8 *)d_wS, (const float *)((const _Float16 *)d_wS + HS_WS_ELEMS), d_scale, d_shift,
-                    d_residual, d_out, height, width, n_blk, tiles_base, tiles_rem, relu};
+                    d_residual, d_out, d_w1x1, d_h1, s1, b1, height, width, n_blk, tiles_base, tiles_rem, relu};
     const int n_mt = tiles_max, grid = n_images * n_blk;
     hipStream_t st = (hipStream_t)stream;
     if (n_mt == 1) k_conv3x3_f16s<1><<<grid, 256, 0, st>>>(a);
@@ -368,4 +379,22 @@ extern "C" int snk_conv3x3_bn_f16s(const float *d_x, const void *d_wS, const flo
     else k_conv3x3_f16s<8><<<grid, 256, 0, st>>>(a);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int snk_conv3x3_bn_f16s(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
+                                   const float *d_residual, float *d_out, int n_images, int height, int width, int relu,
+                                   void *stream)
+{
+    SNK_REQUIRE(d_x && d_wS && d_scale && d_shift && d_out, "snk_conv3x3_bn_f16s: NULL argument");
+    return conv_f16s_launch(d_x, d_wS, d_scale, d_shift, d_residual, d_out, nullptr, 0.f, 0.f, nullptr, n_images, height, width,
+                            relu, stream);
+}
+
+extern "C" int snk_conv3x3_bn_f16s_head(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
+                                        const float *d_residual, float *d_out, const float *d_w1x1, float bn_scale,
+                                        float bn_shift, float *d_h1, int n_images, int height, int width, void *stream)
+{
+    SNK_REQUIRE(d_x && d_wS && d_scale && d_shift && d_w1x1 && d_h1, "snk_conv3x3_bn_f16s_head: NULL argument");
+    return conv_f16s_launch(d_x, d_wS, d_scale, d_shift, d_residual, d_out, d_w1x1, bn_scale, bn_shift, d_h1, n_images, height,
+                            width, 1, stream);
 }

@@ -700,6 +700,45 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs p)
     }
 }
 
+// The head behind a fused 1x1 stage (snk_conv3x3_bn_f16s_head wrote h1 = relu(bn(conv1x1)) [n][HW]):
+// Flatten -> Dense(128) + ReLU -> Dense(3) + tanh -> obstacle overwrite.  16 states per block, so the 226 KB Dense
+// kernel is read once per 16 states instead of once per state; thread (j = tid % 128, half = tid / 128) accumulates
+// output j of 8 states.
+#define HD_S 16
+__global__ __launch_bounds__(256) void k_head_dense(HeadArgs p, const float *__restrict__ h1g)
+{
+    extern __shared__ float sm[];
+    float *h1 = sm;                        // [HD_S][HW]
+    float *h2 = sm + HD_S * p.HW;          // [HD_S][128]
+    const int tid = threadIdx.x, j = tid & 127, half = tid >> 7;
+    const int s0 = blockIdx.x * HD_S, ns = min(HD_S, p.n - s0);
+    for (int i = tid; i < HD_S * p.HW; i += 256) h1[i] = i < ns * p.HW ? h1g[(long)s0 * p.HW + i] : 0.f;
+    __syncthreads();
+    float acc[HD_S / 2];
+#pragma unroll
+    for (int k = 0; k < HD_S / 2; ++k) acc[k] = 0.f;
+    const float *hh = h1 + half * (HD_S / 2) * p.HW;
+    for (int i = 0; i < p.HW; ++i) {
+        const float w = p.fc1_w[(long)i * 128 + j];
+#pragma unroll
+        for (int k = 0; k < HD_S / 2; ++k) acc[k] = fmaf(hh[k * p.HW + i], w, acc[k]);
+    }
+    const float b = p.fc1_b[j];
+#pragma unroll
+    for (int k = 0; k < HD_S / 2; ++k) h2[(half * (HD_S / 2) + k) * 128 + j] = fmaxf(acc[k] + b, 0.f);
+    __syncthreads();
+    if (tid < HD_S * 3) {
+        const int sl = tid / 3, o = tid - sl * 3;
+        if (sl < ns) {
+            float v = 0.f;
+            for (int i = 0; i < 128; ++i) v = fmaf(h2[sl * 128 + i], p.fc2_w[i * 3 + o], v);
+            float qv = tanhf(v + p.fc2_b[o]);
+            if (p.mask && p.mask[(long)(s0 + sl) * 3 + o]) qv = -1.0f;
+            p.q[(long)(s0 + sl) * 3 + o] = qv;
+        }
+    }
+}
+
 // weights (kh, kw, cin, cout) -> (tap, cout, cin) so that both GEMM operands are K-contiguous
 __global__ void k_transpose_w(const float *__restrict__ w, float *__restrict__ wT)
 {
@@ -812,6 +851,20 @@ extern "C" int snk_head_f32(const float *d_x, const float *d_w1x1, float bn_scal
     HeadArgs a = {d_x, d_w1x1, bn_scale, bn_shift, d_fc1_w, d_fc1_b, d_fc2_w, d_fc2_b, d_mask, d_q, n_images, height * width};
     const size_t lds = (size_t)(height * width + 128 + 256) * sizeof(float);
     k_head<<<n_images, 256, lds, (hipStream_t)stream>>>(a);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int snk_head_dense_f32(const float *d_h1, const float *d_fc1_w, const float *d_fc1_b, const float *d_fc2_w,
+                                  const float *d_fc2_b, const uint8_t *d_mask, float *d_q, int n_images, int height, int width,
+                                  void *stream)
+{
+    SNK_REQUIRE(d_h1 && d_fc1_w && d_fc1_b && d_fc2_w && d_fc2_b && d_q, "snk_head_dense_f32: NULL argument");
+    if (n_images <= 0) return 0;
+    const size_t lds = (size_t)HD_S * (height * width + 128) * sizeof(float);
+    SNK_REQUIRE(lds <= 64 * 1024, "snk_head_dense_f32: %d x %d observation too large", height, width);
+    HeadArgs a = {nullptr, nullptr, 0.f, 0.f, d_fc1_w, d_fc1_b, d_fc2_w, d_fc2_b, d_mask, d_q, n_images, height * width};
+    k_head_dense<<<(n_images + HD_S - 1) / HD_S, 256, lds, (hipStream_t)stream>>>(a, d_h1);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }

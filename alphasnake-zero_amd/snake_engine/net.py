@@ -168,9 +168,19 @@ class QNet:
         check(L.snk_stem_conv_bn_relu_f32(x.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(),
                                           self.stem_sh.data_ptr(), a.data_ptr(), m, h, w, st))
         cur, t1, t2 = a, b, c
+        # the last layer's epilogue also does the head's 1x1 stage (snk_head_dense_f32 keeps 16 states' h1 in 64 KB of LDS)
+        fused_head = self.conv_algo == "f16s" and self.blocks > 0 and 16 * (h * w + 128) * 4 <= 64 * 1024
         for blk in range(self.blocks):
             i0, i1 = 2 * blk, 2 * blk + 1
             self._conv(i0, cur, None, t1, m, st)
+            if fused_head and blk == self.blocks - 1:
+                h1 = self._h1_workspace(m, k)
+                self._conv(i1, t1, cur, None, m, st, h1=h1)
+                mk = None if mask is None else mask[s0:s0 + m]
+                check(L.snk_head_dense_f32(h1.data_ptr(), self.fc1_w.data_ptr(), self.fc1_b.data_ptr(), self.fc2_w.data_ptr(),
+                                           self.fc2_b.data_ptr(), 0 if mk is None else mk.data_ptr(), out[s0:s0 + m].data_ptr(),
+                                           m, h, w, st))
+                return
             self._conv(i1, t1, cur, t2, m, st)
             cur, t2 = t2, cur
         mk = None if mask is None else mask[s0:s0 + m]
@@ -178,11 +188,26 @@ class QNet:
                              self.fc1_w.data_ptr(), self.fc1_b.data_ptr(), self.fc2_w.data_ptr(), self.fc2_b.data_ptr(),
                              0 if mk is None else mk.data_ptr(), out[s0:s0 + m].data_ptr(), m, h, w, st))
 
-    def _conv(self, i, x, res, out, m, st):
+    def _h1_workspace(self, n, k=0):
+        key = ("h1", k)
+        if key not in self._ws or self._ws[key].shape[0] < n:
+            self._ws[key] = torch.empty((n, self.h * self.w), dtype=torch.float32, device=self.device)
+        return self._ws[key]
+
+    def _conv(self, i, x, res, out, m, st, h1=None):
         tm = self.conv_timing
         if tm is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream())
+        if h1 is not None:
+            check(self.L.snk_conv3x3_bn_f16s_head(x.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
+                                                  self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),
+                                                  None if out is None else out.data_ptr(), self.head_w.data_ptr(),
+                                                  self.head_s, self.head_b, h1.data_ptr(), m, self.h, self.w, st))
+            if tm is not None:
+                e1.record(torch.cuda.current_stream())
+                tm.append((e0, e1, 2.0 * m * self.h * self.w * 9 * 128 * 128))
+            return
         fn = {"winograd": self.L.snk_conv3x3_bn_f32_winograd, "bf16": self.L.snk_conv3x3_bn_bf16,
               "f16s": self.L.snk_conv3x3_bn_f16s}.get(
             self.conv_algo, self.L.snk_conv3x3_bn_f32)

@@ -182,6 +182,17 @@ int snk_conv3x3_prepare_weights_f16s(const float *d_w_hwio, void *d_wS, float x_
 int snk_conv3x3_bn_f16s(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
                         const float *d_residual, float *d_out, int n_images, int height, int width, int relu,
                         void *stream);
+/* The tower's LAST layer with the head's 1x1 stage fused into its epilogue (alpha_nnet.py:46-50): besides (or, with
+ * d_out NULL, instead of) the layer output it writes d_h1[n][height*width] = relu(dot(out[pixel][:], w1x1) * bn_scale
+ * + bn_shift); snk_head_dense_f32 finishes AlphaNNet.v from d_h1 (Flatten, Dense(128) + ReLU, Dense(3) + tanh,
+ * obstacle overwrite) -- together they equal snk_conv3x3_bn_f16s(relu = 1) followed by snk_head_f32 without the
+ * round trip of the last activation through HBM. */
+int snk_conv3x3_bn_f16s_head(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
+                             const float *d_residual, float *d_out, const float *d_w1x1, float bn_scale,
+                             float bn_shift, float *d_h1, int n_images, int height, int width, void *stream);
+int snk_head_dense_f32(const float *d_h1, const float *d_fc1_w, const float *d_fc1_b, const float *d_fc2_w,
+                       const float *d_fc2_b, const uint8_t *d_mask, float *d_q, int n_images, int height, int width,
+                       void *stream);
 int snk_stem_conv_bn_relu_f32(const float *d_x, const float *d_w, const float *d_scale,
                               const float *d_shift, float *d_out, int n_images, int height, int width,
                               void *stream);

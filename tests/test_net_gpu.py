@@ -101,6 +101,47 @@ def test_f16s_activation_scale(env):
                                     out.data_ptr(), 1, 4, 2, 1, _st()))
 
 
+def test_f16s_fused_head_equals_layer_plus_head(env):
+    """snk_conv3x3_bn_f16s_head + snk_head_dense_f32 == snk_conv3x3_bn_f16s(relu) + snk_head_f32 (alpha_nnet.py:46-54)"""
+    torch, se, _ = env
+    from snake_engine._lib import lib, check
+    from snake_engine.net import F16S_WEIGHT_BYTES
+    L = lib()
+    g = torch.Generator().manual_seed(123)
+    n, hw = 37, 21                      # 37 states: three dense-head blocks, the last one ragged
+    x = torch.randn(n, hw, hw, 128, generator=g).cuda()
+    r = torch.randn(n, hw, hw, 128, generator=g).cuda()
+    w = (torch.randn(3, 3, 128, 128, generator=g) * 0.05).cuda()
+    sc, sh = (torch.rand(128, generator=g) + 0.5).cuda(), (torch.randn(128, generator=g) * 0.1).cuda()
+    w1 = (torch.randn(128, generator=g) * 0.1).cuda()
+    s1, b1 = 0.7, 0.05
+    f1w, f1b = (torch.randn(hw * hw, 128, generator=g) * 0.05).cuda(), (torch.randn(128, generator=g) * 0.1).cuda()
+    f2w, f2b = (torch.randn(128, 3, generator=g) * 0.1).cuda(), (torch.randn(3, generator=g) * 0.1).cuda()
+    mask = (torch.rand(n, 3, generator=g) < 0.2).to(torch.uint8).cuda()
+    wS = torch.empty(F16S_WEIGHT_BYTES, dtype=torch.uint8, device="cuda")
+    check(L.snk_conv3x3_prepare_weights_f16s(w.data_ptr(), wS.data_ptr(), C.c_float(256.0), _st()))
+    act = torch.full((n, hw, hw, 128), float("nan"), device="cuda")
+    q_ref = torch.full((n, 3), float("nan"), device="cuda")
+    check(L.snk_conv3x3_bn_f16s(x.data_ptr(), wS.data_ptr(), sc.data_ptr(), sh.data_ptr(), r.data_ptr(), act.data_ptr(), n, hw, hw, 1, _st()))
+    check(L.snk_head_f32(act.data_ptr(), w1.data_ptr(), C.c_float(s1), C.c_float(b1), f1w.data_ptr(), f1b.data_ptr(),
+                         f2w.data_ptr(), f2b.data_ptr(), mask.data_ptr(), q_ref.data_ptr(), n, hw, hw, _st()))
+    h1_ref = ((act.double().reshape(n, hw * hw, 128) @ w1.double()) * s1 + b1).clamp_min(0)
+    for keep_out in (True, False):
+        act2 = torch.full((n, hw, hw, 128), float("nan"), device="cuda")
+        h1 = torch.full((n, hw * hw), float("nan"), device="cuda")
+        q = torch.full((n, 3), float("nan"), device="cuda")
+        check(L.snk_conv3x3_bn_f16s_head(x.data_ptr(), wS.data_ptr(), sc.data_ptr(), sh.data_ptr(), r.data_ptr(),
+                                         act2.data_ptr() if keep_out else None, w1.data_ptr(), C.c_float(s1), C.c_float(b1),
+                                         h1.data_ptr(), n, hw, hw, _st()))
+        check(L.snk_head_dense_f32(h1.data_ptr(), f1w.data_ptr(), f1b.data_ptr(), f2w.data_ptr(), f2b.data_ptr(),
+                                   mask.data_ptr(), q.data_ptr(), n, hw, hw, _st()))
+        if keep_out:
+            assert torch.equal(act2, act)
+        assert (h1.double() - h1_ref).abs().max().item() <= 2e-6 * max(1.0, h1_ref.abs().max().item())
+        assert (q - q_ref).abs().max().item() <= 2e-6
+        assert (q[mask.bool()] == -1.0).all()
+
+
 def test_stem_and_head_layers(env):
     torch, se, _ = env
     from snake_engine._lib import lib, check
