@@ -70,9 +70,16 @@ extern "C" int snk_dbg_conv_stamps(unsigned long long *h_out, int n_blocks)
 #define HS_STAMP_REAL(k)
 #endif
 
-template <int NI>      // M tiles (of 32 GEMM rows) per block, <= 8
+// NI: M tiles (of 32 GEMM rows) per block, <= 8.  MODE fixes the epilogue's options at compile time (no branches per row):
+//   0 all read from the arguments; 1 ReLU, no residual; 2 ReLU + residual; 3 ReLU + residual + fused head, no layer output
+#define hs_dpp(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+template <int NI, int MODE>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
 {
+    const bool has_res = MODE == 0 ? p.res != nullptr : MODE >= 2;
+    const bool has_head = MODE == 0 ? p.w1x1 != nullptr : MODE == 3;
+    const bool has_out = MODE == 0 ? p.out != nullptr : MODE != 3;
+    const float relu_floor = (MODE != 0 || p.relu) ? 0.f : -__builtin_inff();
     __shared__ __align__(16) unsigned char smem[HS_SMEM];
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;        // wave wn owns outputs 32 wn .. 32 wn + 31
     const int h = lane >> 5, l31 = lane & 31;
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
     float *Ms = (float *)smem;                                      // [2][64 rows][HS_MLD]
     const long obase = (long)img * HW * HS_C + 4 * cq;
     float4 wh = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.w1x1) wh = *(const float4 *)(p.w1x1 + 4 * cq);
+    if (has_head) wh = *(const float4 *)(p.w1x1 + 4 * cq);
     constexpr int NPASS = (NI + 1) / 2;
     float4 rv[2][8];
     int off[2][8];
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
             const int m_ = m0 + 64 * (pass) + rr0 + 8 * j;                                      \
             off[(pass) & 1][j] = m_ < m1 ? m_ * HS_C : -1;                                      \
         }                                                                                       \
-        if (p.res) {                                                                            \
+        if (has_res) {                                                                          \
             _Pragma("unroll") for (int j = 0; j < HS_ROWS(pass) / 8; ++j)                       \
                 rv[(pass) & 1][j] = *(const float4 *)(p.res + obase + max(off[(pass) & 1][j], 0)); \
         }                                                                                       \
@@ -268,19 +275,21 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
 #pragma unroll
         for (int j = 0; j < HS_ROWS(pass) / 8; ++j) {
             float4 v = m[j];
-            v.x = v.x * sc4.x + sh4.x; v.y = v.y * sc4.y + sh4.y; v.z = v.z * sc4.z + sh4.z; v.w = v.w * sc4.w + sh4.w;
-            if (p.res) {
+            v.x = __builtin_fmaf(v.x, sc4.x, sh4.x); v.y = __builtin_fmaf(v.y, sc4.y, sh4.y);
+            v.z = __builtin_fmaf(v.z, sc4.z, sh4.z); v.w = __builtin_fmaf(v.w, sc4.w, sh4.w);
+            if (has_res) {
                 const float4 r_ = rv[pass & 1][j];
                 v.x += r_.x; v.y += r_.y; v.z += r_.z; v.w += r_.w;
             }
-            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (p.out && off[pass & 1][j] >= 0) *(float4 *)(p.out + obase + off[pass & 1][j]) = v;
-            if (p.w1x1) {                   // the 32 lanes of this row hold its 128 outputs: reduce their dot product with w1x1
+            v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
+            if (has_out && off[pass & 1][j] >= 0) *(float4 *)(p.out + obase + off[pass & 1][j]) = v;
+            if (has_head) {                 // the 32 lanes of this row hold its 128 outputs: reduce their dot product with w1x1
                 float d_ = (v.x * wh.x + v.y * wh.y) + (v.z * wh.z + v.w * wh.w);
-#pragma unroll
-                for (int o_ = 16; o_ >= 1; o_ >>= 1) d_ += __shfl_xor(d_, o_, 64);
+                // butterfly inside each 16-lane DPP row (quad swaps, half-row mirror, row mirror), then the other row of the 32
+                d_ += hs_dpp(d_, 0xB1); d_ += hs_dpp(d_, 0x4E); d_ += hs_dpp(d_, 0x141); d_ += hs_dpp(d_, 0x140);
+                d_ += __shfl_xor(d_, 16, 64);
                 if (cq == 0 && off[pass & 1][j] >= 0)
-                    p.h1[(long)img * HW + off[pass & 1][j] / HS_C] = fmaxf(d_ * p.s1 + p.b1, 0.f);
+                    p.h1[(long)img * HW + off[pass & 1][j] / HS_C] = fmaxf(__builtin_fmaf(d_, p.s1, p.b1), 0.f);
             }
         }
     }
@@ -369,14 +378,20 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
                     d_residual, d_out, d_w1x1, d_h1, s1, b1, height, width, n_blk, tiles_base, tiles_rem, relu};
     const int n_mt = tiles_max, grid = n_images * n_blk;
     hipStream_t st = (hipStream_t)stream;
-    if (n_mt == 1) k_conv3x3_f16s<1><<<grid, 256, 0, st>>>(a);
-    else if (n_mt == 2) k_conv3x3_f16s<2><<<grid, 256, 0, st>>>(a);
-    else if (n_mt == 3) k_conv3x3_f16s<3><<<grid, 256, 0, st>>>(a);
-    else if (n_mt == 4) k_conv3x3_f16s<4><<<grid, 256, 0, st>>>(a);
-    else if (n_mt == 5) k_conv3x3_f16s<5><<<grid, 256, 0, st>>>(a);
-    else if (n_mt == 6) k_conv3x3_f16s<6><<<grid, 256, 0, st>>>(a);
-    else if (n_mt == 7) k_conv3x3_f16s<7><<<grid, 256, 0, st>>>(a);
-    else k_conv3x3_f16s<8><<<grid, 256, 0, st>>>(a);
+    // the three epilogue shapes the net wrapper uses get compile-time versions at the 21x21 tile count; everything else
+    // takes the generic version
+    const int mode = !relu ? 0 : (d_w1x1 ? (d_residual && !d_out ? 3 : 0) : (d_residual ? 2 : 1));
+    if (n_mt == 7 && mode == 1) k_conv3x3_f16s<7, 1><<<grid, 256, 0, st>>>(a);
+    else if (n_mt == 7 && mode == 2) k_conv3x3_f16s<7, 2><<<grid, 256, 0, st>>>(a);
+    else if (n_mt == 7 && mode == 3) k_conv3x3_f16s<7, 3><<<grid, 256, 0, st>>>(a);
+    else if (n_mt == 1) k_conv3x3_f16s<1, 0><<<grid, 256, 0, st>>>(a);
+    else if (n_mt == 2) k_conv3x3_f16s<2, 0><<<grid, 256, 0, st>>>(a);
+    else if (n_mt == 3) k_conv3x3_f16s<3, 0><<<grid, 256, 0, st>>>(a);
+    else if (n_mt == 4) k_conv3x3_f16s<4, 0><<<grid, 256, 0, st>>>(a);
+    else if (n_mt == 5) k_conv3x3_f16s<5, 0><<<grid, 256, 0, st>>>(a);
+    else if (n_mt == 6) k_conv3x3_f16s<6, 0><<<grid, 256, 0, st>>>(a);
+    else if (n_mt == 7) k_conv3x3_f16s<7, 0><<<grid, 256, 0, st>>>(a);
+    else k_conv3x3_f16s<8, 0><<<grid, 256, 0, st>>>(a);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }

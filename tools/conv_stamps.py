@@ -26,7 +26,7 @@ while time.time() < t_end:
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record(); f(); b.record(); torch.cuda.synchronize()
 ms = a.elapsed_time(b)
-nb = min(n, 16384)
+nb = min(2 * n, 16384)
 buf = np.zeros((nb, 8), np.uint64)
 assert L.snk_dbg_conv_stamps(buf.ctypes.data, nb) == 0
 t = buf[:, :5].astype(np.int64)
