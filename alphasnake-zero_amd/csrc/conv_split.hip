@@ -54,6 +54,7 @@ struct ConvHsArgs {
     float *h1;                 // [n][Hd * Wd], written when w1x1 is given
     float s1, b1;
     int Hd, Wd, n_blk, tiles_base, tiles_rem, relu;      // block b of an image has tiles_base + (b < tiles_rem) M tiles
+    int n_img_grouped;         // images (a multiple of 8) that use the XCD-aware block order
 };
 
 #ifdef HS_STAMPS       // development build only (tools/conv_stamps.py): s_memtime at the phase boundaries of every block
@@ -83,7 +84,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
     __shared__ __align__(16) unsigned char smem[HS_SMEM];
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;        // wave wn owns outputs 32 wn .. 32 wn + 31
     const int h = lane >> 5, l31 = lane & 31;
-    const int img = blockIdx.x / p.n_blk, blk = blockIdx.x - img * p.n_blk;
+    // XCD-aware block -> (image, part) map: workgroups go round-robin to the 8 XCDs, each with its own L2, and the parts of
+    // an image share halo rows; parts of one image are therefore 8 workgroups apart (same XCD, dispatched back to back)
+    int img, blk;
+    {
+        const int b = blockIdx.x, per = 8 * p.n_blk;
+        if (b < p.n_img_grouped * p.n_blk) { const int r = b % per; img = (b / per) * 8 + (r & 7); blk = r >> 3; }
+        else { img = b / p.n_blk; blk = b - img * p.n_blk; }
+    }
     const int HW = p.Hd * p.Wd;
     const int tile0 = blk * p.tiles_base + min(blk, p.tiles_rem), ntile = p.tiles_base + (blk < p.tiles_rem ? 1 : 0);
     const int m0 = 32 * tile0, m1 = min(32 * (tile0 + ntile), HW);      // the block's GEMM rows = pixels m0 .. m1 - 1 of the image
@@ -375,7 +383,7 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
     const int tiles_base = T / n_blk, tiles_rem = T % n_blk;
     SNK_REQUIRE((long)n_images * n_blk < (1l << 31) && (long)HW * HS_C < (1l << 31), "snk_conv3x3_bn_f16s: batch too large");
     ConvHsArgs a = {d_x, (const f16x8 *)d_wS, (const float *)((const _Float16 *)d_wS + HS_WS_ELEMS), d_scale, d_shift,
-                    d_residual, d_out, d_w1x1, d_h1, s1, b1, height, width, n_blk, tiles_base, tiles_rem, relu};
+                    d_residual, d_out, d_w1x1, d_h1, s1, b1, height, width, n_blk, tiles_base, tiles_rem, relu, (n_images / 8) * 8};
     const int n_mt = tiles_max, grid = n_images * n_blk;
     hipStream_t st = (hipStream_t)stream;
     // the three epilogue shapes the net wrapper uses get compile-time versions at the 21x21 tile count; everything else
