@@ -66,6 +66,33 @@ def test_conv3x3_layer(env, n, hw, res, relu, algo):
     assert err <= 2e-5 * scale, (err, scale)
 
 
+@pytest.mark.parametrize("n,H,W", [(2, 13, 21), (3, 21, 13), (5, 3, 3), (1, 4, 80), (2, 9, 37), (9, 21, 21), (1, 1, 5)])
+def test_f16s_rectangular_and_edge_shapes(env, n, H, W):
+    """the split-f16 layer on non-square images, the widest supported row, single-row images and a batch that is not a
+    multiple of the XCD-aware group of 8 images"""
+    torch, se, _ = env
+    from snake_engine._lib import lib, check
+    from snake_engine.net import F16S_WEIGHT_BYTES
+    L = lib()
+    g = torch.Generator().manual_seed(1000 * H + W)
+    x = torch.randn(n, H, W, 128, generator=g)
+    r = torch.randn(n, H, W, 128, generator=g)
+    w = torch.randn(3, 3, 128, 128, generator=g) * 0.05
+    sc, sh = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.1
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1)
+    ref = (ref * sc.double() + sh.double() + r.double()).clamp_min(0)
+    xd, rd, wd, scd, shd = x.cuda(), r.cuda(), w.cuda(), sc.cuda(), sh.cuda()
+    wS = torch.empty(F16S_WEIGHT_BYTES, dtype=torch.uint8, device="cuda")
+    out = torch.full((n + 1, H, W, 128), float("nan"), device="cuda")          # one image of slack: nothing may be written there
+    check(L.snk_conv3x3_prepare_weights_f16s(wd.data_ptr(), wS.data_ptr(), C.c_float(256.0), _st()))
+    check(L.snk_conv3x3_bn_f16s(xd.data_ptr(), wS.data_ptr(), scd.data_ptr(), shd.data_ptr(), rd.data_ptr(),
+                                out.data_ptr(), n, H, W, 1, _st()))
+    got = out.cpu().double()
+    assert torch.isnan(got[n]).all()
+    err = (got[:n] - ref).abs().max().item()
+    assert err <= 5e-6 * max(1.0, ref.abs().max().item()), err
+
+
 def test_f16s_activation_scale(env):
     """the split-f16 layer keeps float32-level accuracy for small activations when the caller passes the matching power
     of two (hi + lo f16 carry 22 significand bits only while lo is a normal f16 number), and rejects other scales"""
