@@ -41,8 +41,12 @@ __host__ __device__ static inline int lds_per_wave_obs(const Layout &L)
 
 // ------------------------------------------------------------------------------------------
 // Game.tic (game.py:87-205)
+// GL lanes own one game: 16 (four games per wavefront; 11x11 and 7x7, whose per-game LDS is ~1.2 KB) or 64.  With 4 snakes
+// and 121 cells most of a 64-lane wave idles in the per-snake and per-cell steps, and the kernel is instruction-issue
+// bound, not HBM bound: four games per wave cut the wave-instructions per game about three times.
+// Sub-lane sl = lane % GL plays the role the lane index had; shuffles and ballots are confined to the game's lane group.
 // ------------------------------------------------------------------------------------------
-template <int H, int W>
+template <int H, int W, int GL>
 __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ state, Layout L,
                                                        const int32_t *__restrict__ slots, int n,
                                                        const uint8_t *__restrict__ moves,
@@ -54,23 +58,27 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
 {
     using cell_t = typename CellT<H * W>::type;
     constexpr int NC = H * W;
+    constexpr int GPW = 64 / GL;                       // games per wavefront
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int gi = blockIdx.x * WAVES_PER_BLOCK + wv;
+    const int sl = lane % GL, gq = lane / GL, gbase = lane - sl;
+    const int gi = (blockIdx.x * WAVES_PER_BLOCK + wv) * GPW + gq;
     const bool valid = gi < n;
     const int S = L.S, mask = L.cap_mask;
-    uint8_t *g = smem + wv * lds_per_wave(L);
+#define GSHFL(v, o) __shfl((v), gbase + (o), 64)
+#define GBALLOT(pr) (GL == 64 ? __ballot(pr) : ((__ballot(pr) >> gbase) & ((1ull << (GL & 63)) - 1ull)))
+    uint8_t *g = smem + (wv * GPW + gq) * lds_per_wave(L);
     uint8_t *occ = g + L.stride;       // 1 = some snake's non-head node sits here (Game.bodies)
     uint8_t *hd = occ + L.nc_pad;      // 1 = some snake's head sits here (Game.heads, on-board ones)
     const int slot = valid ? (slots ? slots[gi] : gi) : 0;
     uint8_t *gsrc = state + (size_t)slot * L.stride;
 
     // the per-game inputs do not depend on the record: request them together with it (one HBM round trip, not two)
-    const int mv_in = (valid && lane < S) ? moves[(size_t)gi * S + lane] : 1;
+    const int mv_in = (valid && sl < S) ? moves[(size_t)gi * S + sl] : 1;
     const int tape_in = (valid && spawn_tape) ? spawn_tape[gi] : -1;
     if (valid)
-        for (int i = lane; i < L.stride / 16; i += 64) ((uint4 *)g)[i] = ((const uint4 *)gsrc)[i];
-    for (int i = lane * 4; i < 2 * L.nc_pad; i += 256) *(uint32_t *)(occ + i) = 0u;
+        for (int i = sl; i < L.stride / 16; i += GL) ((uint4 *)g)[i] = ((const uint4 *)gsrc)[i];
+    for (int i = sl * 4; i < 2 * L.nc_pad; i += GL * 4) *(uint32_t *)(occ + i) = 0u;
     __syncthreads();
 
     SnakeMeta *meta = (SnakeMeta *)(g + L.meta_off);
@@ -78,14 +86,14 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
     uint32_t *cnt = (uint32_t *)(g + L.cnt_off);
     int8_t *rew = (int8_t *)(g + L.rew_off);
 
-    const bool act = valid && lane < S;
+    const bool act = valid && sl < S;
     SnakeMeta m = {0, 0, 0, 0, 0};
-    if (act) m = meta[lane];
+    if (act) m = meta[sl];
     const bool alive0 = act && m.alive;
-    const int n_alive0 = __popcll(__ballot(alive0));
+    const int n_alive0 = __popcll(GBALLOT(alive0));
     const bool ended = !valid || n_alive0 <= 1;     // tic already returned the rewards list earlier
     const bool go = alive0 && !ended;
-    cell_t *ring = (cell_t *)(g + (lane < S ? lane : 0) * L.ring_bytes);
+    cell_t *ring = (cell_t *)(g + (sl < S ? sl : 0) * L.ring_bytes);
 
     // ---- execute moves (game.py:90-114; Snake.move game.py:329-358) + health (117-118)
     int head_cell = -1;
@@ -108,9 +116,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
     const bool hasfood = go && !oob && food_bit(food, head_cell);
     bool eats = hasfood;
     for (int o = 0; o < S; ++o) {
-        const int ho = __shfl(head_cell, o, 64);
-        const int fo = __shfl((int)hasfood, o, 64);
-        if (o < lane && fo && ho == head_cell) eats = false;
+        const int ho = GSHFL(head_cell, o);
+        const int fo = GSHFL((int)hasfood, o);
+        if (o < sl && fo && ho == head_cell) eats = false;
     }
     if (eats) {
         m.health = 100;
@@ -119,38 +127,44 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
         m.tail = (uint16_t)t;
         m.len = (uint16_t)(m.len + 1);
     }
-    const int n_eat = __popcll(__ballot(eats));
+    const int n_eat = __popcll(GBALLOT(eats));
     for (int o = 0; o < S; ++o) {
-        const int eo = __shfl((int)eats, o, 64);
-        const int co = __shfl(head_cell, o, 64);
-        if (eo && lane == 0) food[co >> 6] &= ~(1ull << (co & 63));
+        const int eo = GSHFL((int)eats, o);
+        const int co = GSHFL(head_cell, o);
+        if (eo && sl == 0) food[co >> 6] &= ~(1ull << (co & 63));
     }
     __syncthreads();
 
-    // ---- Game.bodies / Game.heads as LDS byte planes, rebuilt from the rings by all lanes
+    // ---- Game.bodies / Game.heads as LDS byte planes, rebuilt from the rings by all lanes of the game
     for (int s = 0; s < S; ++s) {
-        const int len_s = __shfl((int)m.len, s, 64);
-        const int tail_s = __shfl((int)m.tail, s, 64);
-        const int go_s = __shfl((int)go, s, 64);
+        const int len_s = GSHFL((int)m.len, s);
+        const int tail_s = GSHFL((int)m.tail, s);
+        const int go_s = GSHFL((int)go, s);
         if (go_s) {
             const cell_t *r = (const cell_t *)(g + s * L.ring_bytes);
-            for (int k = lane; k < len_s - 1; k += 64) occ[r[(tail_s + k) & mask]] = 1;
+            for (int k = sl; k < len_s - 1; k += GL) occ[r[(tail_s + k) & mask]] = 1;
         }
     }
     if (go && !oob) hd[head_cell] = 1;
     __syncthreads();
 
-    // ---- spawn food (game.py:130-138)
+    // ---- spawn food (game.py:130-138).  The game's empty-cell mask is assembled 64 cells per word from GL-cell ballots.
     int spawn = -1;
     if (chance > 0.0 && !ended) {
         int n_food = 0;
         for (int w = 0; w < L.FW; ++w) n_food += __popcll(food[w]);
+        uint64_t emk[(NC + 63) / 64];
         int n_empty = 0;
-        for (int w = 0; w < L.FW; ++w) {
-            const int c = w * 64 + lane;
-            const bool e = c < NC && !occ[c] && !hd[c] && !food_bit(food, c);
-            const uint64_t mk = __ballot(e);
-            if (empty_out && lane == 0) empty_out[(size_t)gi * L.FW + w] = mk;
+        for (int w = 0; w < (NC + 63) / 64; ++w) {
+            uint64_t mk = 0ull;
+#pragma unroll
+            for (int q = 0; q < GPW; ++q) {
+                const int c = w * 64 + q * GL + sl;
+                const bool e = c < NC && !occ[c] && !hd[c] && !food_bit(food, c);
+                mk |= GBALLOT(e) << (q * GL);
+            }
+            emk[w] = mk;
+            if (empty_out && sl == 0) empty_out[(size_t)gi * L.FW + w] = mk;
             n_empty += __popcll(mk);
         }
         if (spawn_tape) {
@@ -162,16 +176,19 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
             const double u1 = ((double)r[0] + 0.5) * (1.0 / 4294967296.0);
             if ((n_food == 0 || u1 <= chance) && n_empty > 0) {
                 int k = (int)(((uint64_t)r[1] * (uint64_t)n_empty) >> 32);   // uniform in [0, n_empty)
-                for (int w = 0; w < L.FW; ++w) {
-                    const int c = w * 64 + lane;
-                    const bool e = c < NC && !occ[c] && !hd[c] && !food_bit(food, c);
-                    const uint64_t mk = __ballot(e);
+                for (int w = 0; w < (NC + 63) / 64; ++w) {
+                    const uint64_t mk = emk[w];
                     const int pc = __popcll(mk);
                     if (spawn < 0) {
-                        if (k < pc) {
-                            const int rank = __popcll(mk & ((1ull << lane) - 1ull));
-                            const uint64_t sel = __ballot(e && rank == k);
-                            spawn = w * 64 + (__ffsll((unsigned long long)sel) - 1);
+                        if (k < pc) {                  // position of the k-th set bit of mk by halving
+                            uint64_t t = mk;
+                            int pos = 0;
+#pragma unroll
+                            for (int sh = 32; sh >= 1; sh >>= 1) {
+                                const int cl = __popcll(t & ((1ull << sh) - 1ull));
+                                if (k >= cl) { k -= cl; t >>= sh; pos += sh; }
+                            }
+                            spawn = w * 64 + pos;
                         } else {
                             k -= pc;
                         }
@@ -179,18 +196,18 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
                 }
             }
         }
-    } else if (empty_out && valid && lane == 0) {
+    } else if (empty_out && valid && sl == 0) {
         for (int w = 0; w < L.FW; ++w) empty_out[(size_t)gi * L.FW + w] = 0ull;
     }
-    if (spawned_out && valid && lane == 0) spawned_out[gi] = (int16_t)spawn;
+    if (spawned_out && valid && sl == 0) spawned_out[gi] = (int16_t)spawn;
 
     // ---- deaths (game.py:144-165, an if/elif chain) and removal (167-192)
     const bool body_hit = go && !oob && occ[head_cell];
     bool shared = false, lose = false;
     for (int o = 0; o < S; ++o) {
-        const int ho = __shfl(head_cell, o, 64);
-        const int lo = __shfl((int)m.len, o, 64);
-        if (o != lane && ho >= 0 && ho == head_cell) {
+        const int ho = GSHFL(head_cell, o);
+        const int lo = GSHFL((int)m.len, o);
+        if (o != sl && ho >= 0 && ho == head_cell) {
             shared = true;
             if ((int)m.len <= lo) lose = true;
         }
@@ -203,27 +220,29 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
         else if (m.health <= 0) cause = 3;
     }
     const bool dead = cause >= 0;
-    const int c0 = __popcll(__ballot(cause == 0)), c1 = __popcll(__ballot(cause == 1));
-    const int c2 = __popcll(__ballot(cause == 2)), c3 = __popcll(__ballot(cause == 3));
-    const int n_alive = __popcll(__ballot(go && !dead));
+    const int c0 = __popcll(GBALLOT(cause == 0)), c1 = __popcll(GBALLOT(cause == 1));
+    const int c2 = __popcll(GBALLOT(cause == 2)), c3 = __popcll(GBALLOT(cause == 3));
+    const int n_alive = __popcll(GBALLOT(go && !dead));
     if (!ended) {
-        if (spawn >= 0 && lane == 0) food[spawn >> 6] |= 1ull << (spawn & 63);
+        if (spawn >= 0 && sl == 0) food[spawn >> 6] |= 1ull << (spawn & 63);
         if (dead) {
             m.alive = 0; m.len = 0; m.health = 0; m.dir = 0; m.tail = 0;
-            rew[lane] = -1;
+            rew[sl] = -1;
         } else if (go && n_alive == 1) {
-            rew[lane] = 1;                             // game.py:199-202
+            rew[sl] = 1;                               // game.py:199-202
         }
-        if (act) meta[lane] = m;
-        if (lane == 0) {
+        if (act) meta[sl] = m;
+        if (sl == 0) {
             cnt[0] += c0; cnt[1] += c1; cnt[2] += c2; cnt[3] += c3;
             cnt[4] += n_eat; cnt[5] += 1;              // game_length (game.py:197)
         }
     }
     __syncthreads();
     if (!ended)
-        for (int i = lane; i < L.stride / 16; i += 64) ((uint4 *)gsrc)[i] = ((const uint4 *)g)[i];
-    if (done_out && valid && lane == 0) done_out[gi] = (uint8_t)(ended || n_alive <= 1);
+        for (int i = sl; i < L.stride / 16; i += GL) ((uint4 *)gsrc)[i] = ((const uint4 *)g)[i];
+    if (done_out && valid && sl == 0) done_out[gi] = (uint8_t)(ended || n_alive <= 1);
+#undef GSHFL
+#undef GBALLOT
 }
 
 // ------------------------------------------------------------------------------------------
@@ -696,10 +715,24 @@ extern "C" int snk_engine_step(snk_engine *e, const int32_t *d_slots, int n, con
     if (n == 0) return 0;
     SNK_REQUIRE(d_moves != nullptr, "snk_engine_step: d_moves is NULL");
     const Layout L = e->L;
-    const size_t lds = (size_t)WAVES_PER_BLOCK * lds_per_wave(L);
-    DISPATCH_BOARD(L, (k_step<BH, BW><<<wave_grid(n), BLOCK_THREADS, lds, (hipStream_t)stream>>>(
-        e->d_state, L, d_slots, n, d_moves, d_spawn_tape, d_done, d_spawned, d_empty, e->health_dec,
-        e->food_chance, (uint32_t)e->seed, (uint32_t)(e->seed >> 32))));
+    // four games per wavefront where the per-game LDS is small (11x11, 7x7), one per wavefront on 19x19
+    if (L.H <= 11) {
+        const size_t lds = (size_t)WAVES_PER_BLOCK * 4 * lds_per_wave(L);
+        const int grid = (n + WAVES_PER_BLOCK * 4 - 1) / (WAVES_PER_BLOCK * 4);
+        if (L.H == 11)
+            k_step<11, 11, 16><<<grid, BLOCK_THREADS, lds, (hipStream_t)stream>>>(
+                e->d_state, L, d_slots, n, d_moves, d_spawn_tape, d_done, d_spawned, d_empty, e->health_dec,
+                e->food_chance, (uint32_t)e->seed, (uint32_t)(e->seed >> 32));
+        else
+            k_step<7, 7, 16><<<grid, BLOCK_THREADS, lds, (hipStream_t)stream>>>(
+                e->d_state, L, d_slots, n, d_moves, d_spawn_tape, d_done, d_spawned, d_empty, e->health_dec,
+                e->food_chance, (uint32_t)e->seed, (uint32_t)(e->seed >> 32));
+    } else {
+        const size_t lds = (size_t)WAVES_PER_BLOCK * lds_per_wave(L);
+        k_step<19, 19, 64><<<wave_grid(n), BLOCK_THREADS, lds, (hipStream_t)stream>>>(
+            e->d_state, L, d_slots, n, d_moves, d_spawn_tape, d_done, d_spawned, d_empty, e->health_dec,
+            e->food_chance, (uint32_t)e->seed, (uint32_t)(e->seed >> 32));
+    }
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }

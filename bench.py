@@ -105,6 +105,11 @@ def engine_kernel_rooflines(se, n=32768):
     byts = m * (G + 5292)
     out["observe"] = {"bound": "hbm", "achieved": byts / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": byts / t / 8e12,
                       "bytes_per_unit": G + 5292, "units": m, "us": t * 1e6}
+    if n < 262144:      # 32 768 games move 39 MB: launch latency shows; the 8-GPU total of BASELINE configs[3] shows the kernel
+        del eng, snap, planes, mask, key
+        big = engine_kernel_rooflines(se, 262144)
+        out["step_262144_games"] = big["step"]
+        out["clone_262144_games"] = big["clone"]
     return out
 
 
