@@ -1,9 +1,9 @@
 // engine.hip -- gfx950 kernels + C ABI for the batched Battlesnake engine.
 //
-// One wavefront (64 lanes) owns one game for the duration of a kernel: the game's HBM record
-// (common.h) is streamed into LDS with 16-byte loads, the rules are evaluated with lanes 0..S-1
-// holding one snake each (cross-snake questions go through wave shuffles / ballots), body
-// occupancy is rebuilt as an LDS byte plane by all 64 lanes, and the record is streamed back.
+// A lane group (16 lanes in k_step on 11x11 / 7x7 = four games per wavefront, 64 lanes elsewhere) owns one game for
+// the duration of a kernel: the game's HBM record (common.h) is streamed into LDS with 16-byte loads, the rules are
+// evaluated with sub-lanes 0..S-1 holding one snake each (cross-snake questions go through group-confined shuffles /
+// ballots), body occupancy is rebuilt as an LDS byte plane by all lanes of the group, and the record is streamed back.
 // Reference semantics: Game.tic game.py:87-205, Game.make_state game.py:215-257,
 // Game.__init__ game.py:13-61, Game.subgame game.py:266-276 (see the per-kernel comments).
 #include "common.h"
