@@ -83,14 +83,15 @@ class QNet:
         st = torch.cuda.current_stream().cuda_stream
         # "f16s": a bound on each tower layer's input from the producing batch-norm (|beta| + 8 |gamma|: eight standard
         # deviations of a normalised pre-activation; the shortcut adds its own bound) picks the power of two that brings the
-        # inputs to <= 2^11 before they are split into f16 hi + lo (16x headroom to the f16 range, lo parts normal numbers)
+        # inputs to <= 2^9 before they are split into f16 hi + lo: 128x headroom to the f16 range (beyond it the kernel
+        # clamps), and lo stays a normal f16 number for every input above 1/2048 of the bound
         def bn_bound(g, b):
             return float((b.abs() + 8.0 * g.abs()).max().item())
         bound_in = bn_bound(t[1], t[2])              # stem output
         self.conv_x_scale = []
         for i in range(2 * self.blocks):
             base = 5 + 5 * i
-            self.conv_x_scale.append(2.0 ** (11 - math.ceil(math.log2(max(bound_in, 2.0 ** -100)))))
+            self.conv_x_scale.append(2.0 ** (9 - math.ceil(math.log2(max(bound_in, 2.0 ** -100)))))
             if i % 2 == 0:
                 bound_block_in, bound_in = bound_in, bn_bound(t[base + 1], t[base + 2])
             else:
