@@ -26,7 +26,7 @@ def forward64(ws, states):
 s = np.load(os.path.join(REPO, "tests", "golden", "states_11x11x4.npz"))
 states = s["raw"][:128]
 rng = np.random.RandomState(5)
-for name in ("gen-0 Glorot (bench net)", "randomised BN", "randomised BN, small gamma"):
+for name in ("gen-0 Glorot (bench net)", "randomised BN"):
     ws = net.glorot_uniform_weights((21, 21, 3), blocks=4, seed=0)
     if name != "gen-0 Glorot (bench net)":
         k = 0
