@@ -615,10 +615,13 @@ __global__ __launch_bounds__(256) void k_stem_conv(StemArgs p)
         patch[px][q] = v;
     }
     if (tid < ST_PX) patch[tid][27] = 0.f;
-    float4 w4[28];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 wlo[27], whi[27];                    // outputs (4 cq, 4 cq + 1) and (4 cq + 2, 4 cq + 3): v_pk_fma_f32 operands
 #pragma unroll
-    for (int q = 0; q < 27; ++q) w4[q] = *(const float4 *)(p.w + q * CV_C + 4 * cq);
-    w4[27] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < 27; ++q) {
+        const float4 w_ = *(const float4 *)(p.w + q * CV_C + 4 * cq);
+        wlo[q] = (f32x2){w_.x, w_.y}; whi[q] = (f32x2){w_.z, w_.w};
+    }
     const float4 sc = *(const float4 *)(p.scale + 4 * cq), sh = *(const float4 *)(p.shift + 4 * cq);
     __syncthreads();
 #pragma unroll 2
@@ -626,15 +629,16 @@ __global__ __launch_bounds__(256) void k_stem_conv(StemArgs p)
         const int px = pg + 8 * k;
         const int m = m0 + px;
         if (m >= p.M) break;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x2 alo = (f32x2){0.f, 0.f}, ahi = (f32x2){0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             const float4 pv = *(const float4 *)&patch[px][4 * j];
-#define ST_FMA(PV, W) a.x = fmaf(PV, W.x, a.x); a.y = fmaf(PV, W.y, a.y); a.z = fmaf(PV, W.z, a.z); a.w = fmaf(PV, W.w, a.w);
-            ST_FMA(pv.x, w4[4 * j + 0]) ST_FMA(pv.y, w4[4 * j + 1]) ST_FMA(pv.z, w4[4 * j + 2])
-            if (j < 6) { ST_FMA(pv.w, w4[4 * j + 3]) }
+#define ST_FMA(PV, Q) alo = __builtin_elementwise_fma((f32x2){PV, PV}, wlo[Q], alo); ahi = __builtin_elementwise_fma((f32x2){PV, PV}, whi[Q], ahi);
+            ST_FMA(pv.x, 4 * j + 0) ST_FMA(pv.y, 4 * j + 1) ST_FMA(pv.z, 4 * j + 2)
+            if (j < 6) { ST_FMA(pv.w, 4 * j + 3) }
 #undef ST_FMA
         }
+        const float4 a = make_float4(alo.x, alo.y, ahi.x, ahi.y);
         float4 v;
         v.x = fmaxf(a.x * sc.x + sh.x, 0.f); v.y = fmaxf(a.y * sc.y + sh.y, 0.f);
         v.z = fmaxf(a.z * sc.z + sh.z, 0.f); v.w = fmaxf(a.w * sc.w + sh.w, 0.f);
