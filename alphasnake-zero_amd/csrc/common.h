@@ -128,3 +128,16 @@ __device__ static inline uint64_t wave_sum_u64(uint64_t v)
     }
     return v;
 }
+
+// sum of a 64-bit value over an aligned group of GL lanes (16 or 64), result in every lane of the group
+template <int GL>
+__device__ static inline uint64_t group_sum_u64(uint64_t v)
+{
+#pragma unroll
+    for (int off = GL / 2; off >= 1; off >>= 1) {
+        uint32_t lo = __shfl_xor((int)(uint32_t)v, off, 64);
+        uint32_t hi = __shfl_xor((int)(uint32_t)(v >> 32), off, 64);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}

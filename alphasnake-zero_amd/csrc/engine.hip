@@ -374,10 +374,13 @@ __global__ void k_sum_counters(const uint8_t *__restrict__ state, Layout L, cons
 
 // ------------------------------------------------------------------------------------------
 // Game.make_state (game.py:215-257) + obstacle test (alpha_nnet.py:63-76) + observation key
-// One wavefront per (slot, snake) pair.
+// GL lanes per (slot, snake) pair: 16 (four observations per wavefront; 11x11 and 7x7) or 64 (19x19).  Everything before
+// the first plane byte (record load, tail-distance plane, 2 x splitmix64 per board cell for the key) is per-observation
+// work that left most of a 64-lane wave idle; with four observations per wave it costs a quarter of the instructions.
+// The host uses GL = 16 for requests without planes and GL = 64 for requests with planes (see snk_engine_observe).
 // ------------------------------------------------------------------------------------------
-template <int H, int W>
-__global__ __launch_bounds__(BLOCK_THREADS) void k_observe(const uint8_t *__restrict__ state, Layout L,
+template <int H, int W, int GL, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict__ state, Layout L,
                                                           const int32_t *__restrict__ pairs, int m, int layout,
                                                           float *__restrict__ planes, uint8_t *__restrict__ mask_out,
                                                           uint64_t *__restrict__ key_out, int legacy_mask)
@@ -386,11 +389,13 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_observe(const uint8_t *__rest
     constexpr int NC = H * W, N = 2 * H - 1, NPIX = N * N, NEL = NPIX * 3;
     static_assert(H == W, "only square boards batch (rot90 transposes odd-k shapes)");
     extern __shared__ __align__(16) uint8_t smem[];
+    constexpr int GPW = 64 / GL;                       // observations per wavefront
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int pi = blockIdx.x * WAVES_PER_BLOCK + wv;
+    const int sl = lane % GL, gq = lane / GL;
+    const int pi = (blockIdx.x * WPB + wv) * GPW + gq;
     const bool valid = pi < m;
     const int S = L.S, mask = L.cap_mask;
-    uint8_t *g = smem + wv * lds_per_wave_obs(L);
+    uint8_t *g = smem + (wv * GPW + gq) * (planes ? lds_per_wave_obs(L) : lds_per_wave(L));
     uint16_t *ttl = (uint16_t *)(g + L.stride);             // max tail-distance of any node on the cell
     uint8_t *hidx = (uint8_t *)(g + L.stride + 2 * L.nc_pad);  // 1 + id of the snake whose head is here
     float *hval = (float *)(g + L.stride + 4 * L.nc_pad);   // channel-0 value per snake id (8 floats)
@@ -399,8 +404,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_observe(const uint8_t *__rest
     const int you = valid ? pairs[2 * pi + 1] : 0;
     const uint8_t *gsrc = state + (size_t)slot * L.stride;
     if (valid)
-        for (int i = lane; i < L.stride / 16; i += 64) ((uint4 *)g)[i] = ((const uint4 *)gsrc)[i];
-    for (int i = lane * 4; i < 4 * L.nc_pad; i += 256) *(uint32_t *)((uint8_t *)ttl + i) = 0u;
+        for (int i = sl; i < L.stride / 16; i += GL) ((uint4 *)g)[i] = ((const uint4 *)gsrc)[i];
+    for (int i = sl * 4; i < 4 * L.nc_pad; i += GL * 4) *(uint32_t *)((uint8_t *)ttl + i) = 0u;
     __syncthreads();
 
     const SnakeMeta *meta = (const SnakeMeta *)(g + L.meta_off);
@@ -415,13 +420,13 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_observe(const uint8_t *__rest
         const SnakeMeta ms = meta[s];
         if (!ms.alive) continue;
         const cell_t *r = (const cell_t *)(g + s * L.ring_bytes);
-        for (int k = lane; k < ms.len; k += 64) {
+        for (int k = sl; k < ms.len; k += GL) {
             const int c = r[(ms.tail + k) & mask];
             const bool last = (k == ms.len - 1) || (r[(ms.tail + k + 1) & mask] != c);
             if (last) ttl[c] = (uint16_t)(k + 1);
             if (k == ms.len - 1) hidx[c] = (uint8_t)(s + 1);
         }
-        if (lane == 0)   // (snake.length - (you.length - 0.5)) * 0.04 in float64, then float32 (game.py:229-232,257)
+        if (sl == 0)   // (snake.length - (you.length - 0.5)) * 0.04 in float64, then float32 (game.py:229-232,257)
             hval[s] = (float)(((double)ms.len - ((double)me.len - 0.5)) * 0.04);
     }
     __syncthreads();
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_observe(const uint8_t *__rest
         float *cv = canvas + lead;                     // cv[e] <-> out[e]
         const int nvec = (NEL + lead + 3) / 4;
         if (valid)
-            for (int q = lane; q < nvec; q += 64) {
+            for (int q = sl; q < nvec; q += GL) {
                 float4 v;
                 float *pv = (float *)&v;
 #pragma unroll
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_observe(const uint8_t *__rest
             }
         __syncthreads();
         if (live)
-            for (int c = lane; c < NC; c += 64) {
+            for (int c = sl; c < NC; c += GL) {
                 const int y = c / W, x = c - y * W;
                 const int si = y - hy + (H - 1), sj = x - hx + (W - 1);
                 int i, j;                              // numpy.rot90(grid, k): out[i][j] = grid[si][sj], inverted
@@ -480,7 +485,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_observe(const uint8_t *__rest
             }
         __syncthreads();
         if (valid)
-            for (int q = lane; q < nvec; q += 64) {
+            for (int q = sl; q < nvec; q += GL) {
                 const int e0 = 4 * q - lead;
                 const float4 v = *(const float4 *)(canvas + 4 * q);
                 if (e0 >= 0 && e0 + 3 < NEL) {
@@ -493,21 +498,21 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_observe(const uint8_t *__rest
                 }
             }
     }
-    if (mask_out && valid && lane < 3) {
+    if (mask_out && valid && sl < 3) {
         uint8_t b = 1;
         if (live) {
-            const int ad = (k + 3 + lane) & 3;           // left / straight / right of the heading
+            const int ad = (k + 3 + sl) & 3;           // left / straight / right of the heading
             const int y = hy + (ad == 2) - (ad == 0), x = hx + (ad == 1) - (ad == 3);
             float v = 1.0f;
             if (y >= 0 && y < H && x >= 0 && x < W) v = cell_val(y * W + x, 1);
             b = legacy_mask ? ((double)v >= 0.04) : (v >= 0.04f);          // alpha_nnet.py:75-76
         }
-        mask_out[(size_t)pi * 3 + lane] = b;
+        mask_out[(size_t)pi * 3 + sl] = b;
     }
     if (key_out) {
         uint64_t lo = 0, hi = 0;
         if (live) {
-            for (int c = lane; c < NC; c += 64) {
+            for (int c = sl; c < NC; c += GL) {
                 const uint32_t b0 = __float_as_uint(cell_val(c, 0)), b1 = __float_as_uint(cell_val(c, 1)),
                                b2 = __float_as_uint(cell_val(c, 2));
                 if (b0 == 0u && b1 == 0x3F800000u && b2 == 0u) continue;   // indistinguishable from a wall
@@ -525,9 +530,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_observe(const uint8_t *__rest
                 hi += sm64(xk ^ 0xD6E8FEB86659FD93ull);
             }
         }
-        lo = wave_sum_u64(lo);
-        hi = wave_sum_u64(hi);
-        if (valid && lane == 0) { key_out[2 * (size_t)pi] = lo; key_out[2 * (size_t)pi + 1] = hi; }
+        lo = group_sum_u64<GL>(lo);
+        hi = group_sum_u64<GL>(hi);
+        if (valid && sl == 0) { key_out[2 * (size_t)pi] = lo; key_out[2 * (size_t)pi + 1] = hi; }
     }
 }
 
@@ -756,9 +761,20 @@ extern "C" int snk_engine_observe(const snk_engine *e, const int32_t *d_pairs, i
     if (m <= 0) return 0;                               // an empty request is a no-op (its buffers may be NULL)
     SNK_REQUIRE(d_pairs != nullptr, "snk_engine_observe: d_pairs is NULL");
     const Layout L = e->L;
-    const size_t lds = (size_t)WAVES_PER_BLOCK * lds_per_wave_obs(L);
-    DISPATCH_BOARD(L, (k_observe<BH, BW><<<wave_grid(m), BLOCK_THREADS, lds, (hipStream_t)stream>>>(
-        e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask)));
+    // Without planes (mask and key only: every rollout state of the MCTS) the work is the per-observation preamble and four
+    // observations share a wavefront (11x11, 7x7: their LDS is 1.2 KB each); with planes the kernel is a 5.3 KB store
+    // stream per observation and one wavefront per observation keeps more stores in flight (measured: 61 us against 105).
+    if (L.H <= 11 && !d_planes) {
+        constexpr int WPB = 4;
+        const size_t lds = (size_t)WPB * 4 * lds_per_wave(L);
+        const int grid = (m + WPB * 4 - 1) / (WPB * 4);
+        if (L.H == 11) k_observe<11, 11, 16, WPB><<<grid, WPB * 64, lds, (hipStream_t)stream>>>(e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask);
+        else k_observe<7, 7, 16, WPB><<<grid, WPB * 64, lds, (hipStream_t)stream>>>(e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask);
+    } else {
+        const size_t lds = (size_t)WAVES_PER_BLOCK * (d_planes ? lds_per_wave_obs(L) : lds_per_wave(L));
+        DISPATCH_BOARD(L, (k_observe<BH, BW, 64, WAVES_PER_BLOCK><<<wave_grid(m), BLOCK_THREADS, lds, (hipStream_t)stream>>>(
+            e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask)));
+    }
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
