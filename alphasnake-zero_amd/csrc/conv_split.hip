@@ -366,6 +366,7 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
                             int n_images, int height, int width, int relu, void *stream)
 {
     SNK_REQUIRE(n_images >= 0 && height >= 1 && width >= 3, "snk_conv3x3_bn_f16s: bad shape %d x %d x %d", n_images, height, width);
+    SNK_REQUIRE(d_out != d_x, "snk_conv3x3_bn_f16s: in-place convolution is not possible (blocks read their neighbours' input rows)");
     if (n_images == 0) return 0;
     const int P = width + 1, HW = height * width;
     // GEMM rows = the image's pixels in row-major order, 32 per M tile; an image is cut into n_blk blocks of at most 8 M
