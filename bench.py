@@ -101,10 +101,16 @@ def engine_kernel_rooflines(se, n=32768):
     planes = torch.empty((m, 21, 21, 3), device="cuda")
     mask = torch.empty((m, 3), dtype=torch.uint8, device="cuda")
     key = torch.empty((m, 2), dtype=torch.int64, device="cuda")
-    t = timed(lambda: eng.observe(pairs, m, planes, mask, key), 10)
+    # the two forms the MCTS loop launches (snake_engine/mcts.py): mask + key for every rollout state, planes for the misses
+    t = timed(lambda: eng.observe(pairs, m, planes, None, None), 10)
     byts = m * (G + 5292)
     out["observe"] = {"bound": "hbm", "achieved": byts / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": byts / t / 8e12,
-                      "bytes_per_unit": G + 5292, "units": m, "us": t * 1e6}
+                      "bytes_per_unit": G + 5292, "units": m, "us": t * 1e6, "form": "planes only"}
+    t = timed(lambda: eng.observe(pairs, m, None, mask, key), 10)
+    byts = m * (G + 19)
+    out["observe_mask_key"] = {"bound": "hbm", "achieved": byts / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": byts / t / 8e12,
+                               "bytes_per_unit": G + 19, "units": m, "us": t * 1e6,
+                               "form": "mask + key (instruction-bound: two splitmix64 per board cell)"}
     if n < 262144:      # 32 768 games move 39 MB: launch latency shows; the 8-GPU total of BASELINE configs[3] shows the kernel
         del eng, snap, planes, mask, key
         big = engine_kernel_rooflines(se, 262144)

@@ -75,6 +75,8 @@ def main():
         print(f"observe(planes+mask+key) m={m}: {t*1e6:.1f} us  {(m*5292 + m*eng.slot_bytes)/t/1e9:.0f} GB/s")
         t = timeit(lambda: eng.observe(pairs, m, None, mask, key), iters=5)
         print(f"observe(mask+key) m={m}: {t*1e6:.1f} us  {m/t/1e6:.1f} Mobs/s")
+        t = timeit(lambda: eng.observe(pairs, m, planes, None, None), iters=5)
+        print(f"observe(planes only) m={m}: {t*1e6:.1f} us  {(m*5292 + m*eng.slot_bytes)/t/1e9:.0f} GB/s")
         del eng, snap, planes
 
 
