@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--breadth", type=int, default=50)
     ap.add_argument("--chunk", type=int, default=8192, help="states per net forward chunk")
     ap.add_argument("--conv-algo", choices=["winograd", "direct", "bf16", "f16s"], default=None,
-                    help="default: winograd (fp32, the judged configuration); bf16 = configs[4]-style bf16 MFMA, outside the 1e-5 tolerance")
+                    help="default: f16s (float32-accurate split-f16 MFMA, the judged configuration); winograd, direct: f32 MFMA; bf16 = configs[4]-style bf16 MFMA, outside the 1e-5 tolerance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rooflines", action="store_true")
     args = ap.parse_args()
