@@ -451,7 +451,7 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
         // mod 16 bytes whatever the row's position in the output array.
         float *out = planes + (size_t)pi * NEL;
         float *canvas = (float *)(g + L.stride + 4 * L.nc_pad + 64);
-        const int lead = (int)(((size_t)pi * NEL) & 3);
+        const int lead = (layout == SNK_NCHW_BF16) ? 0 : (int)(((size_t)pi * NEL) & 3);
         float *cv = canvas + lead;                     // cv[e] <-> out[e]
         const int nvec = (NEL + lead + 3) / 4;
         if (valid)
@@ -484,7 +484,13 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
                     cv[(layout == SNK_NHWC_F32) ? 3 * pp + ch : ch * NPIX + pp] = cell_val(c, ch);
             }
         __syncthreads();
-        if (valid)
+        if (valid && layout == SNK_NCHW_BF16) {            // same values, channel-major, rounded to bf16 (nearest even)
+            unsigned short *o16 = (unsigned short *)planes + (size_t)pi * NEL;
+            for (int e = sl; e < NEL; e += GL) {
+                const uint32_t u = __float_as_uint(canvas[e]);
+                o16[e] = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);      // observation values are finite
+            }
+        } else if (valid)
             for (int q = sl; q < nvec; q += GL) {
                 const int e0 = 4 * q - lead;
                 const float4 v = *(const float4 *)(canvas + 4 * q);
@@ -757,7 +763,7 @@ extern "C" int snk_engine_observe(const snk_engine *e, const int32_t *d_pairs, i
                                   float *d_planes, uint8_t *d_mask, uint64_t *d_key, int legacy_mask, void *stream)
 {
     SNK_REQUIRE(e != nullptr, "snk_engine_observe: engine is NULL");
-    SNK_REQUIRE(layout == SNK_NHWC_F32 || layout == SNK_NCHW_F32, "snk_engine_observe: unknown layout %d", layout);
+    SNK_REQUIRE(layout == SNK_NHWC_F32 || layout == SNK_NCHW_F32 || layout == SNK_NCHW_BF16, "snk_engine_observe: unknown layout %d", layout);
     if (m <= 0) return 0;                               // an empty request is a no-op (its buffers may be NULL)
     SNK_REQUIRE(d_pairs != nullptr, "snk_engine_observe: d_pairs is NULL");
     const Layout L = e->L;

@@ -10,7 +10,7 @@ import torch
 
 from ._lib import lib, check, SnkGameState, EngineError
 
-NHWC_F32, NCHW_F32 = 0, 1
+NHWC_F32, NCHW_F32, NCHW_BF16 = 0, 1, 2
 
 
 def _ptr(t):
@@ -132,7 +132,7 @@ class Engine:
         pairs = self._i32(pairs)
         m = pairs.shape[0]
         shape = (m,) + (self.obs_shape if layout == NHWC_F32 else (3,) + self.obs_shape[:2])
-        planes = self.new(shape, torch.float32) if want_planes else None
+        planes = self.new(shape, torch.bfloat16 if layout == NCHW_BF16 else torch.float32) if want_planes else None
         mask = self.new((m, 3), torch.uint8) if want_mask else None
         key = self.new((m, 2), torch.int64) if want_key else None
         self.observe(pairs, m, planes, mask, key, layout, legacy_mask)

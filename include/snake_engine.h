@@ -109,13 +109,14 @@ int snk_engine_ids(const snk_engine *e, const int32_t *d_slots, int n, int32_t *
  *      (alpha_nnet.py:63-76) + the transposition key (agent.py:175) -------------------------
  * d_pairs: int32[m][2] = (slot, snake id) of the observations wanted, any order.
  * layout: SNK_NHWC_F32 writes the reference's exact bytes ((2H-1) x (2W-1) x 3 float32, rotated
- *   so the snake faces up); SNK_NCHW_F32 the same values channel-major.
+ *   so the snake faces up); SNK_NCHW_F32 the same values channel-major; SNK_NCHW_BF16 those rounded to bf16
+ *   (nearest even), 2 bytes per value (d_planes then points to uint16[m][3][2H-1][2W-1]).
  * d_planes (optional): float[m][...] observation planes.
  * d_mask (optional): uint8[m][3] 1 = left/straight/right blocked (obstacle test on channel 1;
  *   legacy_mask != 0 selects the float64 compare of the reference's pinned NumPy 1.18).
  * d_key (optional): uint64[m][2] 128-bit digest of the observation bytes (oracle/obs_key.py).
  * A pair naming a dead snake yields zero planes, mask 1,1,1 and key 0,0.                      */
-enum { SNK_NHWC_F32 = 0, SNK_NCHW_F32 = 1 };
+enum { SNK_NHWC_F32 = 0, SNK_NCHW_F32 = 1, SNK_NCHW_BF16 = 2 };
 int snk_engine_observe(const snk_engine *e, const int32_t *d_pairs, int m, int layout,
                        float *d_planes, uint8_t *d_mask, uint64_t *d_key, int legacy_mask,
                        void *stream);

@@ -214,7 +214,8 @@ def test_no_empty_cell_for_food(se, oracle):
 @pytest.mark.parametrize("cfg", TIC_CFGS)
 def test_observe_bytes_masks_keys(se, cfg):
     """Game.get_states() bytes, obstacle masks (both NumPy semantics) and 128-bit keys for every golden observation"""
-    from snake_engine.engine import state_from_compact, NCHW_F32
+    import torch
+    from snake_engine.engine import state_from_compact, NCHW_F32, NCHW_BF16
     z = load_golden(f"tic_{cfg}.npz")
     s = load_golden(f"states_{cfg}.npz")
     uniq = np.unique(s["state_index"])
@@ -233,6 +234,8 @@ def test_observe_bytes_masks_keys(se, cfg):
     assert np.array_equal(key.cpu().numpy().view(np.uint64), s["key"])
     nchw, _, _ = eng.observe_all(pairs, want_mask=False, want_key=False, layout=NCHW_F32)
     assert np.array_equal(nchw.cpu().numpy(), planes_h.transpose(0, 3, 1, 2))
+    nchw16, _, _ = eng.observe_all(pairs, want_mask=False, want_key=False, layout=NCHW_BF16)      # same values, round-to-nearest-even bf16
+    assert torch.equal(nchw16.view(torch.int16), nchw.to(torch.bfloat16).view(torch.int16))
 
 
 def test_observe_dead_snake_and_any_order(se):
