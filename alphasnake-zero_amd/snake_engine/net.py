@@ -40,6 +40,29 @@ def glorot_uniform_weights(input_shape, blocks=4, seed=0):
     return ws
 
 
+def activation_scales(weights, target_log2=9):
+    """Power-of-two scale of every tower layer's INPUT for the split-f16 kernel (snk_conv3x3_prepare_weights_f16s).
+    A bound on the input comes from the producing batch-norm: |beta| + 8 |gamma| (eight standard deviations of a
+    normalised pre-activation), plus the shortcut's own bound behind a residual add.  The scale brings the bound to at
+    most 2^target_log2: 2^9 leaves 128x headroom to the f16 maximum (beyond it the kernel clamps) and keeps the lo
+    part a normal f16 number for every input above 1/2048 of the bound."""
+    blocks = n_blocks_of(weights)
+
+    def bn_bound(g, b):
+        return float(np.max(np.abs(np.asarray(b, np.float64)) + 8.0 * np.abs(np.asarray(g, np.float64))))
+    bound_in = bn_bound(weights[1], weights[2])              # stem output
+    scales = []
+    bound_block_in = bound_in
+    for i in range(2 * blocks):
+        base = 5 + 5 * i
+        scales.append(2.0 ** (target_log2 - math.ceil(math.log2(max(bound_in, 2.0 ** -100)))))
+        if i % 2 == 0:
+            bound_block_in, bound_in = bound_in, bn_bound(weights[base + 1], weights[base + 2])
+        else:
+            bound_in = bound_block_in + bn_bound(weights[base + 1], weights[base + 2])       # relu(bn(conv) + shortcut)
+    return scales
+
+
 def n_blocks_of(weights):
     return (len(weights) - 14) // 10
 
@@ -81,21 +104,9 @@ class QNet:
         self.stem_sc, self.stem_sh = fold(*t[1:5])
         self.conv_wT, self.conv_sc, self.conv_sh = [], [], []
         st = torch.cuda.current_stream().cuda_stream
-        # "f16s": a bound on each tower layer's input from the producing batch-norm (|beta| + 8 |gamma|: eight standard
-        # deviations of a normalised pre-activation; the shortcut adds its own bound) picks the power of two that brings the
-        # inputs to <= 2^9 before they are split into f16 hi + lo: 128x headroom to the f16 range (beyond it the kernel
-        # clamps), and lo stays a normal f16 number for every input above 1/2048 of the bound
-        def bn_bound(g, b):
-            return float((b.abs() + 8.0 * g.abs()).max().item())
-        bound_in = bn_bound(t[1], t[2])              # stem output
-        self.conv_x_scale = []
+        self.conv_x_scale = activation_scales(self.weights)      # used by the "f16s" kernel only
         for i in range(2 * self.blocks):
             base = 5 + 5 * i
-            self.conv_x_scale.append(2.0 ** (9 - math.ceil(math.log2(max(bound_in, 2.0 ** -100)))))
-            if i % 2 == 0:
-                bound_block_in, bound_in = bound_in, bn_bound(t[base + 1], t[base + 2])
-            else:
-                bound_in = bound_block_in + bn_bound(t[base + 1], t[base + 2])       # relu(bn(conv) + shortcut)
             if self.conv_algo == "bf16":
                 wT = torch.empty(9 * 128 * 128, dtype=torch.int16, device=dev)
                 check(self.L.snk_conv3x3_prepare_weights_bf16(t[base].contiguous().data_ptr(), wT.data_ptr(), st))
