@@ -74,7 +74,9 @@ extern "C" int snk_dbg_conv_stamps(unsigned long long *h_out, int n_blocks)
 // NI: M tiles (of 32 GEMM rows) per block, <= 8.  MODE fixes the epilogue's options at compile time (no branches per row):
 //   0 all read from the arguments; 1 ReLU, no residual; 2 ReLU + residual; 3 ReLU + residual + fused head, no layer output
 #define hs_dpp(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
-template <int NI, int MODE>
+// SPLIT = false: the reduced-precision form for BASELINE configs[4] ("bf16 MFMA conv"): the same kernel with the hi parts
+//   only, one MFMA per product instead of three (f16 operands: 11 significand bits against bf16's 8, float32 accumulate).
+template <int NI, int MODE, bool SPLIT = true>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
 {
     const bool has_res = MODE == 0 ? p.res != nullptr : MODE >= 2;
@@ -129,16 +131,20 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
         v_.x = __builtin_amdgcn_fmed3f(v_.x, -65504.f, 65504.f); v_.y = __builtin_amdgcn_fmed3f(v_.y, -65504.f, 65504.f); \
         v_.z = __builtin_amdgcn_fmed3f(v_.z, -65504.f, 65504.f); v_.w = __builtin_amdgcn_fmed3f(v_.w, -65504.f, 65504.f); \
         hi_t[0] = (_Float16)v_.x; hi_t[1] = (_Float16)v_.y; hi_t[2] = (_Float16)v_.z; hi_t[3] = (_Float16)v_.w; \
-        d_t.x = v_.x - (float)hi_t[0]; d_t.y = v_.y - (float)hi_t[1];                           \
-        d_t.z = v_.z - (float)hi_t[2]; d_t.w = v_.w - (float)hi_t[3];                           \
+        if (SPLIT) {                                                                            \
+            d_t.x = v_.x - (float)hi_t[0]; d_t.y = v_.y - (float)hi_t[1];                       \
+            d_t.z = v_.z - (float)hi_t[2]; d_t.w = v_.w - (float)hi_t[3];                       \
+        }                                                                                       \
     }
 #define HS_SPLIT_B(k_, bufoff)                                                                  \
     {                                                                                           \
-        f16x4 lo_;                                                                              \
-        lo_[0] = (_Float16)d_t.x; lo_[1] = (_Float16)d_t.y; lo_[2] = (_Float16)d_t.z; lo_[3] = (_Float16)d_t.w; \
         unsigned char *d_ = smem + (bufoff) + ldo[k_];                                          \
         *(f16x4 *)d_ = hi_t;                                                                    \
-        *(f16x4 *)(d_ + 32) = lo_;                                                              \
+        if (SPLIT) {                                                                            \
+            f16x4 lo_;                                                                          \
+            lo_[0] = (_Float16)d_t.x; lo_[1] = (_Float16)d_t.y; lo_[2] = (_Float16)d_t.z; lo_[3] = (_Float16)d_t.w; \
+            *(f16x4 *)(d_ + 32) = lo_;                                                          \
+        }                                                                                       \
     }
 
     HS_STAMP(0)
@@ -147,7 +153,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
 #define HS_LOADB(slot, g)                                                                       \
     {                                                                                           \
         const f16x8 *w_ = wl + (long)(g) * 512;                                                 \
-        Bq[slot][0] = w_[0]; Bq[slot][1] = w_[64];                                              \
+        Bq[slot][0] = w_[0];                                                                    \
+        if (SPLIT) Bq[slot][1] = w_[64];                                                        \
     }
     HS_LOAD(0)
 #pragma unroll
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
             _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                    \
                 const int t2_ = (s) * NI + i + 2;                                               \
                 f16x8 nh = a1h, nl = a1l;                                                       \
-                if (t2_ < 9 * NI) { nh = HS_LDS(HS_AOFF(t2_)); nl = HS_LDS(HS_AOFF(t2_) + 32); } \
+                if (t2_ < 9 * NI) { nh = HS_LDS(HS_AOFF(t2_)); if (SPLIT) nl = HS_LDS(HS_AOFF(t2_) + 32); } \
                 __builtin_amdgcn_sched_barrier(0);                                              \
                 if (i == 0) {                                                                   \
                     if (MORE || (s) + HS_AHEAD < 9) { HS_LOADB(((s) + HS_AHEAD) % HS_RING, gnext + (s)); } \
@@ -197,8 +204,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
                     }                                                                           \
                 }                                                                               \
                 HS_MFMA(a0h, Bq[(s) % HS_RING][0], acc[i]);                                     \
-                HS_MFMA(a0h, Bq[(s) % HS_RING][1], acc[i]);                                     \
-                HS_MFMA(a0l, Bq[(s) % HS_RING][0], acc[i]);                                     \
+                if (SPLIT) {                                                                    \
+                    HS_MFMA(a0h, Bq[(s) % HS_RING][1], acc[i]);                                 \
+                    HS_MFMA(a0l, Bq[(s) % HS_RING][0], acc[i]);                                 \
+                }                                                                               \
                 a0h = a1h; a0l = a1l; a1h = nh; a1l = nl;                                       \
                 __builtin_amdgcn_sched_barrier(0);                                              \
             }                                                                                   \
@@ -208,8 +217,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
         const unsigned rb = (unsigned)(c & 1) * (HS_NPB * HS_LDP);                              \
         const unsigned wb = (unsigned)((c & 1) ^ 1) * (HS_NPB * HS_LDP);                        \
         const int gnext = c * 9 + HS_AHEAD;             /* global step the first prefetch of this chunk fetches */ \
-        f16x8 a0h = HS_LDS(HS_AOFF(0)), a0l = HS_LDS(HS_AOFF(0) + 32);                          \
-        f16x8 a1h = HS_LDS(HS_AOFF(1)), a1l = HS_LDS(HS_AOFF(1) + 32);                          \
+        f16x8 a0h = HS_LDS(HS_AOFF(0)), a1h = HS_LDS(HS_AOFF(1)), a0l = a0h, a1l = a1h;         \
+        if (SPLIT) { a0l = HS_LDS(HS_AOFF(0) + 32); a1l = HS_LDS(HS_AOFF(1) + 32); }            \
         HS_TAP(0, MORE) HS_TAP(1, MORE) HS_TAP(2, MORE) HS_TAP(3, MORE) HS_TAP(4, MORE)         \
         HS_TAP(5, MORE) HS_TAP(6, MORE) HS_TAP(7, MORE) HS_TAP(8, MORE)                         \
         if (MORE && 9 * NI < 2 * HS_NST) {              /* too few regions to spread the split over: do it here */ \
@@ -363,7 +372,7 @@ extern "C" int snk_conv3x3_prepare_weights_f16s(const float *d_w_hwio, void *d_w
 
 static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
                             const float *d_residual, float *d_out, const float *d_w1x1, float s1, float b1, float *d_h1,
-                            int n_images, int height, int width, int relu, void *stream)
+                            int n_images, int height, int width, int relu, bool split, void *stream)
 {
     SNK_REQUIRE(n_images >= 0 && height >= 1 && width >= 3, "snk_conv3x3_bn_f16s: bad shape %d x %d x %d", n_images, height, width);
     SNK_REQUIRE(d_out != d_x, "snk_conv3x3_bn_f16s: in-place convolution is not possible (blocks read their neighbours' input rows)");
@@ -389,6 +398,20 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
     hipStream_t st = (hipStream_t)stream;
     // the three epilogue shapes the net wrapper uses get compile-time versions at the 21x21 tile count; everything else
     // takes the generic version
+    if (!split) {
+        switch (n_mt) {
+        case 1: k_conv3x3_f16s<1, 0, false><<<grid, 256, 0, st>>>(a); break;
+        case 2: k_conv3x3_f16s<2, 0, false><<<grid, 256, 0, st>>>(a); break;
+        case 3: k_conv3x3_f16s<3, 0, false><<<grid, 256, 0, st>>>(a); break;
+        case 4: k_conv3x3_f16s<4, 0, false><<<grid, 256, 0, st>>>(a); break;
+        case 5: k_conv3x3_f16s<5, 0, false><<<grid, 256, 0, st>>>(a); break;
+        case 6: k_conv3x3_f16s<6, 0, false><<<grid, 256, 0, st>>>(a); break;
+        case 7: k_conv3x3_f16s<7, 0, false><<<grid, 256, 0, st>>>(a); break;
+        default: k_conv3x3_f16s<8, 0, false><<<grid, 256, 0, st>>>(a); break;
+        }
+        SNK_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     const int mode = !relu ? 0 : (d_w1x1 ? (d_residual && !d_out ? 3 : 0) : (d_residual ? 2 : 1));
     if (n_mt == 7 && mode == 1) k_conv3x3_f16s<7, 1><<<grid, 256, 0, st>>>(a);
     else if (n_mt == 7 && mode == 2) k_conv3x3_f16s<7, 2><<<grid, 256, 0, st>>>(a);
@@ -411,7 +434,16 @@ extern "C" int snk_conv3x3_bn_f16s(const float *d_x, const void *d_wS, const flo
 {
     SNK_REQUIRE(d_x && d_wS && d_scale && d_shift && d_out, "snk_conv3x3_bn_f16s: NULL argument");
     return conv_f16s_launch(d_x, d_wS, d_scale, d_shift, d_residual, d_out, nullptr, 0.f, 0.f, nullptr, n_images, height, width,
-                            relu, stream);
+                            relu, true, stream);
+}
+
+extern "C" int snk_conv3x3_bn_f16(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
+                                  const float *d_residual, float *d_out, int n_images, int height, int width, int relu,
+                                  void *stream)
+{
+    SNK_REQUIRE(d_x && d_wS && d_scale && d_shift && d_out, "snk_conv3x3_bn_f16: NULL argument");
+    return conv_f16s_launch(d_x, d_wS, d_scale, d_shift, d_residual, d_out, nullptr, 0.f, 0.f, nullptr, n_images, height, width,
+                            relu, false, stream);
 }
 
 extern "C" int snk_conv3x3_bn_f16s_head(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
@@ -420,5 +452,5 @@ extern "C" int snk_conv3x3_bn_f16s_head(const float *d_x, const void *d_wS, cons
 {
     SNK_REQUIRE(d_x && d_wS && d_scale && d_shift && d_w1x1 && d_h1, "snk_conv3x3_bn_f16s_head: NULL argument");
     return conv_f16s_launch(d_x, d_wS, d_scale, d_shift, d_residual, d_out, d_w1x1, bn_scale, bn_shift, d_h1, n_images, height,
-                            width, 1, stream);
+                            width, 1, true, stream);
 }

@@ -58,6 +58,7 @@ PROTOTYPES = {
     "snk_conv3x3_bn_f32_winograd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "snk_conv3x3_prepare_weights_f16s": (i32, [vp, vp, C.c_float, vp]),
     "snk_conv3x3_bn_f16s": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "snk_conv3x3_bn_f16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "snk_conv3x3_bn_f16s_head": (i32, [vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, i32, i32, i32, vp]),
     "snk_head_dense_f32": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "snk_stem_conv_bn_relu_f32": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),

@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--games", type=int, default=4096, help="parallel root games per GPU")
     ap.add_argument("--breadth", type=int, default=50)
     ap.add_argument("--chunk", type=int, default=8192, help="states per net forward chunk")
-    ap.add_argument("--conv-algo", choices=["winograd", "direct", "bf16", "f16s"], default=None,
+    ap.add_argument("--conv-algo", choices=["winograd", "direct", "bf16", "f16s", "f16"], default=None,
                     help="default: f16s (float32-accurate split-f16 MFMA, the judged configuration); winograd, direct: f32 MFMA; bf16 = configs[4]-style bf16 MFMA, outside the 1e-5 tolerance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rooflines", action="store_true")
@@ -211,9 +211,9 @@ def main():
         conv_flops = sum(f for _, _, f in tm)
         achieved = conv_flops / conv_s / 1e12 if conv_s > 0 else 0.0
         algo = nnet._qnet.conv_algo
-        peak = 2500.0 if algo in ("bf16", "f16s") else 157.3      # dense MFMA peaks (bf16 / f16, f32), MI355X_MICROARCH.md
+        peak = 2500.0 if algo in ("bf16", "f16s", "f16") else 157.3      # dense MFMA peaks (bf16 / f16, f32), MI355X_MICROARCH.md
         # MFMA flops the kernel executes per algorithmic (direct-convolution) flop
-        executed = {"f16s": 3.0 * 448 / 441, "winograd": 16 * 121 / (441 * 9.0)}.get(algo, 1.0)
+        executed = {"f16s": 3.0 * 448 / 441, "f16": 448 / 441.0, "winograd": 16 * 121 / (441 * 9.0)}.get(algo, 1.0)
         traffic = None      # HBM bytes per average launch, from the committed rocprofv3 --pmc passes (profiles/)
         tfile = os.path.join(REPO, "profiles", {"f16s": "r1_conv_f16s_traffic.json", "winograd": "r1_conv_traffic.json"}.get(algo, "none"))
         if os.path.exists(tfile) and tm:
@@ -224,6 +224,7 @@ def main():
             "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"bf16": "bf16 operands, f32 accumulate (outside the 1e-5 parity tolerance)",
+                      "f16": "f16 operands, f32 accumulate (outside the 1e-5 parity tolerance)",
                       "f16s": "f32 (tower convolutions: each f32 operand split into f16 hi + lo, 3 f16 MFMAs per product, f32 accumulate)"}.get(algo, "f32"),
             "data": "synthetic",
             "config": {"workload": f"configs[1]: 11x11, 4 snakes, {args.games} parallel games per GPU, max_MCTS_breadth "
@@ -233,7 +234,8 @@ def main():
                        "net_evals_per_env_step": evals / max(1, gr.env_steps), "sim_steps_per_env_step": sims / max(1, gr.env_steps),
                        "net_evals_per_s_rank0": evals / dt, "sample_rows_gathered": int(Xg.shape[0])},
             "roofline": {"bound": "mfma",
-                         "kernel": {"winograd": "k_conv3x3_wino_f32", "bf16": "k_conv3x3_bf16", "f16s": "k_conv3x3_f16s"}.get(algo, "k_conv3x3_f32"),
+                         "kernel": {"winograd": "k_conv3x3_wino_f32", "bf16": "k_conv3x3_bf16", "f16s": "k_conv3x3_f16s",
+                                    "f16": "k_conv3x3_f16s<SPLIT = false>"}.get(algo, "k_conv3x3_f32"),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "launches": len(tm),
                          "flops_convention": "algorithmic = direct 3x3 convolution, 2*441*1152*128 per state and layer (SURVEY 8d)",
@@ -241,6 +243,7 @@ def main():
                          "algorithm": {"winograd": "Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: executes 16*121/(441*9) = 0.488 of the "
                                                    "algorithmic flops, fp32 throughout",
                                        "bf16": "implicit GEMM on v_mfma_f32_32x32x16_bf16",
+                                       "f16": "implicit GEMM on v_mfma_f32_32x32x16_f16, f16-rounded operands (reduced precision)",
                                        "f16s": "implicit GEMM on v_mfma_f32_32x32x16_f16 with split operands: executes 3 (hi*hi, hi*lo, lo*hi) "
                                                "x 448/441 (M-tile padding) = 3.05 MFMA flops per algorithmic flop; peak = dense f16 MFMA "
                                                "at 2.4 GHz, the chip holds ~1.55 GHz in this loop on random data (DESIGN.md section 4)"}.get(

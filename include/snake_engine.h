@@ -183,6 +183,12 @@ int snk_conv3x3_prepare_weights_f16s(const float *d_w_hwio, void *d_wS, float x_
 int snk_conv3x3_bn_f16s(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
                         const float *d_residual, float *d_out, int n_images, int height, int width, int relu,
                         void *stream);
+/* Reduced-precision form of the same kernel for BASELINE configs[4] ("bf16 MFMA conv"; NOT the 1e-5 parity path): the hi
+ * parts only, one v_mfma_f32_32x32x16_f16 per product (f16 operands: 11 significand bits, float32 accumulate).  Takes
+ * the weight image of snk_conv3x3_prepare_weights_f16s. */
+int snk_conv3x3_bn_f16(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
+                       const float *d_residual, float *d_out, int n_images, int height, int width, int relu,
+                       void *stream);
 /* The tower's LAST layer with the head's 1x1 stage fused into its epilogue (alpha_nnet.py:46-50): besides (or, with
  * d_out NULL, instead of) the layer output it writes d_h1[n][height*width] = relu(dot(out[pixel][:], w1x1) * bn_scale
  * + bn_shift); snk_head_dense_f32 finishes AlphaNNet.v from d_h1 (Flatten, Dense(128) + ReLU, Dense(3) + tanh,

@@ -262,6 +262,46 @@ def test_full_net_19x19_10_blocks(env, algo, monkeypatch):
     assert np.abs(got - ref).max() <= TOL_Q, np.abs(got - ref).max()
 
 
+def test_f16_reduced_precision_layer_and_net(env, monkeypatch):
+    """configs[4]'s reduced-precision option on the f16s kernel (`SNK_CONV_ALGO=f16`): operands rounded to f16 (after the
+    power-of-two scales), one MFMA per product, float32 accumulation.  Against a float64 reference computed from the SAME
+    f16-rounded operands the layer is exact to float32 rounding; the whole net stays within 5e-3 of the float32 net."""
+    torch, se, net = env
+    from snake_engine._lib import lib, check
+    from snake_engine.net import F16S_WEIGHT_BYTES
+    from oracle import net_ref
+    L = lib()
+    g = torch.Generator().manual_seed(21)
+    n, hw = 3, 21
+    x = torch.randn(n, hw, hw, 128, generator=g)
+    w = torch.randn(3, 3, 128, 128, generator=g) * 0.05
+    sc, sh = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.1
+    r = torch.randn(n, hw, hw, 128, generator=g)
+    xs = 256.0
+    ws = 2.0 ** (8 - int(torch.floor(torch.log2(w.abs().max())).item()))        # the kernel's weight scale: max|w| -> [256, 512)
+    xh = (x * xs).to(torch.float16).double() / xs
+    wh = (w * ws).to(torch.float16).double() / ws
+    ref = torch.nn.functional.conv2d(xh.permute(0, 3, 1, 2), wh.permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1)
+    ref = (ref * sc.double() + sh.double() + r.double()).clamp_min(0)
+    dev = [t.cuda() for t in (x, w, sc, sh, r)]
+    wS = torch.empty(F16S_WEIGHT_BYTES, dtype=torch.uint8, device="cuda")
+    out = torch.full((n, hw, hw, 128), float("nan"), device="cuda")
+    check(L.snk_conv3x3_prepare_weights_f16s(dev[1].data_ptr(), wS.data_ptr(), C.c_float(xs), _st()))
+    check(L.snk_conv3x3_bn_f16(dev[0].data_ptr(), wS.data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(),
+                               out.data_ptr(), n, hw, hw, 1, _st()))
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-5 * ref.abs().max().item(), err
+    monkeypatch.setenv("SNK_CONV_ALGO", "f16")
+    s = load_golden("states_11x11x4.npz")
+    states = s["raw"][:48]
+    wts = _randomised_bn(net.glorot_uniform_weights((21, 21, 3), blocks=4, seed=0), 3)
+    got = net.QNet(wts, (21, 21, 3)).forward(torch.as_tensor(states, device="cuda")).cpu().numpy()
+    ref32 = net_ref.forward(wts, states, apply_mask=False)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref32).max() <= 5e-3, np.abs(got - ref32).max()
+    assert np.abs(got - ref32).max() > 1e-6, "the reduced-precision path did not run"
+
+
 def test_bf16_conv_layer_and_net(env, monkeypatch):
     """configs[4] ("bf16 MFMA conv"): operands rounded to bf16, float32 accumulation.  Against a float64 reference
     computed from the SAME bf16-rounded operands the layer is exact to float32 rounding; the whole 10-block 19x19 net

@@ -1,5 +1,5 @@
 """times one 3x3 tower-layer kernel and checks it against a float64 torch conv2d:
-   conv_time.py [winograd|direct|f16s|bf16] [H] [batch sizes ...]"""
+   conv_time.py [winograd|direct|f16s|f16|bf16] [H] [batch sizes ...]"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [REPO, os.path.join(REPO, "alphasnake-zero_amd")]
@@ -12,14 +12,15 @@ sizes = [int(v) for v in sys.argv[3:]] or [64, 512, 4096]
 prep, conv, wbytes = {"winograd": (L.snk_conv3x3_prepare_weights_winograd, L.snk_conv3x3_bn_f32_winograd, 16 * 128 * 128 * 4),
                       "direct": (L.snk_conv3x3_prepare_weights, L.snk_conv3x3_bn_f32, 9 * 128 * 128 * 4),
                       "bf16": (L.snk_conv3x3_prepare_weights_bf16, L.snk_conv3x3_bn_bf16, 9 * 128 * 128 * 2),
-                      "f16s": (L.snk_conv3x3_prepare_weights_f16s, L.snk_conv3x3_bn_f16s, 9 * 128 * 128 * 4 + 16)}[algo]
+                      "f16s": (L.snk_conv3x3_prepare_weights_f16s, L.snk_conv3x3_bn_f16s, 9 * 128 * 128 * 4 + 16),
+                      "f16": (L.snk_conv3x3_prepare_weights_f16s, L.snk_conv3x3_bn_f16, 9 * 128 * 128 * 4 + 16)}[algo]
 torch.manual_seed(0)
 for n in sizes:
     for mag in (1.0, 1e-3) if n <= 64 else (1.0,):
         x = torch.randn(n, H, H, 128, device="cuda") * mag; o = torch.full_like(x, float("nan"))
         w = torch.randn(3, 3, 128, 128, device="cuda") * 0.05; U = torch.empty(wbytes, dtype=torch.uint8, device="cuda")
         sc = torch.rand(128, device="cuda") + 0.5; sh = torch.randn(128, device="cuda") * mag
-        if algo == "f16s":      # the activation scale the net wrapper would pick: inputs up to ~8 |x| -> 2^11
+        if algo in ("f16s", "f16"):      # the activation scale the net wrapper would pick: inputs up to ~8 |x| -> 2^11
             import math
             check(prep(w.data_ptr(), U.data_ptr(), 2.0 ** (11 - math.ceil(math.log2(8 * mag))), st))
         else:
