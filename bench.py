@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=8192, help="states per net forward chunk")
     ap.add_argument("--conv-algo", choices=["winograd", "direct", "bf16", "f16s", "f16"], default=None,
                     help="default: f16s (float32-accurate split-f16 MFMA, the judged configuration); winograd, direct: f32 MFMA; bf16 = configs[4]-style bf16 MFMA, outside the 1e-5 tolerance")
+    ap.add_argument("--board", type=int, default=11, choices=[7, 11, 19], help="board side; 19 with --snakes 8 --blocks 10 = BASELINE configs[4]")
+    ap.add_argument("--snakes", type=int, default=4)
+    ap.add_argument("--blocks", type=int, default=4, help="residual blocks of the Q-net")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-rooflines", action="store_true")
     args = ap.parse_args()
@@ -156,13 +159,15 @@ def main():
     from utils.alpha_nnet import AlphaNNet
     from utils.mp_game_runner import MPGameRunner
 
-    weights = net.glorot_uniform_weights((21, 21, 3), blocks=4, seed=0)
-    nnet = AlphaNNet(input_shape=(21, 21, 3), _weights=weights)
+    B, OBS = args.board, 2 * args.board - 1
+    judged = (B, args.snakes, args.blocks) == (11, 4, 4)          # configs[1]'s shape: the one cpu_baseline / rooflines describe
+    weights = net.glorot_uniform_weights((OBS, OBS, 3), blocks=args.blocks, seed=0)
+    nnet = AlphaNNet(input_shape=(OBS, OBS, 3), _weights=weights)
     nnet._qnet.max_chunk = args.chunk
     MPGameRunner.verbose = False
     MPGameRunner.init = "device"
     alice = Agent(nnet, 2, True, 8, args.breadth, seed=1234 + rank)
-    gr = MPGameRunner(11, 11, 4, 1, args.games, seed=1234 + rank)
+    gr = MPGameRunner(B, B, args.snakes, 1, args.games, seed=1234 + rank)
 
     def barrier():
         torch.cuda.synchronize()
@@ -185,9 +190,9 @@ def main():
     # iteration-end exchange (trainer.py:63-75 across ranks): sampled rows all-gathered, counters all-reduced
     rng = np.random.RandomState(rank)
     idx, share = sdist.sample_share(len(alice.records), 5 * 2048, world, rng)
-    X = torch.as_tensor(alice.records.fetch(idx) if len(idx) else np.zeros((share, 21, 21, 3), np.float32), device="cuda")
+    X = torch.as_tensor(alice.records.fetch(idx) if len(idx) else np.zeros((share, OBS, OBS, 3), np.float32), device="cuda")
     if X.shape[0] < share:
-        X = torch.cat([X, X.new_zeros((share - X.shape[0], 21, 21, 3))])
+        X = torch.cat([X, X.new_zeros((share - X.shape[0], OBS, OBS, 3))])
     Vs = torch.as_tensor(alice._values_host()[idx] if len(idx) else np.zeros((share, 3), np.float32), device="cuda")
     if Vs.shape[0] < share:
         Vs = torch.cat([Vs, Vs.new_zeros((share - Vs.shape[0], 3))])
@@ -218,7 +223,7 @@ def main():
         tfile = os.path.join(REPO, "profiles", {"f16s": "r1_conv_f16s_traffic.json", "winograd": "r1_conv_traffic.json"}.get(algo, "none"))
         if os.path.exists(tfile) and tm:
             per_state_layer = json.load(open(tfile))["hbm_bytes_per_state_layer"]
-            traffic = per_state_layer * (conv_flops / len(tm)) / (2.0 * 441 * 9 * 128 * 128)
+            traffic = per_state_layer * (conv_flops / len(tm)) / (2.0 * 441 * 9 * 128 * 128) if judged else None
         res = {
             "metric": "self-play env-steps/sec (11x11, 4 snakes, 50 MCTS sims)",
             "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -227,7 +232,8 @@ def main():
                       "f16": "f16 operands, f32 accumulate (outside the 1e-5 parity tolerance)",
                       "f16s": "f32 (tower convolutions: each f32 operand split into f16 hi + lo, 3 f16 MFMAs per product, f32 accumulate)"}.get(algo, "f32"),
             "data": "synthetic",
-            "config": {"workload": f"configs[1]: 11x11, 4 snakes, {args.games} parallel games per GPU, max_MCTS_breadth "
+            "config": {"workload": f"{'configs[1]' if judged else 'configs[4] shape' if (B, args.snakes, args.blocks) == (19, 8, 10) else 'custom'}: "
+                                   f"{B}x{B}, {args.snakes} snakes, {args.blocks}-block net, {args.games} parallel games per GPU, max_MCTS_breadth "
                                    f"{args.breadth} (= {args.breadth // 8 * 8} rollouts), depth 8, health_dec 1, softmax_base 2, "
                                    "training=True, gen-0 Glorot net (seed 0), fp32 Q-net",
                        "games_per_gpu": args.games, "breadth": args.breadth, "parallelism": f"games sharded x{world}",
@@ -251,11 +257,11 @@ def main():
                          "avg_launch_ms": conv_s / max(1, len(tm)) * 1e3,
                          "share_of_step_time": conv_s / dt},
         }
-        if not args.no_kernel_rooflines and world == 1:
+        if not args.no_kernel_rooflines and world == 1 and judged:
             del alice, gr
             torch.cuda.empty_cache()
             res["engine_kernels"] = engine_kernel_rooflines(se)
-        if not args.no_cpu_baseline and world == 1:          # reported at N = 1 only
+        if not args.no_cpu_baseline and world == 1 and judged:          # reported at N = 1 only
             res["cpu_baseline"] = cpu_baseline(weights, args.breadth)
         print(json.dumps(res), flush=True)
     if world > 1:
