@@ -17,13 +17,15 @@
 // W + 1 so that the right border of a row is the left border of the next: the input of output pixel (y, x) for tap
 // (dy, dx) is at LDS position of (y, x) + dy (W+1) + dx, so all nine taps of an MFMA A-fragment are the SAME LDS image
 // at nine constant offsets from the lane's pixel address -- the rows are staged (and split into hi/lo) once per
-// 16-channel chunk, not once per tap.  Wave wn owns outputs 32 wn .. 32 wn + 31 for all M tiles; per (chunk, tap) and M tile it reads two
-// ds_read_b128 (hi, lo) for three MFMAs, two tiles ahead of their use.  B fragments (the pre-split weights, 576 KB,
+// 16-channel chunk, not once per tap.  Wave wn owns outputs 32 wn .. 32 wn + 31 for all M tiles; per (chunk, tap) and M
+// tile it reads two ds_read_b128 (hi, lo) for three MFMAs, two tiles ahead of their use.  B fragments (the pre-split weights, 576 KB,
 // L2 resident, stored in fragment order so that a wave's load is 1 KB contiguous) stream straight into a 3-deep
 // register ring two taps ahead; the next chunk's strip is loaded at the chunk's first tap, split and written to the
 // other LDS buffer in the chunk's last MFMA regions; one block barrier per chunk.  Epilogue: accumulators -> LDS
 // (64 rows at a time, double-buffered), read back as float4 rows, * scale + shift + residual, ReLU, whole 512-byte
-// pixel rows written; the residual loads of the next 64 rows are in flight meanwhile.
+// pixel rows written; the residual loads of the next 64 rows are in flight meanwhile.  In the tower's last layer the
+// epilogue also reduces the head's 1x1 convolution per pixel and skips the layer output.  Workgroups map to (image,
+// part) XCD-aware: the parts of an image, which share halo rows, run on the same XCD (same L2) back to back.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
