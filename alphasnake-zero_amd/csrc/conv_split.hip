@@ -392,6 +392,12 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
         if (fits || tiles_max == 1) break;
     }
     SNK_REQUIRE(fits, "snk_conv3x3_bn_f16s: observation width %d not supported (max 80)", width);
+    // small batches: cut the images finer until the grid fills the chip's 2 x 256 block slots (a block's duration, not the
+    // throughput, is what a launch of a few dozen states costs); smaller blocks always fit
+    if (n_images * n_blk < 512) {
+        n_blk = min(T, max(n_blk, (512 + n_images - 1) / n_images));
+        tiles_max = (T + n_blk - 1) / n_blk;
+    }
     const int tiles_base = T / n_blk, tiles_rem = T % n_blk;
     SNK_REQUIRE((long)n_images * n_blk < (1l << 31) && (long)HW * HS_C < (1l << 31), "snk_conv3x3_bn_f16s: batch too large");
     ConvHsArgs a = {d_x, (const f16x8 *)d_wS, (const float *)((const _Float16 *)d_wS + HS_WS_ELEMS), d_scale, d_shift,
