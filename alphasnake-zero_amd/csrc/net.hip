@@ -722,7 +722,17 @@ __global__ __launch_bounds__(256) void k_head_dense(HeadArgs p, const float *__r
 #pragma unroll
     for (int k = 0; k < HD_S / 2; ++k) acc[k] = 0.f;
     const float *hh = h1 + half * (HD_S / 2) * p.HW;
-    for (int i = 0; i < p.HW; ++i) {
+    int i = 0;
+    for (; i + 8 <= p.HW; i += 8) {             // eight Dense rows in flight per thread: the loop is load-latency bound otherwise
+        float w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = p.fc1_w[(long)(i + u) * 128 + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int k = 0; k < HD_S / 2; ++k) acc[k] = fmaf(hh[k * p.HW + i + u], w[u], acc[k]);
+    }
+    for (; i < p.HW; ++i) {
         const float w = p.fc1_w[(long)i * 128 + j];
 #pragma unroll
         for (int k = 0; k < HD_S / 2; ++k) acc[k] = fmaf(hh[k * p.HW + i], w, acc[k]);

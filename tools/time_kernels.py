@@ -51,7 +51,7 @@ def main():
         print(f"stem conv n={n}: {t*1e3:.3f} ms  {n*441*128*4/t/1e9:.0f} GB/s written")
     ws = net.glorot_uniform_weights((21, 21, 3))
     qn = net.QNet(ws, (21, 21, 3), max_chunk=4096)
-    for n in (4096, 16384):
+    for n in (16, 128, 4096, 16384):
         p = torch.randn(n, 21, 21, 3, device="cuda")
         t = timeit(lambda: qn.forward(p), iters=3, warm=1)
         print(f"net forward n={n}: {t*1e3:.1f} ms  {n/t:.0f} states/s  {qn.flops_per_state()*n/t/1e12:.1f} TFLOP/s")
