@@ -392,9 +392,10 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
         if (fits || tiles_max == 1) break;
     }
     SNK_REQUIRE(fits, "snk_conv3x3_bn_f16s: observation width %d not supported (max 80)", width);
-    // small batches: cut the images finer until the grid fills the chip's 2 x 256 block slots (a block's duration, not the
-    // throughput, is what a launch of a few dozen states costs); smaller blocks always fit
-    if (n_images * n_blk < 512) {
+    // very small batches (measured: up to ~40 images at 21x21): cut the images finer so that the grid covers more of the
+    // chip's block slots -- a block's duration, not the throughput, is what such a launch costs (16 states: 31 -> 14 us);
+    // from ~48 images on the 7-tile blocks with their compile-time epilogues are faster again
+    if (n_images <= 40 && n_images * n_blk < 512) {
         n_blk = min(T, max(n_blk, (512 + n_images - 1) / n_images));
         tiles_max = (T + n_blk - 1) / n_blk;
     }
