@@ -422,17 +422,24 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
         return 0;
     }
     const int mode = !relu ? 0 : (d_w1x1 ? (d_residual && !d_out ? 3 : 0) : (d_residual ? 2 : 1));
-    if (n_mt == 7 && mode == 1) k_conv3x3_f16s<7, 1><<<grid, 256, 0, st>>>(a);
-    else if (n_mt == 7 && mode == 2) k_conv3x3_f16s<7, 2><<<grid, 256, 0, st>>>(a);
-    else if (n_mt == 7 && mode == 3) k_conv3x3_f16s<7, 3><<<grid, 256, 0, st>>>(a);
-    else if (n_mt == 1) k_conv3x3_f16s<1, 0><<<grid, 256, 0, st>>>(a);
-    else if (n_mt == 2) k_conv3x3_f16s<2, 0><<<grid, 256, 0, st>>>(a);
-    else if (n_mt == 3) k_conv3x3_f16s<3, 0><<<grid, 256, 0, st>>>(a);
-    else if (n_mt == 4) k_conv3x3_f16s<4, 0><<<grid, 256, 0, st>>>(a);
-    else if (n_mt == 5) k_conv3x3_f16s<5, 0><<<grid, 256, 0, st>>>(a);
-    else if (n_mt == 6) k_conv3x3_f16s<6, 0><<<grid, 256, 0, st>>>(a);
-    else if (n_mt == 7) k_conv3x3_f16s<7, 0><<<grid, 256, 0, st>>>(a);
-    else k_conv3x3_f16s<8, 0><<<grid, 256, 0, st>>>(a);
+#define HS_LAUNCH_MODES(NI_)                                                                    \
+    case NI_:                                                                                   \
+        if (mode == 1) k_conv3x3_f16s<NI_, 1><<<grid, 256, 0, st>>>(a);                         \
+        else if (mode == 2) k_conv3x3_f16s<NI_, 2><<<grid, 256, 0, st>>>(a);                    \
+        else if (mode == 3) k_conv3x3_f16s<NI_, 3><<<grid, 256, 0, st>>>(a);                    \
+        else k_conv3x3_f16s<NI_, 0><<<grid, 256, 0, st>>>(a);                                   \
+        break;
+    switch (n_mt) {
+        HS_LAUNCH_MODES(1) HS_LAUNCH_MODES(2) HS_LAUNCH_MODES(3) HS_LAUNCH_MODES(4)
+        HS_LAUNCH_MODES(5) HS_LAUNCH_MODES(6) HS_LAUNCH_MODES(7)
+    default:
+        if (mode == 1) k_conv3x3_f16s<8, 1><<<grid, 256, 0, st>>>(a);
+        else if (mode == 2) k_conv3x3_f16s<8, 2><<<grid, 256, 0, st>>>(a);
+        else if (mode == 3) k_conv3x3_f16s<8, 3><<<grid, 256, 0, st>>>(a);
+        else k_conv3x3_f16s<8, 0><<<grid, 256, 0, st>>>(a);
+        break;
+    }
+#undef HS_LAUNCH_MODES
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
