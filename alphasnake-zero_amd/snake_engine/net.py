@@ -230,6 +230,30 @@ class QNet:
             e1.record(torch.cuda.current_stream())
             tm.append((e0, e1, 2.0 * m * self.h * self.w * 9 * 128 * 128))
 
+    def activation_report(self, planes):
+        """Largest |input| of every tower layer on the given observations against the range the split-f16 kernel was
+        given for it: a list of (max |x|, x_scale, headroom) with headroom = 65504 / (max |x| * x_scale).  The kernel
+        clamps inputs beyond the f16 range, so headroom < 1 on representative data means the batch-norm-derived scales
+        (activation_scales) do not fit these weights; use SNK_CONV_ALGO=winograd or direct for such a net."""
+        assert planes.is_cuda and planes.dtype == torch.float32 and tuple(planes.shape[1:]) == self.input_shape
+        m = planes.shape[0]
+        st = torch.cuda.current_stream().cuda_stream
+        a, b, c = self._workspace(m, 0)
+        check(self.L.snk_stem_conv_bn_relu_f32(planes.contiguous().data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(),
+                                               self.stem_sh.data_ptr(), a.data_ptr(), m, self.h, self.w, st))
+        rep, cur, t1, t2 = [], a, b, c
+
+        def note(x, i):
+            amax = float(x[:m].abs().max().item())
+            rep.append((amax, self.conv_x_scale[i], 65504.0 / max(amax * self.conv_x_scale[i], 1e-30)))
+        for blk in range(self.blocks):
+            note(cur, 2 * blk)
+            self._conv(2 * blk, cur, None, t1, m, st)
+            note(t1, 2 * blk + 1)
+            self._conv(2 * blk + 1, t1, cur, t2, m, st)
+            cur, t2 = t2, cur
+        return rep
+
     def flops_per_state(self):
         hw = self.h * self.w
         return 2 * (hw * (27 * 128 + 2 * self.blocks * 9 * 128 * 128 + 128) + hw * 128 + 128 * 3)

@@ -128,6 +128,20 @@ def test_f16s_activation_scale(env):
                                     out.data_ptr(), 1, 4, 2, 1, _st()))
 
 
+def test_activation_report_shows_the_f16s_headroom(env):
+    """QNet.activation_report: on the gen-0 net and on a net with randomised batch-norm the layer inputs stay far inside
+    the range the batch-norm-derived power-of-two scales leave (the kernel clamps beyond 65504 / x_scale)"""
+    torch, se, net = env
+    s = load_golden("states_11x11x4.npz")
+    states = torch.as_tensor(s["raw"][:64], device="cuda")
+    for ws in (net.glorot_uniform_weights((21, 21, 3), blocks=4, seed=0),
+               _randomised_bn(net.glorot_uniform_weights((21, 21, 3), blocks=4, seed=0), 3)):
+        rep = net.QNet(ws, (21, 21, 3)).activation_report(states)
+        assert len(rep) == 8
+        for amax, xs, headroom in rep:
+            assert amax > 0 and headroom >= 64, (amax, xs, headroom)
+
+
 def test_f16s_fused_head_equals_layer_plus_head(env):
     """snk_conv3x3_bn_f16s_head + snk_head_dense_f32 == snk_conv3x3_bn_f16s(relu) + snk_head_f32 (alpha_nnet.py:46-54)"""
     torch, se, _ = env
