@@ -51,6 +51,11 @@ class MPGameRunner:
                                                       _engine=self.engine, _slot=ID) for ID in range(game_cnt)})
         for name in LOG_FIELDS:              # the six log counters the trainer reads (mp_game_runner.py:14-20)
             setattr(self, name, 0)
+        # raw sums and results live on the instance so that run(max_turns=...) can be resumed: the public counters are
+        # always totals / game_cnt (mp_game_runner.py:71-76), never an average of an average
+        self._totals = dict.fromkeys(LOG_FIELDS, 0)
+        self._rewards = [None] * game_cnt
+        self.turns = 0
 
     def run(self, Alice, spawn_tape=None, max_turns=None):
         """mp_game_runner.py:23-77.  ``spawn_tape`` (optional, parity runs): callable turn -> int16[game_cnt]
@@ -60,11 +65,12 @@ class MPGameRunner:
         eng = self.engine
         S = self.snake_cnt
         show = self.game_cnt == 1
-        rewards = [None] * self.game_cnt
-        turn = 0
+        rewards = self._rewards
+        turn = self.turns                      # a resumed run continues the turn count (and the spawn tape)
+        first_turn = turn
         self.env_steps = 0
         while games:
-            if max_turns is not None and turn >= max_turns:
+            if max_turns is not None and turn - first_turn >= max_turns:
                 break
             turn += 1
             self.env_steps += len(games)       # one root Game.tic per live game (mp_game_runner.py:52)
@@ -95,7 +101,7 @@ class MPGameRunner:
             if done_h.any():
                 fin = np.flatnonzero(done_h)
                 for name, v in zip(LOG_FIELDS, eng.sum_counters(slots=slots[fin])):      # mp_game_runner.py:54-60
-                    setattr(self, name, getattr(self, name) + v)
+                    self._totals[name] += v
                 rw = torch.empty((len(fin), S), dtype=torch.int8, device=eng.device)
                 check(eng.L.snk_engine_rewards(eng.h, torch.as_tensor(slots[fin], device=eng.device).data_ptr(), len(fin),
                                                rw.data_ptr(), torch.cuda.current_stream().cuda_stream))
@@ -106,8 +112,8 @@ class MPGameRunner:
             if self.verbose:
                 print(f"Root game turn {turn} finished. Total time spent: {time() - t0}", end="\n\n")
         self.turns = turn
-        for name in LOG_FIELDS:              # per-game averages (mp_game_runner.py:71-76)
-            setattr(self, name, getattr(self, name) / self.game_cnt)
+        for name in LOG_FIELDS:              # per-game averages (mp_game_runner.py:71-76) over the games finished so far
+            setattr(self, name, self._totals[name] / self.game_cnt)
         return rewards
 
 

@@ -8,9 +8,11 @@ One "step" = one root turn of MPGameRunner.run over all live games (mp_game_runn
 MCTS behind every root Game.tic.  value = root env-steps of all ranks / max-over-ranks wall time.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--games G] [--breadth B] [--no-cpu-baseline]
-N > 1: launched by torch.distributed.run, one rank per GPU; games shard across ranks (weak scaling:
-G games per GPU), no collective in the self-play path; the timed region ends with the iteration-end
-exchange (all-gather of this rank's share of 10 240 sampled rows + all-reduce of the log counters).
+N > 1: one rank per GPU, either under torch.distributed.run (RANK / WORLD_SIZE in the environment) or started by
+this script itself (`python bench.py --gpus N` spawns N fresh rank processes before touching the GPU and relays
+rank 0's JSON line).  Games shard across ranks (weak scaling: G games per GPU), no collective in the self-play
+path; the timed region ends with the iteration-end exchange over RCCL (all-gather of this rank's share of 10 240
+sampled rows + all-reduce of the log counters).  With fewer GPUs than ranks the ranks share GPUs and use gloo.
 """
 import argparse
 import json
@@ -119,6 +121,71 @@ def engine_kernel_rooflines(se, n=32768):
     return out
 
 
+def workload_label(board, snakes, blocks, games, breadth, world):
+    """which BASELINE.json config a run is (shape AND size), or 'custom'"""
+    if (board, snakes, blocks) == (11, 4, 4):
+        if (games, breadth) == (4096, 50):
+            return "configs[1]" if world == 1 else f"configs[1] per GPU x{world} (weak scaling)"
+        if (games, breadth) == (8, 25) and world == 1:
+            return "configs[0] (on the GPU)"
+        if (games, breadth) == (32768, 200):
+            return "configs[2]" if world == 1 else f"configs[2] per GPU x{world}"
+        if games * world == 262144:
+            return f"configs[3] ({games} games per GPU x{world}, breadth {breadth})"
+        return "custom (configs[1] shape)"
+    if (board, snakes, blocks) == (19, 8, 10):
+        return "configs[4] shape" + (f" x{world}" if world > 1 else "")
+    return "custom"
+
+
+def launch_ranks(n):
+    """Parent of an N-rank run: one fresh child process per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set
+    (what torch.distributed.run would do), started BEFORE this process makes any HIP call.  Rank 0's stdout (the one
+    JSON line) is relayed; the exit code is the first non-zero child code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    # rank 0's stdout is drained by a thread so that a crashed rank is noticed while the others sit in a collective
+    import threading
+    chunks = []
+    t = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    t.start()
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            for r, p in enumerate(procs):       # the exact children started above, nothing else
+                if codes[r] is None:
+                    p.terminate()
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = p.wait(timeout=30)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[r] = p.wait()
+            break
+        time.sleep(0.2)
+    t.join(timeout=10)
+    sys.stdout.write("".join(chunks))
+    sys.stdout.flush()
+    bad = [c for c in codes if c != 0]
+    if bad:
+        log(f"bench.py: rank exit codes {codes}")
+    return bad[0] if bad else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,14 +203,27 @@ def main():
     ap.add_argument("--no-kernel-rooflines", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process stays off the GPU (nothing above touches it;
+        # torch.cuda.device_count() does not initialise HIP on this image) and starts N fresh rank processes.
+        sys.exit(launch_ranks(args.gpus))
+    # stdout carries exactly one JSON line: anything a library prints there (gloo's "[Gloo] Rank 0 is connected ...",
+    # RCCL banners) is sent to stderr by pointing fd 1 at fd 2 and keeping a private handle on the real stdout
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if args.conv_algo:
         os.environ["SNK_CONV_ALGO"] = args.conv_algo
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:      # checked before any GPU call: a process that has touched the GPU must never be re-launched
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    backend = os.environ.get("SNK_DIST_BACKEND", "nccl")     # "gloo": rehearsal of the N > 1 path on fewer GPUs than ranks
-    dev_index = local_rank % torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()
+    # RCCL needs one GPU per rank; with fewer GPUs than ranks (a 1-GPU box) the ranks share GPUs and talk over gloo
+    backend = os.environ.get("SNK_DIST_BACKEND") or ("nccl" if n_dev >= world else "gloo")
+    dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
@@ -151,7 +231,6 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import snake_engine as se
     from snake_engine import net, dist as sdist
@@ -232,11 +311,11 @@ def main():
                       "f16": "f16 operands, f32 accumulate (outside the 1e-5 parity tolerance)",
                       "f16s": "f32 (tower convolutions: each f32 operand split into f16 hi + lo, 3 f16 MFMAs per product, f32 accumulate)"}.get(algo, "f32"),
             "data": "synthetic",
-            "config": {"workload": f"{'configs[1]' if judged else 'configs[4] shape' if (B, args.snakes, args.blocks) == (19, 8, 10) else 'custom'}: "
+            "config": {"workload": f"{workload_label(B, args.snakes, args.blocks, args.games, args.breadth, world)}: "
                                    f"{B}x{B}, {args.snakes} snakes, {args.blocks}-block net, {args.games} parallel games per GPU, max_MCTS_breadth "
                                    f"{args.breadth} (= {args.breadth // 8 * 8} rollouts), depth 8, health_dec 1, softmax_base 2, "
                                    "training=True, gen-0 Glorot net (seed 0), fp32 Q-net",
-                       "games_per_gpu": args.games, "breadth": args.breadth, "parallelism": f"games sharded x{world}",
+                       "games_per_gpu": args.games, "breadth": args.breadth, "parallelism": f"games sharded x{world}", "dist_backend": backend if world > 1 else None,
                        "net_evals_per_env_step": evals / max(1, gr.env_steps), "sim_steps_per_env_step": sims / max(1, gr.env_steps),
                        "net_evals_per_s_rank0": evals / dt, "sample_rows_gathered": int(Xg.shape[0])},
             "roofline": {"bound": "mfma",
@@ -263,7 +342,7 @@ def main():
             res["engine_kernels"] = engine_kernel_rooflines(se)
         if not args.no_cpu_baseline and world == 1 and judged:          # reported at N = 1 only
             res["cpu_baseline"] = cpu_baseline(weights, args.breadth)
-        print(json.dumps(res), flush=True)
+        print(json.dumps(res), file=json_out, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -94,10 +94,11 @@ def stub_q_from_key(klo):
     return out
 
 
-def stub_q(states, legacy=False):
-    """Deterministic Q(left, straight, right) with the reference's obstacle mask applied."""
+def stub_q(states, legacy=False, which=0):
+    """Deterministic Q(left, straight, right) with the reference's obstacle mask applied.
+    ``which`` = 0 / 1 picks the low / high key word: two different "nets" for the pit runs."""
     k = obs_key(states)
-    q = stub_q_from_key(k[:, 0])
+    q = stub_q_from_key(k[:, which])
     q[obstacle_mask(states, legacy)] = np.float32(-1.0)
     return q
 
@@ -105,10 +106,11 @@ def stub_q(states, legacy=False):
 class StubNet:
     """Object with the ``nnet.v(list_of_states) -> (N,3) float32`` contract (alpha_nnet.py:61-73)."""
 
-    def __init__(self):
+    def __init__(self, which=0):
         self.calls = []
+        self.which = which
 
     def v(self, X):
         arr = np.array(X, dtype=np.float32)
         self.calls.append(len(X))
-        return stub_q(arr)
+        return stub_q(arr, which=self.which)

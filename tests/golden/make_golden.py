@@ -18,6 +18,10 @@ What is recorded:
   mcts_tiny.npz    2-game MCTS self-play with a deterministic stub net and taped
                    uniforms (Agent.make_moves / MCTSAgent.make_moves)
   runner.npz       MPGameRunner.run with a taped-move agent: rewards + counters
+  pit.npz          pit_mp_game_runner.MPGameRunner.run with two stub nets (1v3, 2v2, 3v1):
+                   start boards, spawn tape, moves, winner indices
+  replay.npz       the replay.rep text one-game MPGameRunner.run writes (Game.draw, two
+                   boards per tick) with the start board, moves and spawn tape behind it
 
 Only the RNG *bindings* inside the imported modules are wrapped (utils.game.random /
 choice / sample and utils.agent.choice are plain ``from x import y`` names,
@@ -608,9 +612,133 @@ def record_runner(n_games=6, seed=99, H=11, W=11, S=4, hd=3):
     print(f"[runner] turns={n_turns} rewards={np.array(rewards).tolist()} counters={flat['counters'].tolist()}")
 
 
+# ----------------------------------------------------------------------------- pit runner (winner indices)
+def record_pit(seed=21, H=11, W=11, S=4):
+    """pit_mp_game_runner.MPGameRunner.run(Alice, Bob, Alice_snake_cnt) through the reference's own loop
+    (pit_mp_game_runner.py:14-63) with two deterministic stub nets: start boards, spawn tape, winners."""
+    import utils.pit_mp_game_runner as P
+    import utils.pit_agent as PA
+    flat = {}
+    cases = [("1v3", 1, 3, 24), ("2v2", None, 3, 24), ("3v1", 3, 9, 16), ("2v2_dec1", 2, 1, 6)]
+    for ci, (name, a_cnt, hd, n_games) in enumerate(cases):
+        pyrandom.seed(seed + ci)
+        np.random.seed(seed + ci)
+        runner = P.MPGameRunner(H, W, S, hd, n_games)
+        L = H * W + 2
+        init_states = [snapshot(runner.games[g], L) for g in range(n_games)]
+        spawn_log = {g: [] for g in range(n_games)}
+        moves_log = {g: [] for g in range(n_games)}
+        orig = G.Game.tic
+
+        def tic_log(self, moves, show=False):
+            dense = np.full(S, 255, np.uint8)
+            for s, m in zip(self.snakes, moves):
+                dense[s.id] = m
+            r = orig(self, moves, show)
+            sp = self._last_spawn
+            spawn_log[self.id].append(-1 if sp is None else sp[0] * W + sp[1])
+            moves_log[self.id].append(dense)
+            return r
+        G.Game.tic = tic_log
+        try:
+            alice, bob = PA.Agent(StubNet(0)), PA.Agent(StubNet(1))
+            winners = runner.run(alice, bob, a_cnt)
+        finally:
+            G.Game.tic = orig
+        n_turns = max(len(v) for v in spawn_log.values())
+        spawn = np.full((n_turns, n_games), -2, np.int16)
+        moves = np.full((n_turns, n_games, S), 255, np.uint8)
+        for g in range(n_games):
+            spawn[:len(spawn_log[g]), g] = spawn_log[g]
+            moves[:len(moves_log[g]), g] = moves_log[g]
+        p = f"p{ci}_"
+        flat[p + "meta"] = np.array([H, W, S, hd, n_games, -1 if a_cnt is None else a_cnt], np.int32)
+        flat[p + "winners"] = np.array([-1 if w is None else w for w in winners], np.int8)
+        flat[p + "spawn"] = spawn
+        flat[p + "moves"] = moves
+        flat[p + "lengths"] = np.array([len(spawn_log[g]) for g in range(n_games)], np.int32)
+        for k in init_states[0]:
+            arr = np.stack([s[k] for s in init_states])
+            if k == "nodes":
+                arr = arr[:, :, :4]
+            flat[p + "init_" + k] = arr
+        print(f"[pit {name}] turns={n_turns} winners={flat[p + 'winners'].tolist()}")
+    flat["names"] = np.array([c[0] for c in cases])
+    np.savez_compressed(os.path.join(HERE, "pit.npz"), **flat)
+
+
+# ----------------------------------------------------------------------------- replay.rep text (Game.draw)
+def record_replay(seed=31, H=11, W=11, S=4, hd=9):
+    """MPGameRunner(game_cnt=1).run: show=True, so every tick appends two boards to ./replay.rep
+    (game.py:140-141, 194-195, 281-300).  The file's text is the expected output."""
+    import contextlib
+    import io
+    import tempfile
+    flat = {}
+    for ci, (sd, p_legal) in enumerate([(seed, 0.8), (seed + 1, 0.95)]):
+        pyrandom.seed(sd)
+        np.random.seed(sd)
+        cwd = os.getcwd()
+        with tempfile.TemporaryDirectory() as tmp:
+            os.chdir(tmp)
+            try:
+                runner = R.MPGameRunner(H, W, S, hd, 1)
+                L = H * W + 2
+                init = snapshot(runner.games[0], L)
+                mover = pyrandom.Random(sd + 5)
+                log = []
+
+                class Ag:
+                    def make_moves(self, games, ids):
+                        out = []
+                        for (gid, sid) in ids:
+                            game = games[gid]
+                            snake = [s for s in game.snakes if s.id == sid][0]
+                            lm = legal_moves(game, snake)
+                            out.append(mover.choice(lm) if lm and mover.random() < p_legal else mover.choice((0, 1, 2)))
+                        log.append((list(ids), list(out)))
+                        return out
+                spawns = []
+                orig = G.Game.tic
+
+                def tic_log(self, moves, show=False):
+                    r = orig(self, moves, show)
+                    sp = self._last_spawn
+                    spawns.append(-1 if sp is None else sp[0] * W + sp[1])
+                    return r
+                G.Game.tic = tic_log
+                try:
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        rewards = runner.run(Ag())
+                finally:
+                    G.Game.tic = orig
+                text = open("replay.rep", "rb").read()
+            finally:
+                os.chdir(cwd)
+        n_turns = len(log)
+        moves = np.full((n_turns, 1, S), 255, np.uint8)
+        for t, (ids, mv) in enumerate(log):
+            for (gid, sid), m in zip(ids, mv):
+                moves[t, gid, sid] = m
+        p = f"r{ci}_"
+        flat[p + "meta"] = np.array([H, W, S, hd], np.int32)
+        flat[p + "moves"] = moves
+        flat[p + "spawn"] = np.array(spawns, np.int16).reshape(n_turns, 1)
+        flat[p + "rewards"] = np.array(rewards, np.float32)
+        flat[p + "text"] = np.frombuffer(text, np.uint8)
+        for k in init:
+            arr = init[k][None]
+            if k == "nodes":
+                arr = arr[:, :, :4]
+            flat[p + "init_" + k] = arr
+        print(f"[replay {ci}] turns={n_turns} frames={text.count(bytes([10, 10]))} bytes={len(text)}")
+    flat["n"] = 2
+    np.savez_compressed(os.path.join(HERE, "replay.npz"), **flat)
+
+
 if __name__ == "__main__":
     os.chdir("/tmp")
-    which = set(sys.argv[1:]) or {"tic", "corner", "tables", "mcts", "runner"}
+    which = set(sys.argv[1:]) or {"tic", "corner", "tables", "mcts", "runner", "pit", "replay"}
     if "tic" in which:
         record_trajectories("11x11x4", 11, 11, 4, 1, 40, seed=1, p_legal=0.92, max_ticks=400, raw_every=23)
         record_trajectories("11x11x4_dec9", 11, 11, 4, 9, 10, seed=2, p_legal=0.97, max_ticks=400, raw_every=29)
@@ -625,3 +753,7 @@ if __name__ == "__main__":
         record_mcts_tiny("tiny_greedybase", n_games=3, breadth=8, depth=4, base=10, seed=12, max_turns=8)
     if "runner" in which:
         record_runner()
+    if "pit" in which:
+        record_pit()
+    if "replay" in which:
+        record_replay()

@@ -34,3 +34,29 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     for k in ("step", "clone", "observe"):
         e = d["engine_kernels"][k]
         assert e["bound"] == "hbm" and e["unit"] == "GB/s" and 0 < e["frac"] < 1
+
+
+def test_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the parent spawns two fresh ranks before touching the GPU and
+    relays rank 0's line (RCCL when the box has >= 2 GPUs, otherwise both ranks share GPU 0 and talk over gloo)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--games", "16", "--breadth", "16",
+                          "--steps", "2", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2
+    assert d["config"]["games_per_gpu"] == 16 and d["config"]["parallelism"] == "games sharded x2"
+    assert d["config"]["sample_rows_gathered"] == 10240            # 2 x 5120 rows all-gathered
+    # whole-job value: both ranks' root env-steps (2 turns x 16 games each, nobody dies in two turns) over the slowest rank's time
+    assert abs(d["value"] - 2 * 2 * 16 / (d["ms_per_step"] * 2e-3)) / d["value"] < 0.05
+    assert "cpu_baseline" not in d                                 # rank 0 at N = 1 only
+    assert d["config"]["dist_backend"] in ("nccl", "gloo")
+
+
+def test_bench_refuses_a_world_size_mismatch_before_touching_the_gpu():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--games", "16"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE" in out.stderr
