@@ -167,7 +167,8 @@ class Game:
 
     def tic(self, moves, show=False):
         """game.py:87-205: ``moves`` pairs with the alive snakes in list order. Returns 0 or the rewards list."""
-        alive = np.flatnonzero(self._pull()["alive"])
+        pre = self._pull()
+        alive = np.flatnonzero(pre["alive"])
         dense = np.ones((1, self.snake_cnt), np.uint8)
         dense[0, alive] = np.asarray(moves, np.uint8)[: len(alive)]
         eng = self._engine
@@ -176,8 +177,52 @@ class Game:
         eng.step(torch.as_tensor(dense, device=eng.device), slots=np.array([self._slot], np.int32), done=done)
         self._dirty()
         if show:
-            self.draw()       # the reference draws before and after removal (game.py:140, 194); one frame here
+            self.draw_tick(pre, dense[0])
         return self.rewards if int(done.item()) else 0
+
+    def draw_tick(self, pre, dense_moves):
+        """the two boards Game.tic(show=True) appends (game.py:140-141 before the dead snakes are removed, :194-195
+        after): ``pre`` is the host snapshot taken before the step, ``dense_moves`` the move of every snake id."""
+        self._write_board(self.food, self._moved_snakes(pre, dense_moves))
+        self.draw()
+
+    def _moved_snakes(self, pre, dense_moves):
+        """every snake of the pre-state after the move and eat phases (game.py:90-127), dying ones included: what
+        ``self.snakes`` holds at the first draw.  Rebuilt on the host from the snapshot (one game, show mode only);
+        the food after spawning is the post-state food (removal never touches it)."""
+        food_pre = set(np.flatnonzero(pre["food"]).tolist())
+        out = []
+        for s in np.flatnonzero(pre["alive"]).tolist():
+            L = int(pre["length"][s])
+            nodes = [self._yx(c) for c in pre["nodes"][s, :L]]
+            d = (int(dense_moves[s]) + int(pre["dir"][s]) - 1) % 4           # game.py:92
+            hy, hx = nodes[0]
+            head = (hy + (d == 2) - (d == 0), hx + (d == 1) - (d == 3))
+            body = nodes[:-1]                                                # old head joins the body, tail popped
+            length = L
+            if 0 <= head[0] < self.height and 0 <= head[1] < self.width:
+                c = head[0] * self.width + head[1]
+                if c in food_pre:                                            # first in list order eats (game.py:121-127)
+                    food_pre.discard(c)
+                    length += 1                                              # grow(): duplicate tail, same cells
+            out.append((s, length, head, body))
+        return out
+
+    def _write_board(self, food, snakes):
+        """game.py:281-300 on (id, length, head, body cells) tuples in list order"""
+        board = [[0] * self.width for _ in range(self.height)]
+        for (y, x) in food:
+            board[y][x] = 9
+        for (sid, _, (hy, hx), _) in sorted(snakes, key=lambda t: t[1]):
+            if 0 <= hy < self.height and 0 <= hx < self.width:
+                board[hy][hx] = -(sid + 1)
+        for (sid, _, _, body) in snakes:
+            for (y, x) in body:
+                board[y][x] = sid + 1
+        with open("replay.rep", "a") as f:
+            for row in board:
+                f.write(str(row) + "\n")
+            f.write("\n")
 
     def subgame(self, subgame_id):
         """game.py:266-276: deep copy that never spawns food, fresh counters, copied rewards"""
@@ -187,18 +232,4 @@ class Game:
 
     def draw(self):
         """game.py:281-300: append the board to replay.rep in the text format player.py reads"""
-        board = [[0] * self.width for _ in range(self.height)]
-        for (y, x) in self.food:
-            board[y][x] = 9
-        snakes = self.snakes
-        for s in sorted(snakes, key=lambda s: s.length):
-            hy, hx = s.head.position
-            if 0 <= hy < self.height and 0 <= hx < self.width:
-                board[hy][hx] = -(s.id + 1)
-        for s in snakes:
-            for (y, x) in s:
-                board[y][x] = s.id + 1
-        with open("replay.rep", "a") as f:
-            for row in board:
-                f.write(str(row) + "\n")
-            f.write("\n")
+        self._write_board(self.food, [(s.id, s.length, s.head.position, list(s)) for s in self.snakes])

@@ -59,11 +59,12 @@ class MPGameRunner:
             tape = None
             if spawn_tape is not None:
                 tape = torch.as_tensor(np.ascontiguousarray(spawn_tape(turn)[slots], np.int16), device=eng.device)
+            pre = games[gids[0]]._pull() if show else None
             eng.step(torch.as_tensor(dense, device=eng.device), slots=d_slots, spawn_tape=tape, done=done)
             for g in games.values():
                 g._dirty()
-            if show:
-                games[gids[0]].draw()
+            if show:                         # both boards of game.py:140-141, 194-195
+                games[gids[0]].draw_tick(pre, dense[0])
             done_h = done.cpu().numpy().astype(bool)
             rw = torch.empty((len(gids), S), dtype=torch.int8, device=eng.device)
             check(eng.L.snk_engine_rewards(eng.h, d_slots.data_ptr(), len(gids), rw.data_ptr(),

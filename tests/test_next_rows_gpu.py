@@ -18,33 +18,102 @@ class TableNet:
         return stub_q(np.array(X, np.float32))
 
 
-def test_pit_runner_matches_the_oracle_with_taped_spawns(oracle):
-    """pit_mp_game_runner.MPGameRunner.run(Alice, Bob): greedy moves from nnet.v, team elimination early exit.
-    The same games are replayed on the CPU oracle (same stub net, the device's own food spawns as a tape)."""
-    import random
-    import torch
+KEYS = ("alive", "health", "length", "dir", "nodes", "food", "rewards", "counters")
+
+
+def _import_golden_boards(runner, z, p, H, W, S, n):
+    from snake_engine.engine import state_from_compact
+    runner.engine.import_states([state_from_compact(H, W, S, {k: z[p + "init_" + k][g] for k in KEYS}) for g in range(n)])
+    for g in runner.games.values():
+        g._dirty()
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2, 3])
+def test_pit_winners_match_the_reference_bit_exact(ci):
+    """pit_mp_game_runner.MPGameRunner.run(Alice, Bob, Alice_snake_cnt) on the HIP engine: the reference's start boards
+    and food-spawn tape in, the reference's winner indices out (1v3, 2v2 by default split, 3v1, 2v2 with health_dec 1);
+    the agents are the product's pit agents around the two stub nets the reference run used."""
+    from oracle.obs_key import StubNet
     from utils.pit_agent import Agent
     from utils.pit_mp_game_runner import MPGameRunner
-    from snake_engine.engine import compact_from_state
+    z = load_golden("pit.npz")
+    p = f"p{ci}_"
+    H, W, S, hd, n, a_cnt = (int(v) for v in z[p + "meta"])
+    gr = MPGameRunner(H, W, S, hd, n, seed=1)
+    _import_golden_boards(gr, z, p, H, W, S, n)
+    winners = gr.run(Agent(StubNet(0)), Agent(StubNet(1)), None if a_cnt < 0 else a_cnt,
+                     spawn_tape=lambda turn: z[p + "spawn"][turn - 1])
+    assert [-1 if w is None else w for w in winners] == z[p + "winners"].tolist()
+    assert len(gr.games) == 0
+
+
+def test_pit_agent_device_path_equals_host_path(oracle):
+    """pit_agent.Agent.make_moves on a device tensor of planes (the engine-backed runner's form) and on the reference's
+    list of arrays give the same greedy moves"""
+    import torch
+    from utils.pit_agent import Agent
     from oracle.mcts_oracle import argmaxs
-    random.seed(5); np.random.seed(5)
-    n = 12
-    gr = MPGameRunner(11, 11, 4, 3, n, seed=9)
-    start = gr.engine.export()
-    games = [oracle.Game.from_compact(11, 11, 4, 3, 0.15, compact_from_state(start[g])) for g in range(n)]
+    z = load_golden("pit.npz")
     net = TableNet()
-    # record the device's spawn decisions by stepping a shadow engine? simpler: replay afterwards from final states:
-    winners = gr.run(Agent(net), Agent(net), 2)
-    assert len(winners) == n and len(gr.games) == 0
-    assert all(w is None or 0 <= w < 4 for w in winners)
-    # oracle replay with its own RNG cannot reproduce device spawns; check the decision rule instead on fresh states
-    for g in games[:4]:
-        sts = g.get_states()
+    for g in range(4):
+        game = oracle.Game.from_compact(11, 11, 4, 3, 0.15, {k: z["p0_init_" + k][g] for k in KEYS})
+        sts = game.get_states()
         V = net.v(sts)
-        ag = Agent(net)
-        assert ag.make_moves(sts) == argmaxs(V)
-        planes = torch.as_tensor(np.array(sts), device="cuda")
-        assert Agent(net).make_moves(planes) == argmaxs(V)
+        assert Agent(net).make_moves(sts) == argmaxs(V)
+        assert Agent(net).make_moves(torch.as_tensor(np.array(sts), device="cuda")) == argmaxs(V)
+
+
+@pytest.mark.parametrize("ci", [0, 1])
+def test_replay_rep_matches_the_reference_text(ci, tmp_path, monkeypatch):
+    """MPGameRunner(game_cnt=1).run shows the game: two boards per tick appended to ./replay.rep (game.py:140-141,
+    194-195, 281-300); same start board, moves and spawn tape as the reference run -> the same bytes"""
+    from utils.mp_game_runner import MPGameRunner
+    z = load_golden("replay.npz")
+    p = f"r{ci}_"
+    H, W, S, hd = (int(v) for v in z[p + "meta"])
+    monkeypatch.chdir(tmp_path)
+    MPGameRunner.verbose = False
+    gr = MPGameRunner(H, W, S, hd, 1, seed=1)
+    _import_golden_boards(gr, z, p, H, W, S, 1)
+
+    class Taped:
+        t = 0
+
+        def make_moves(self, games, ids):
+            out = [int(z[p + "moves"][self.t][gid][sid]) for gid, sid in ids]
+            self.t += 1
+            return out
+    rewards = gr.run(Taped(), spawn_tape=lambda turn: z[p + "spawn"][turn - 1])
+    assert np.array_equal(np.array(rewards, np.float32), z[p + "rewards"])
+    assert open("replay.rep", "rb").read() == z[p + "text"].tobytes()
+
+
+def test_run_resumed_in_pieces_equals_one_run():
+    """run(max_turns=k) resumed until the games are over: same rewards and per-game averages as one uninterrupted run
+    (the counters are totals / game_cnt, never an average of an average)"""
+    from utils.mp_game_runner import MPGameRunner
+    z = load_golden("runner.npz")
+    H, W, S, hd, n = int(z["H"]), int(z["W"]), int(z["S"]), int(z["hd"]), int(z["n_games"])
+    MPGameRunner.verbose = False
+
+    class Taped:
+        t = 0
+
+        def make_moves(self, games, ids):
+            out = [int(z["moves"][self.t][gid][sid]) for gid, sid in ids]
+            self.t += 1
+            return out
+    gr = MPGameRunner(H, W, S, hd, n, seed=1)
+    _import_golden_boards(gr, z, "", H, W, S, n)
+    agent = Taped()
+    steps = 0
+    while gr.games:
+        rewards = gr.run(agent, spawn_tape=lambda turn: z["spawn"][turn - 1], max_turns=3)
+        steps += gr.env_steps
+    assert np.array_equal(np.array(rewards, np.float32), z["rewards"])
+    got = [gr.wall_collision, gr.body_collision, gr.head_collision, gr.starvation, gr.food_eaten, gr.game_length]
+    assert got == z["counters"].tolist()
+    assert steps == int(z["game_lengths"].sum()) and gr.turns == len(z["moves"])
 
 
 def test_trainer_flow_train_copy_save_load(tmp_path, monkeypatch):
