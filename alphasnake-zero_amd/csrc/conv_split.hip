@@ -7,7 +7,8 @@
 // 5.3x the f32 MFMA rate, 2.6x the Winograd kernel's arithmetic rate, at the same |dQ| (about 3e-7 for the whole
 // net, tests/test_net_gpu.py).  Weights are pre-scaled by a power of two so that their lo parts are normal f16
 // numbers; the inverse goes into the batch-norm scale (exact).  Activations are multiplied by a caller-chosen power
-// of two on the way into LDS (so that their lo parts are normal numbers too) and clamped to +-65504 after it.
+// of two on the way into LDS (so that their lo parts are normal numbers too) and clamped to +-65504 after it; a clamp
+// sets the layer's range flag (a word behind the scales in the weight image) so that the host can refuse the result.
 //
 // GEMM rows are the image's pixels in row-major order, 32 per M tile (14 tiles at 21x21, 7 junk rows).  One block =
 // up to 8 consecutive M tiles of one image (7 + 7 at 21x21) x all 128 outputs, 4 wavefronts, at most 128 accumulator
@@ -48,7 +49,8 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 struct ConvHsArgs {
     const float *x;            // [n][Hd][Wd][128]
     const f16x8 *wS;           // [chunk 8][tap 9][wn 4][hi/lo][lane 64] x 8 f16
-    const float *wscale_inv;   // tail of the weight image: {2^-k (weights), 2^k, activation scale s (a power of two), 1 / s}
+    const float *wscale_inv;   // tail of the weight image: {2^-k (weights), 2^k, activation scale s (a power of two), 1 / s,
+                               //   int32 range flag (set by the kernel when an input was clamped), 3 words of padding}
     const float *scale, *shift;
     const float *res;          // or NULL
     float *out;                // or NULL when only the fused 1x1 head output is wanted
@@ -123,6 +125,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
     float4 st[HS_NST];
     f16x4 hi_t;
     float4 d_t;
+    float amax = 0.f;                                      // largest |scaled input| this thread staged: 65504 = something was clamped
 #define HS_LOAD(c) _Pragma("unroll") for (int k_ = 0; k_ < HS_NST; ++k_) st[k_] = *(const float4 *)(xrow + gof[k_] + HS_KC * (c));
 // split of one staged float4 in two halves that sit in different MFMA regions (a region hides about 15 VALU instructions):
 //   A: clamp to the f16 range, hi = f16(v), d = v - hi;   B: lo = f16(d), both written to LDS
@@ -132,6 +135,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
         v_.x *= xs; v_.y *= xs; v_.z *= xs; v_.w *= xs;                                         \
         v_.x = __builtin_amdgcn_fmed3f(v_.x, -65504.f, 65504.f); v_.y = __builtin_amdgcn_fmed3f(v_.y, -65504.f, 65504.f); \
         v_.z = __builtin_amdgcn_fmed3f(v_.z, -65504.f, 65504.f); v_.w = __builtin_amdgcn_fmed3f(v_.w, -65504.f, 65504.f); \
+        amax = fmaxf(fmaxf(amax, fabsf(v_.x)), fabsf(v_.y)); amax = fmaxf(fmaxf(amax, fabsf(v_.z)), fabsf(v_.w)); /* 2 v_max3 */ \
         hi_t[0] = (_Float16)v_.x; hi_t[1] = (_Float16)v_.y; hi_t[2] = (_Float16)v_.z; hi_t[3] = (_Float16)v_.w; \
         if (SPLIT) {                                                                            \
             d_t.x = v_.x - (float)hi_t[0]; d_t.y = v_.y - (float)hi_t[1];                       \
@@ -236,6 +240,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
     HS_STAMP(2)
     HS_CHUNK(false)                    // the last chunk stages nothing
     HS_STAMP(3)
+    // range guard: an input beyond the f16 range after scaling was clamped, the layer's result is then NOT float32-accurate.
+    // The flag word sits behind the scales in the weight image (one per layer); the host reads it (QNet.check_range).
+    if (amax >= 65504.f) atomicOr((int *)const_cast<float *>(p.wscale_inv) + 4, 1);
     HS_STAMP_REAL(6)
 #undef HS_TAP
 #undef HS_CHUNK
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
     HS_STAMP(4)
 }
 
-// max |w| of the layer -> k with 256 <= max * 2^k < 512; writes {2^-k, 2^k, x_scale, 1 / x_scale} behind the fragment image
+// max |w| of the layer -> k with 256 <= max * 2^k < 512; writes {2^-k, 2^k, x_scale, 1 / x_scale, range flag = 0} behind the fragment image
 __global__ __launch_bounds__(1024) void k_f16s_wscale(const float *__restrict__ w, float *__restrict__ tail, float x_scale)
 {
     __shared__ float red[1024];
@@ -338,6 +345,7 @@ __global__ __launch_bounds__(1024) void k_f16s_wscale(const float *__restrict__ 
         tail[1] = ldexpf(1.0f, k);
         tail[2] = x_scale;
         tail[3] = 1.0f / x_scale;
+        tail[4] = tail[5] = tail[6] = tail[7] = 0.f;          // range flag (an int32, bit pattern 0) + padding
     }
 }
 

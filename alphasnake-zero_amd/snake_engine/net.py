@@ -16,7 +16,9 @@ from ._lib import lib, check, EngineError
 
 BN_EPS = 1e-3        # Keras BatchNormalization default epsilon (alpha_nnet.py:22)
 K_FILTERS = 128      # alpha_nnet.py:17
-F16S_WEIGHT_BYTES = 9 * 128 * 128 * 4 + 16     # SNK_CONV_F16S_WEIGHT_BYTES (include/snake_engine.h)
+F16S_WEIGHT_BYTES = 9 * 128 * 128 * 4 + 32     # SNK_CONV_F16S_WEIGHT_BYTES (include/snake_engine.h)
+F16S_TAIL_OFFSET = 9 * 128 * 128 * 4           # float32 {2^-k, 2^k, x_scale, 1/x_scale}, int32 range flag, padding
+F16S_FLAG_OFFSET = F16S_TAIL_OFFSET + 16
 
 
 def glorot_uniform_weights(input_shape, blocks=4, seed=0):
@@ -128,10 +130,71 @@ class QNet:
         self.head_s, self.head_b = float(hs.item()), float(hb.item())
         self.fc1_w, self.fc1_b = t[base + 5].contiguous(), t[base + 6].contiguous()
         self.fc2_w, self.fc2_b = t[base + 7].contiguous(), t[base + 8].contiguous()
+        self.calibrated = False                 # new weights: the next caller with observations at hand calibrates
         torch.cuda.current_stream().synchronize()
 
     def get_weights(self):
         return [w.copy() for w in self.weights]
+
+    # ---- range guard of the split-f16 kernel -------------------------------------------------------
+    def _tail(self, i, dtype):
+        return self.conv_wT[i][F16S_TAIL_OFFSET:F16S_TAIL_OFFSET + 32].view(dtype)
+
+    def set_x_scale(self, i, scale):
+        """activation scale of tower layer i (a power of two); only the weight image's tail changes"""
+        m, _ = math.frexp(scale)
+        assert scale > 0 and m == 0.5, f"x_scale {scale} is not a power of two"
+        self.conv_x_scale[i] = float(scale)
+        t = self._tail(i, torch.float32)
+        t[2] = float(scale)
+        t[3] = 1.0 / float(scale)
+
+    def range_flags(self, clear=True):
+        """per tower layer: 1 when a launch since the last call clamped an input (one small device-to-host copy)"""
+        if self.conv_algo not in ("f16s", "f16") or not self.conv_wT:
+            return []
+        flags = torch.stack([self._tail(i, torch.int32)[4] for i in range(len(self.conv_wT))])
+        out = flags.cpu().tolist()
+        if clear and any(out):
+            for i, f in enumerate(out):
+                if f:
+                    self._tail(i, torch.int32)[4] = 0
+        return out
+
+    def widen(self, layers, factor=2.0 ** -6):
+        for i in layers:
+            self.set_x_scale(i, self.conv_x_scale[i] * factor)
+
+    def check_range(self, on_overflow="raise"):
+        """Reads the range flags.  Returns the list of layers that clamped (empty = every result since the last check is
+        float32-accurate).  Those layers' scales are lowered by 2^6 either way, so a repeated evaluation fits;
+        on_overflow="raise" then raises (the results computed in between are not within the 1e-5 contract),
+        "widen" leaves the decision to the caller (AlphaNNet.v re-evaluates the batch)."""
+        bad = [i for i, f in enumerate(self.range_flags()) if f]
+        if bad:
+            self.widen(bad)
+            if on_overflow == "raise":
+                raise EngineError(
+                    f"split-f16 convolution: inputs of tower layer(s) {bad} exceeded the f16 range after scaling and were "
+                    "clamped, so Q values computed since the last check are not float32-accurate.  The layers' activation "
+                    "scales have been lowered (x 2^-6): evaluate again, call QNet.calibrate(observations) after loading "
+                    "weights, or use SNK_CONV_ALGO=winograd (no range limit).")
+        return bad
+
+    def calibrate(self, planes, target_log2=9):
+        """Measures every tower layer's largest |input| on the given observations and lowers the activation scales the
+        batch-norm heuristic chose (activation_scales) wherever the measured maximum would come within 2^4 of the f16
+        limit: a net whose moving statistics do not describe its activations (freshly trained, loaded from a checkpoint)
+        gets scales from data instead.  Returns the activation report."""
+        if self.conv_algo not in ("f16s", "f16"):
+            return []
+        rep = self.activation_report(planes)
+        for i, (amax, scale, _) in enumerate(rep):
+            if amax * scale > 2.0 ** 12:
+                self.set_x_scale(i, 2.0 ** (target_log2 - math.ceil(math.log2(amax))))
+        self.range_flags()                      # the measuring pass itself may have tripped them
+        self.calibrated = True
+        return rep
 
     # ---- forward -------------------------------------------------------------------------------
     def _workspace(self, n, k=0):

@@ -158,7 +158,15 @@ class Agent:
         slots = np.fromiter((g._slot for g in games.values()), np.int32, len(games))
         d_slots = torch.as_tensor(slots, device=eng.device)
         alive = eng.alive(slots=d_slots)
+        if hasattr(self.nnet, "calibrate") and not getattr(getattr(self.nnet, "_qnet", None), "calibrated", True):
+            # new weights: fit the split-f16 kernel's activation scales to real observations (the root states) once
+            pairs = torch.nonzero(alive)[:4096].to(torch.int32)
+            pairs[:, 0] = d_slots[pairs[:, 0].long()]
+            planes, _, _ = eng.observe_all(pairs.contiguous(), want_mask=False, want_key=False)
+            self.nnet.calibrate(planes)
         V, moves = self._mcts.search(eng, d_slots, alive)
+        if hasattr(self.nnet, "check_range"):
+            self.nnet.check_range()           # raises if a convolution clamped its input during this root turn
         alive_h = alive.cpu().numpy().astype(bool)
         if self.training:
             self._record(eng, d_slots, alive_h, V)

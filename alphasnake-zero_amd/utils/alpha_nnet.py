@@ -66,7 +66,21 @@ class AlphaNNet:
     def v(self, X):
         """alpha_nnet.py:61-73: list/array of (h, w, 3) float32 observations -> (N, 3) float32"""
         planes = torch.as_tensor(np.ascontiguousarray(np.array(X, dtype=np.float32)), device=self._qnet.device)
-        return self.v_device(planes).cpu().numpy()
+        for _ in range(4):
+            V = self.v_device(planes).cpu().numpy()
+            if not self._qnet.check_range(on_overflow="widen"):       # nothing was clamped: float32-accurate
+                return V
+        raise RuntimeError("AlphaNNet.v: activations exceed the split-f16 kernel's range even after widening; "
+                           "use SNK_CONV_ALGO=winograd")
+
+    def check_range(self):
+        """range guard of the split-f16 convolutions for device-side callers (Agent.make_moves calls it once per root
+        turn): raises when any evaluation since the last check was clamped"""
+        self._qnet.check_range(on_overflow="raise")
+
+    def calibrate(self, planes):
+        if not self._qnet.calibrated:
+            self._qnet.calibrate(planes)
 
     def is_obstacle(self, value):
         return value >= 0.04

@@ -33,36 +33,53 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(weights, breadth, budget_s=25.0):
-    """the oracle's restatement of the same loop (oracle/mcts_oracle.py over oracle/snake_oracle.c), PyTorch-CPU
-    fp32 net with identical weights, on this box's host cores: a bounded sample of the same workload"""
-    from oracle import snake_oracle as so, net_ref
-    from oracle.mcts_oracle import SelfPlayOracle, Draws
-    import random
+def usable_cpus():
+    """host cpus this process may really use: the scheduler affinity capped by the cgroup cpu quota (the GPU boxes show
+    256 cpus but grant 16: 128 PyTorch threads on a 16-cpu quota is why round 1's baseline was not reproducible)"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
-    class CpuNet:
-        def v(self, X):
-            return net_ref.forward(weights, np.array(X, np.float32))
-    rnd = random.Random(0)
-    n_games = 2
-    games = []
-    for g in range(n_games):
-        pos = rnd.sample(range(8), 4)
-        games.append(so.Game.new(11, 11, 4, 1, 0.15, pos, [rnd.randrange(4) for _ in range(4)], [rnd.randrange(4) for _ in range(4)]))
-    sp = SelfPlayOracle(CpuNet(), 2, True, 8, breadth, Draws(seed=1))
+
+def cpu_baseline(weights, breadth, n_games=16, n_turns=2):
+    """The same workload on this box's host cores, as a FIXED amount of work: oracle/mcts_cpu.c (the C restatement of
+    MPGameRunner.run + Agent/MCTSAgent.make_moves over oracle/snake_oracle.c, pinned to the reference's recorded runs by
+    tests/test_mcts_cpu_baseline.py) with the PyTorch-CPU fp32 net (oracle/net_ref.py, identical weights), n_games
+    seeded start boards x n_turns root turns, one net batch per rollout tick (n_games x 8 sub-games x <= 4 snakes rows).
+    Also timed: the engine + MCTS alone (stub net inside the C code) on 1 and on all usable threads."""
+    from oracle import net_ref
+    from oracle.mcts_cpu import CpuSelfPlay, seeded_games
+    cpus = usable_cpus()
+    torch.set_num_threads(cpus)
+    net_ref.forward(weights, np.zeros((64, 21, 21, 3), np.float32))        # thread pool / oneDNN primitives warm
+    sp = CpuSelfPlay(seeded_games(n_games, seed=1), net=lambda X: net_ref.forward(weights, X), threads=min(cpus, n_games),
+                     base=2, training=True, max_depth=8, max_breadth=breadth, seed=1)
     t0 = time.time()
-    steps = 0
-    turns = 0
-    while time.time() - t0 < budget_s and turns < 8:
-        _, s = sp.run(games, max_turns=1, rng=np.random.RandomState(turns))
-        steps += s
-        turns += 1
-        games = [g for g in games if sum(g.g.alive[:4]) > 1] or games
+    st = sp.run(max_turns=n_turns)
     dt = time.time() - t0
-    return {"value": steps / dt, "unit": "env-steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_games} games x {turns} root turns, breadth {breadth} ({sp.net_evals} net evals, "
-                      f"{sp.sim_steps} rollout tics) in {dt:.1f} s; oracle/mcts_oracle.py + PyTorch-CPU fp32 net, "
-                      f"{torch.get_num_threads()} threads of {os.cpu_count()} host cpus"}
+    sp.close()
+    eng = {}
+    for thr in sorted({1, cpus}):
+        e = CpuSelfPlay(seeded_games(64 * thr, seed=2), net=None, threads=thr, base=2, training=True, max_depth=8,
+                        max_breadth=breadth, seed=2)
+        t1 = time.time()
+        es = e.run(max_turns=2)
+        eng[thr] = es["env_steps"] / (time.time() - t1)
+        e.close()
+    return {"value": st["env_steps"] / dt, "unit": "env-steps/s", "cores": cpus, "kind": "port",
+            "sample": f"fixed work: {n_games} seeded games x {n_turns} root turns, breadth {breadth} = {st['env_steps']} env-steps, "
+                      f"{st['net_evals']} net evals, {st['sim_steps']} rollout tics in {dt:.1f} s; oracle/mcts_cpu.c on "
+                      f"{min(cpus, n_games)} threads + PyTorch-CPU fp32 net on {cpus} threads "
+                      f"(os.cpu_count() = {os.cpu_count()}, usable = {cpus})",
+            "net_evals_per_s": st["net_evals"] / dt,
+            "engine_only_env_steps_per_s": {f"{k}_threads": v for k, v in eng.items()},
+            "engine_only_note": "stub net inside the C code (zero net cost), 64 games per thread x 2 root turns: what the "
+                                "reference's Python loop does at 6.5 env-steps/s per core with a stub net (BASELINE.md)"}
 
 
 def engine_kernel_rooflines(se, n=32768):

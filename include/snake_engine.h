@@ -171,14 +171,20 @@ int snk_conv3x3_bn_f32_winograd(const float *d_x, const float *d_U, const float 
                                 int height, int width, int relu, void *stream);
 /* The same layer at float32 accuracy on the f16 matrix pipe: every float32 operand is carried as hi + lo f16 numbers
  * and a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with float32 accumulation (|dQ| of the whole
- * net vs float64 stays ~3e-7, the level of the f32 kernels; activations beyond +-65504 are clamped).
+ * net vs float64 stays ~3e-7, the level of the f32 kernels).  Scaled activations beyond +-65504 are clamped AND
+ * reported: the kernel sets the layer's range flag, the int32 at byte offset SNK_CONV_F16S_FLAG_OFFSET of d_wS (the
+ * only word of the weight image a convolution launch writes); a caller that wants float32 accuracy must read it and
+ * discard the result when it is non-zero (the net wrapper lowers x_scale and re-evaluates, or raises).
  * snk_conv3x3_prepare_weights_f16s: Keras kernel (3,3,128,128) -> the split weights in MFMA fragment order;
- *   d_wS: SNK_CONV_F16S_WEIGHT_BYTES bytes (9*128*128 hi/lo pairs + the power-of-two scales).
+ *   d_wS: SNK_CONV_F16S_WEIGHT_BYTES bytes (9*128*128 hi/lo pairs, then the tail: float 2^-k, 2^k, x_scale,
+ *   1/x_scale, int32 range flag (cleared here), 12 bytes of padding).
  *   x_scale: a power of two the layer's INPUT activations are multiplied by before the split (undone exactly in
  *   the epilogue); choose it so that the largest |activation| * x_scale stays well below 65504 (1.0f is always
  *   valid; the net wrapper derives it from the producing layer's batch-norm parameters).
  * 3 <= width <= 80. */
-#define SNK_CONV_F16S_WEIGHT_BYTES (9 * 128 * 128 * 4 + 16)
+#define SNK_CONV_F16S_WEIGHT_BYTES (9 * 128 * 128 * 4 + 32)
+#define SNK_CONV_F16S_TAIL_OFFSET (9 * 128 * 128 * 4)
+#define SNK_CONV_F16S_FLAG_OFFSET (9 * 128 * 128 * 4 + 16)
 int snk_conv3x3_prepare_weights_f16s(const float *d_w_hwio, void *d_wS, float x_scale, void *stream);
 int snk_conv3x3_bn_f16s(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
                         const float *d_residual, float *d_out, int n_images, int height, int width, int relu,

@@ -353,3 +353,95 @@ def test_bf16_conv_layer_and_net(env, monkeypatch):
     ref32 = net_ref.forward(ws, states)
     assert np.abs(got - ref16).max() <= 1e-3, np.abs(got - ref16).max()
     assert np.abs(got - ref32).max() <= 5e-2, np.abs(got - ref32).max()
+
+
+# ---- range guard of the split-f16 kernel ------------------------------------------------------------------------------
+def _adversarial_bn(net_mod):
+    """a net whose batch-norm parameters hide a huge activation from the |beta| + 8 |gamma| heuristic: the moving mean
+    of the second-to-last tower layer is -3 000 (its output is ~3 000, the heuristic expects <= 8, so the last layer's
+    input scale is 64 and 3 000 x 64 > 65 504), the last layer's gamma is 1e-3 so that Q stays away from tanh saturation"""
+    ws = net_mod.glorot_uniform_weights((21, 21, 3), blocks=4, seed=0)
+    k6, k7 = 5 + 5 * 6, 5 + 5 * 7                      # tower layers 6 and 7: kernel index; BN arrays follow
+    ws[k6 + 3] = np.full(128, -3000.0, np.float32)     # moving_mean
+    ws[k7 + 1] = np.full(128, 1e-3, np.float32)        # gamma
+    return ws
+
+
+def test_f16s_range_flag_trips_on_adversarial_batch_norm(env, monkeypatch):
+    """clamped inputs are reported, not returned: QNet.forward sets the layer's range flag and check_range raises;
+    AlphaNNet.v (the host path) widens the layer's scale, re-evaluates and returns float32-accurate values"""
+    torch, se, net = env
+    monkeypatch.setenv("SNK_CONV_ALGO", "f16s")
+    from oracle import net_ref
+    from snake_engine import EngineError
+    from utils.alpha_nnet import AlphaNNet
+    s = load_golden("states_11x11x4.npz")
+    states = s["raw"][:48]
+    ws = _adversarial_bn(net)
+    ref = net_ref.forward(ws, states)
+    assert len(np.unique(np.round(ref, 3))) > 10, "adversarial net saturates: the case says nothing"
+    qn = net.QNet(ws, (21, 21, 3))
+    scale7 = qn.conv_x_scale[7]
+    planes = torch.as_tensor(states, device="cuda")
+    clamped = qn.forward(planes).cpu().numpy()
+    assert np.abs(clamped - net_ref.forward(ws, states, apply_mask=False)).max() > 1e-3      # the clamp really bites ...
+    assert qn.range_flags(clear=False) == [0, 0, 0, 0, 0, 0, 0, 1]                           # ... and layer 7 says so
+    with pytest.raises(EngineError, match="clamped"):
+        qn.check_range()
+    assert qn.conv_x_scale[7] == scale7 / 64 and qn.range_flags() == [0] * 8                  # widened, flags cleared
+    got = qn.forward(planes).cpu().numpy()
+    assert qn.check_range() == []
+    assert np.abs(got - net_ref.forward(ws, states, apply_mask=False)).max() <= TOL_Q
+    nn_ = AlphaNNet(input_shape=(21, 21, 3), _weights=ws)                                     # fresh scales: v() recovers by itself
+    assert np.abs(nn_.v(list(states)) - ref).max() <= TOL_Q
+    assert nn_._qnet.range_flags() == [0] * 8
+    # calibrate() gets there without tripping anything
+    qn2 = net.QNet(ws, (21, 21, 3))
+    rep = qn2.calibrate(planes)
+    assert rep[7][2] < 1.0 and qn2.conv_x_scale[7] < scale7 and qn2.calibrated
+    assert np.abs(qn2.forward(planes).cpu().numpy() - net_ref.forward(ws, states, apply_mask=False)).max() <= TOL_Q
+    assert qn2.check_range() == []
+
+
+def test_f16s_stays_exact_on_weights_that_went_through_fit(env, monkeypatch):
+    """~30 optimizer steps of trainer_torch.fit on self-play samples move the batch-norm statistics away from the Keras
+    defaults; the split-f16 net with its heuristic scales still matches the float32 CPU restatement to 1e-5 on fresh
+    observations and no range flag trips"""
+    torch, se, net = env
+    monkeypatch.setenv("SNK_CONV_ALGO", "f16s")
+    from oracle import net_ref
+    from utils import trainer_torch
+    s = load_golden("states_11x11x4.npz")
+    X = s["raw"][:256]
+    rng = np.random.RandomState(5)
+    Y = np.tanh(rng.randn(256, 3)).astype(np.float32)
+    ws0 = net.glorot_uniform_weights((21, 21, 3), blocks=4, seed=2)
+    boundaries, values = [20, 40, 60, 80, 100], [1e-3 * 0.25 ** i for i in range(5)] + [0.0]
+    ws = trainer_torch.fit(ws0, (21, 21, 3), X, Y, epochs=8, batch_size=64, lr_schedule=(boundaries, values), seed=1, verbose=False)
+    moved = max(float(np.abs(a - b).max()) for a, b in zip(ws, ws0))
+    assert moved > 1e-3
+    fresh = s["raw"][256:320]
+    ref = net_ref.forward(ws, fresh, apply_mask=False)
+    qn = net.QNet(ws, (21, 21, 3))
+    got = qn.forward(torch.as_tensor(fresh, device="cuda")).cpu().numpy()
+    assert qn.check_range() == []
+    assert np.abs(got - ref).max() <= TOL_Q, np.abs(got - ref).max()
+    rep = qn.activation_report(torch.as_tensor(fresh, device="cuda"))
+    assert min(h for _, _, h in rep) > 8.0, rep          # at least 8x headroom to the f16 limit on every layer
+
+
+def test_agent_calibrates_new_weights_and_checks_the_range_every_turn(env, monkeypatch):
+    """Agent.make_moves: first search after set_weights fits the scales to the root observations; a net that would
+    clamp (adversarial batch-norm) therefore self-plays without tripping the guard"""
+    torch, se, net = env
+    monkeypatch.setenv("SNK_CONV_ALGO", "f16s")
+    from utils.agent import Agent
+    from utils.alpha_nnet import AlphaNNet
+    from utils.mp_game_runner import MPGameRunner
+    MPGameRunner.verbose = False
+    nn_ = AlphaNNet(input_shape=(21, 21, 3), _weights=_adversarial_bn(net))
+    assert not nn_._qnet.calibrated
+    alice = Agent(nn_, 2, True, 4, 8, seed=3)
+    gr = MPGameRunner(11, 11, 4, 1, 8, seed=5)
+    gr.run(alice, max_turns=2)
+    assert nn_._qnet.calibrated and nn_._qnet.range_flags() == [0] * 8 and gr.env_steps == 16
