@@ -2,18 +2,32 @@
 SURVEY.md section 8 row f-1 ("next").  Plain PyTorch (autograd, MIOpen convolutions on the GPU): this is the
 caller-side fit step that consumes the self-play samples, not part of the HIP hot path.
 
-Keras semantics restated: loss = mean squared error + 1e-5 * sum(kernel^2) over every Conv2D/Dense kernel
-(kernel_regularizer=l2(c), alpha_nnet.py:15,21...); Adam(beta 0.9/0.999, epsilon 1e-7) with
-PiecewiseConstantDecay([20,40,60,80,100], [lr, lr/4, lr/16, lr/64, lr/256, 0.0]) on the optimizer step
-(alpha_nnet.py:79-84: the rate is 0 after step 100); BatchNormalization in training mode (batch statistics,
-moving averages with momentum 0.99 of the biased batch variance, epsilon 1e-3); `fit` shuffles every epoch.
-With torch.distributed initialised the gradients are averaged across ranks (RCCL all-reduce) each step.
+Keras 2.x / TF 2.1 semantics restated (the formulas, not the code; cross-checked against an independent float64 NumPy
+restatement, oracle/train_ref.py):
+  loss   mean squared error over batch and the 3 outputs + 1e-5 * sum(kernel^2) over every Conv2D / Dense kernel
+         (kernel_regularizer=l2(c), alpha_nnet.py:15, 21...)
+  Adam   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t);
+         w -= lr_t * m / (sqrt(v) + 1e-7)        (epsilon is added to the UNCORRECTED sqrt(v): Keras' "epsilon hat",
+         not torch.optim.Adam's placement), b1 0.9, b2 0.999
+  lr     PiecewiseConstantDecay([20,40,60,80,100], [lr, lr/4, lr/16, lr/64, lr/256, 0.0]) of the optimizer's step count
+         (alpha_nnet.py:79-84: the rate is 0 after step 100)
+  BN     training mode: normalise with the batch mean and the BIASED batch variance, epsilon 1e-3; moving_mean and
+         moving_variance move with momentum 0.99, the variance that enters the moving average is the UNBIASED one
+         (TF's fused batch norm applies Bessel's correction to the variance it hands to the moving average)
+  fit    shuffles every epoch.
+Data parallel (torch.distributed initialised, one process per GPU, RCCL): every rank holds the same sample set (the
+iteration-end all-gather, snake_engine/dist.py) and the same seed, draws the same global batches and takes every
+world-th row of each; batch-norm statistics are all-reduced (forward: sum, sum of squares; backward: the two reductions
+of the gradient), the gradients are summed in ONE flat bucket per step.  The result equals the one-rank full-batch
+result up to float32 rounding, the ranks run the same number of steps by construction and end with identical weights
+and moving statistics.
 """
 import numpy as np
 import torch
 import torch.nn.functional as F
 
 BN_EPS, BN_MOMENTUM, L2_C = 1e-3, 0.99, 1e-5
+ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-7
 
 
 def lr_at(step, schedule, default=1e-4):
@@ -27,13 +41,59 @@ def lr_at(step, schedule, default=1e-4):
     return values[-1]
 
 
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist
+    return None
+
+
+class _SyncBatchNormTrain(torch.autograd.Function):
+    """y = gamma (x - mean) / sqrt(var + eps) + beta with mean / biased var over (N, H, W) of ALL ranks.
+    Returns (y, mean, var, count) -- the last three for the moving averages."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        dist = _dist()
+        c = x.shape[1]
+        stat = torch.empty(2 * c + 1, dtype=x.dtype, device=x.device)
+        stat[:c] = x.sum(dim=(0, 2, 3))
+        stat[c:2 * c] = (x * x).sum(dim=(0, 2, 3))
+        stat[2 * c] = float(x.numel() // c)
+        if dist is not None:
+            dist.all_reduce(stat)
+        n = stat[2 * c]
+        mean = stat[:c] / n
+        var = (stat[c:2 * c] / n - mean * mean).clamp_min(0.0)
+        inv = torch.rsqrt(var + BN_EPS)
+        xhat = (x - mean[None, :, None, None]) * inv[None, :, None, None]
+        ctx.save_for_backward(xhat, gamma, inv, n)
+        ctx.mark_non_differentiable(mean, var, n)
+        return xhat * gamma[None, :, None, None] + beta[None, :, None, None], mean, var, n
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv, _dn):
+        xhat, gamma, inv, n = ctx.saved_tensors
+        dist = _dist()
+        c = dy.shape[1]
+        red = torch.empty(2 * c, dtype=dy.dtype, device=dy.device)
+        red[:c] = dy.sum(dim=(0, 2, 3))                       # local d beta
+        red[c:] = (dy * xhat).sum(dim=(0, 2, 3))              # local d gamma
+        dbeta, dgamma = red[:c].clone(), red[c:].clone()
+        if dist is not None:
+            dist.all_reduce(red)                               # the input gradient needs the global reductions
+        g = (gamma * inv)[None, :, None, None]
+        dx = g * (dy - red[:c][None, :, None, None] / n - xhat * red[c:][None, :, None, None] / n)
+        return dx, dgamma, dbeta
+
+
 class _Net:
     """functional restatement of the graph on torch tensors kept in the Keras layout"""
 
-    def __init__(self, weights, device):
+    def __init__(self, weights, device, dtype=torch.float32):
         self.device = device
         self.blocks = (len(weights) - 14) // 10
-        self.t = [torch.tensor(np.asarray(w, np.float32), device=device) for w in weights]
+        self.t = [torch.tensor(np.asarray(w), dtype=dtype, device=device) for w in weights]
         self.kernel_idx, self.bn_idx, self.param_idx = [], [], []
         i = 0
         for _ in range(2 + 2 * self.blocks):
@@ -52,14 +112,13 @@ class _Net:
         y = F.conv2d(x, k.permute(3, 2, 0, 1), padding=k.shape[0] // 2)
         g, b, mean, var = self.t[i + 1:i + 5]
         if train:
-            m = y.mean(dim=(0, 2, 3))
-            v = y.var(dim=(0, 2, 3), unbiased=False)
+            out, m, v, n = _SyncBatchNormTrain.apply(y, g, b)
             with torch.no_grad():
-                mean.mul_(BN_MOMENTUM).add_(m.detach() * (1 - BN_MOMENTUM))
-                var.mul_(BN_MOMENTUM).add_(v.detach() * (1 - BN_MOMENTUM))
-        else:
-            m, v = mean, var
-        return (y - m[None, :, None, None]) * (g / torch.sqrt(v + BN_EPS))[None, :, None, None] + b[None, :, None, None]
+                unbiased = v * (n / (n - 1.0).clamp_min(1.0))
+                mean.mul_(BN_MOMENTUM).add_(m * (1 - BN_MOMENTUM))
+                var.mul_(BN_MOMENTUM).add_(unbiased * (1 - BN_MOMENTUM))
+            return out
+        return (y - mean[None, :, None, None]) * (g / torch.sqrt(var + BN_EPS))[None, :, None, None] + b[None, :, None, None]
 
     def forward(self, x_nhwc, train):
         x = x_nhwc.permute(0, 3, 1, 2)
@@ -82,42 +141,73 @@ class _Net:
         return [w.detach().cpu().numpy().copy() for w in self.t]
 
 
-def fit(weights, input_shape, X, Y, epochs=32, batch_size=2048, lr_schedule=None, device=None, seed=None, verbose=True):
-    """Returns the trained weights (Keras order).  X: (N, h, w, 3) float32, Y: (N, 3) float32."""
-    import torch.distributed as dist
+class KerasAdam:
+    """Adam exactly as tf.keras.optimizers.Adam applies it (see the module docstring), on one flat state"""
+
+    def __init__(self, params):
+        self.params = params
+        n = sum(p.numel() for p in params)
+        dev = params[0].device
+        self.m = torch.zeros(n, dtype=params[0].dtype, device=dev)
+        self.v = torch.zeros(n, dtype=params[0].dtype, device=dev)
+        self.t = 0
+
+    def step(self, flat_grad, lr):
+        self.t += 1
+        self.m.mul_(ADAM_B1).add_(flat_grad, alpha=1 - ADAM_B1)
+        self.v.mul_(ADAM_B2).addcmul_(flat_grad, flat_grad, value=1 - ADAM_B2)
+        lr_t = lr * np.sqrt(1.0 - ADAM_B2 ** self.t) / (1.0 - ADAM_B1 ** self.t)
+        upd = self.m / (self.v.sqrt() + ADAM_EPS)
+        o = 0
+        with torch.no_grad():
+            for p in self.params:
+                k = p.numel()
+                p.sub_(upd[o:o + k].view_as(p), alpha=float(lr_t))
+                o += k
+
+
+def fit(weights, input_shape, X, Y, epochs=32, batch_size=2048, lr_schedule=None, device=None, seed=None, verbose=True,
+        shuffle=True, dtype=torch.float32):
+    """Returns the trained weights (Keras order).  X: (N, h, w, 3) float32, Y: (N, 3) float32 -- on every rank the SAME
+    arrays (and the same seed) when torch.distributed is initialised; rank r then works on rows r::world of every batch."""
+    dist = _dist()
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
     if device is None:
-        device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
-    net = _Net(weights, device)
-    Xd = torch.as_tensor(np.ascontiguousarray(X, np.float32), device=device)
-    Yd = torch.as_tensor(np.ascontiguousarray(Y, np.float32), device=device)
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    net = _Net(weights, device, dtype)        # float64 only for cross-checks against oracle/train_ref.py
+    Xd = torch.as_tensor(np.ascontiguousarray(X), dtype=dtype, device=device)
+    Yd = torch.as_tensor(np.ascontiguousarray(Y), dtype=dtype, device=device)
     n = Xd.shape[0]
-    opt = torch.optim.Adam(net.params(), lr=1.0, betas=(0.9, 0.999), eps=1e-7)
+    if seed is None:
+        s = torch.tensor([int(np.random.randint(1 << 31))], dtype=torch.int64, device=device if dist is not None and dist.get_backend() == "nccl" else "cpu")
+        if dist is not None:
+            dist.broadcast(s, 0)                 # one shuffle order for all ranks
+        seed = int(s.item())
     gen = torch.Generator(device="cpu")
-    gen.manual_seed(int(np.random.randint(1 << 31)) if seed is None else seed)
-    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    gen.manual_seed(seed)
+    params = net.params()
+    opt = KerasAdam(params)
     step = 0
     history = []
     for ep in range(epochs):
-        perm = torch.randperm(n, generator=gen).to(device)
+        perm = (torch.randperm(n, generator=gen) if shuffle else torch.arange(n)).to(device)
         tot, cnt = 0.0, 0
         for s0 in range(0, n, batch_size):
-            idx = perm[s0:s0 + batch_size]
+            idx_all = perm[s0:s0 + batch_size]
+            idx = idx_all[rank::world]
             pred = net.forward(Xd[idx], True)
-            mse = ((pred - Yd[idx]) ** 2).mean()
-            loss = mse + net.l2()
-            opt.zero_grad(set_to_none=True)
-            loss.backward()
-            if world > 1:
-                for p in net.params():
-                    dist.all_reduce(p.grad)
-                    p.grad.div_(world)
-            for gparam in opt.param_groups:
-                gparam["lr"] = lr_at(step, lr_schedule)
-            opt.step()
+            # this rank's share of the global batch loss; summed over ranks it is mse + l2 of the whole batch
+            loss = ((pred - Yd[idx]) ** 2).sum() / (3.0 * len(idx_all)) + net.l2() / world
+            grads = torch.autograd.grad(loss, params)
+            flat = torch.cat([g.reshape(-1) for g in grads] + [loss.detach().reshape(1)])
+            if dist is not None:
+                dist.all_reduce(flat)            # one bucket: every gradient + the loss value
+            opt.step(flat[:-1], lr_at(step, lr_schedule))
             step += 1
-            tot += float(loss.item()) * len(idx); cnt += len(idx)
+            tot += float(flat[-1].item()) * len(idx_all); cnt += len(idx_all)
         history.append(tot / max(1, cnt))
-        if verbose:
+        if verbose and rank == 0:
             print(f"Epoch {ep + 1}/{epochs} - loss: {history[-1]:.6f}")
     fit.last_history = history
     return net.weights()

@@ -46,3 +46,83 @@ def test_tensorflow_shim_sends_train_py_down_the_cpu_branch():
     except:                                          # noqa: E722
         TPU = None
     assert TPU is None
+
+
+def _tiny_problem(seed=0, n=12, hw=5):
+    from snake_engine.net import glorot_uniform_weights
+    rng = np.random.RandomState(seed)
+    ws = glorot_uniform_weights((hw, hw, 3), blocks=1, seed=seed)
+    for k in (1, 6, 11, 16):                    # non-trivial batch-norm parameters
+        ws[k] = (1.0 + 0.2 * rng.randn(*ws[k].shape)).astype(np.float32)
+        ws[k + 1] = (0.1 * rng.randn(*ws[k].shape)).astype(np.float32)
+    X = rng.rand(n, hw, hw, 3).astype(np.float32)
+    Y = np.tanh(rng.randn(n, 3)).astype(np.float32) * 0.7
+    return ws, X, Y
+
+
+def test_three_optimizer_steps_match_the_numpy_restatement_of_the_keras_formulas():
+    """trainer_torch (autograd, synchronised batch norm function, flat Keras-Adam) in float64 against oracle/train_ref.py
+    (explicit float64 NumPy forward / backward / Adam / moving averages): loss values, every weight and every moving
+    statistic after three full-batch steps with three different learning rates"""
+    from utils import trainer_torch
+    from oracle import train_ref
+    ws, X, Y = _tiny_problem()
+    lrs = [1e-2, 5e-3, 1e-3]
+    got = trainer_torch.fit(ws, (5, 5, 3), X, Y, epochs=3, batch_size=len(X), lr_schedule=([0, 1], lrs),
+                            device=torch.device("cpu"), seed=3, verbose=False, dtype=torch.float64)
+    ref, losses = train_ref.train_steps(ws, X, Y, lrs)
+    assert np.allclose(trainer_torch.fit.last_history, losses, rtol=1e-10, atol=0)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert np.abs(a - b).max() <= 1e-9, (i, np.abs(a - b).max())
+    assert max(np.abs(a - np.asarray(w, np.float64)).max() for a, w in zip(got, ws)) > 1e-3      # it did move
+    # the same run in float32 (what fit() uses) stays within float32 rounding of it
+    got32 = trainer_torch.fit(ws, (5, 5, 3), X, Y, epochs=3, batch_size=len(X), lr_schedule=([0, 1], lrs),
+                              device=torch.device("cpu"), seed=3, verbose=False)
+    close = np.mean([np.mean(np.abs(a - b) <= 1e-4) for a, b in zip(got32, ref)])
+    assert close > 0.995, close                 # an Adam step is +-lr per element: a gradient that rounds across 0 flips one
+
+
+def _fit_worker(rank, world, port, out_dir):
+    import os
+    import sys
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [repo, os.path.join(repo, "alphasnake-zero_amd"), os.path.join(repo, "tests")]
+    from utils import trainer_torch
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ws, X, Y = _tiny_problem(seed=4, n=32)
+        for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            out = trainer_torch.fit(ws, (5, 5, 3), X, Y, epochs=3, batch_size=16, lr_schedule=([2, 4], [1e-2, 2.5e-3, 6e-4]),
+                                    device=torch.device("cpu"), seed=9, verbose=False, dtype=dt)
+            np.savez(os.path.join(out_dir, f"fit_{tag}_r{rank}.npz"), *out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_fit_equals_one_rank_full_batch(tmp_path):
+    """gloo, world_size 2: each rank takes every other row of every global batch; with all-reduced batch-norm statistics
+    and one summed gradient bucket the weights AND the moving statistics equal the single-process result to 1e-6, and
+    both ranks end with identical arrays"""
+    import socket
+    import torch.multiprocessing as mp
+    from utils import trainer_torch
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_fit_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    ws, X, Y = _tiny_problem(seed=4, n=32)
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        one = trainer_torch.fit(ws, (5, 5, 3), X, Y, epochs=3, batch_size=16, lr_schedule=([2, 4], [1e-2, 2.5e-3, 6e-4]),
+                                device=torch.device("cpu"), seed=9, verbose=False, dtype=dt)
+        r0 = np.load(tmp_path / f"fit_{tag}_r0.npz"); r1 = np.load(tmp_path / f"fit_{tag}_r1.npz")
+        diffs = []
+        for i, w in enumerate(one):
+            a, b = r0[f"arr_{i}"], r1[f"arr_{i}"]
+            assert np.array_equal(a, b), f"{tag}: array {i} differs between the ranks"
+            diffs.append(np.abs(a - w).reshape(-1))
+        d = np.concatenate(diffs)
+        if tag == "f64":          # the arithmetic is the same up to summation order: 1e-6 with six orders to spare
+            assert d.max() <= 1e-10, d.max()
+        else:                     # float32: an Adam step is +-lr_t per element whatever the gradient's size, so an element whose
+            #                       gradient is at rounding level moves differently; all others agree to 1e-6
+            assert np.mean(d <= 1e-6) > 0.99 and d.max() <= 1e-3, (np.mean(d <= 1e-6), d.max())
