@@ -82,6 +82,42 @@ __global__ void k_tt_lookup_insert(snk_tt T, const unsigned long long *__restric
     is_new[i] = fresh;
 }
 
+// read-only probe (the reference's `key in cache` / cache[key], agent.py:16-19): entry index and the raw statistics
+// total[3], visit[3], age = now - touch of keys that exist and have not been evicted; TT_NONE otherwise.  No insert, no touch.
+__global__ void k_tt_find(snk_tt T, const unsigned long long *__restrict__ key, int m, int now, int max_age,
+                          uint32_t *__restrict__ entry, float *__restrict__ stat_out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    unsigned long long klo = key[2 * (size_t)i], khi = key[2 * (size_t)i + 1];
+    uint32_t found = TT_NONE;
+    if (!(klo == 0ull && khi == 0ull)) {
+        if (klo == 0ull) klo = 1ull;
+        if (khi == 0ull) khi = 1ull;
+        uint64_t slot = klo & T.mask;
+        for (uint64_t probes = 0; probes <= T.cap; ++probes) {
+            const unsigned long long cur = ld_u64(&T.key_lo[slot]);
+            if (cur == 0ull) break;
+            if (cur == klo && __hip_atomic_load(&T.key_hi[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == khi) {
+                const int t = __float_as_int(T.stat[slot * 8 + 6]);
+                if (now - t <= max_age + 1) found = (uint32_t)slot;
+                break;
+            }
+            slot = (slot + 1) & T.mask;
+        }
+    }
+    entry[i] = found;
+    if (stat_out) {
+        float *o = stat_out + 7 * (size_t)i;
+        if (found == TT_NONE) { for (int k = 0; k < 7; ++k) o[k] = 0.f; }
+        else {
+            const float *s = &T.stat[(size_t)found * 8];
+            for (int k = 0; k < 6; ++k) o[k] = s[k];
+            o[6] = (float)(now - __float_as_int(s[6]));
+        }
+    }
+}
+
 // new entries: prior = net output, visits 1,1,1 (agent.py:193-201)
 __global__ void k_tt_set_priors(snk_tt T, const uint32_t *__restrict__ entry, const int32_t *__restrict__ idx, int n,
                                 const float *__restrict__ q)
@@ -402,6 +438,17 @@ extern "C" int snk_tt_lookup_insert(snk_tt *t, const uint64_t *d_key, const uint
     if (m <= 0) return 0;
     k_tt_lookup_insert<<<(m + 255) / 256, 256, 0, (hipStream_t)stream>>>(*t, (const unsigned long long *)d_key, d_active, m, now_turn,
                                                                          max_age, d_entry, d_is_new);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int snk_tt_find(snk_tt *t, const uint64_t *d_key, int m, int now_turn, int max_age, uint32_t *d_entry,
+                           float *d_stat7, void *stream)
+{
+    SNK_REQUIRE(t && d_key && d_entry, "snk_tt_find: NULL argument");
+    if (m <= 0) return 0;
+    k_tt_find<<<(m + 255) / 256, 256, 0, (hipStream_t)stream>>>(*t, (const unsigned long long *)d_key, m, now_turn, max_age, d_entry,
+                                                                d_stat7);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }

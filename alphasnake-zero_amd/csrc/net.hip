@@ -646,6 +646,54 @@ __global__ __launch_bounds__(256) void k_stem_conv(StemArgs p)
     }
 }
 
+// The same layer with one block per image (the form the launcher picks whenever the padded image fits 64 KB of LDS):
+// the image is read once, coalesced, into LDS with a zero border ([(H+2)][(W+2)][3] floats), so a pixel's 27-value
+// patch is three runs of 9 consecutive floats at constant offsets from one address -- no per-element index arithmetic
+// (the gather of k_stem_conv costs as many instructions as its FMAs: 2.3 TB/s of output, round 1).  Thread
+// (pg = tid / 32, cq = tid % 32) computes outputs 4 cq .. 4 cq + 3 of pixels pg, pg + 8, ...; its 27 x 4 weights stay in
+// registers; the 32 lanes of a pixel write its 512-byte row.  Same tap order as k_stem_conv: identical sums.
+__global__ __launch_bounds__(256) void k_stem_conv_img(StemArgs p)
+{
+    extern __shared__ __align__(16) float st_img[];
+    const int tid = threadIdx.x, cq = tid & 31, pg = tid >> 5;
+    const int Hd = p.Hd, Wd = p.Wd, HW = Hd * Wd, row3 = Wd * 3, P3 = (Wd + 2) * 3;
+    const float *src = p.x + (long)blockIdx.x * HW * 3;
+    for (int j = tid; j < (Hd + 2) * P3; j += 256) {
+        const int yy = j / P3, rr = j - yy * P3;
+        const bool inside = yy >= 1 && yy <= Hd && rr >= 3 && rr < 3 + row3;
+        st_img[j] = inside ? src[(yy - 1) * row3 + rr - 3] : 0.f;
+    }
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 wlo[27], whi[27];
+#pragma unroll
+    for (int q = 0; q < 27; ++q) {
+        const float4 w_ = *(const float4 *)(p.w + q * CV_C + 4 * cq);
+        wlo[q] = (f32x2){w_.x, w_.y}; whi[q] = (f32x2){w_.z, w_.w};
+    }
+    const float4 sc = *(const float4 *)(p.scale + 4 * cq), sh = *(const float4 *)(p.shift + 4 * cq);
+    float *out = p.out + (long)blockIdx.x * HW * CV_C + 4 * cq;
+    __syncthreads();
+    int y = pg / Wd, x = pg - y * Wd;
+    for (int px = pg; px < HW; px += 8) {
+        const float *b = st_img + y * P3 + x * 3;              // padded (y, x) = top-left tap of pixel (y, x)
+        f32x2 alo = (f32x2){0.f, 0.f}, ahi = (f32x2){0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                const float v = b[r * P3 + c];
+                alo = __builtin_elementwise_fma((f32x2){v, v}, wlo[9 * r + c], alo);
+                ahi = __builtin_elementwise_fma((f32x2){v, v}, whi[9 * r + c], ahi);
+            }
+        float4 v;
+        v.x = fmaxf(alo.x * sc.x + sh.x, 0.f); v.y = fmaxf(alo.y * sc.y + sh.y, 0.f);
+        v.z = fmaxf(ahi.x * sc.z + sh.z, 0.f); v.w = fmaxf(ahi.y * sc.w + sh.w, 0.f);
+        *(float4 *)(out + (long)px * CV_C) = v;
+        x += 8;
+        while (x >= Wd) { x -= Wd; ++y; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // head: conv1x1 (C -> 1) + BN + ReLU -> Flatten (HW) -> Dense(128) + ReLU -> Dense(3) + tanh,
 // then AlphaNNet.v's obstacle overwrite (alpha_nnet.py:67-72).  One block per state.
@@ -851,7 +899,9 @@ extern "C" int snk_stem_conv_bn_relu_f32(const float *d_x, const float *d_w, con
     const long M = (long)n_images * height * width;
     SNK_REQUIRE(M < (1l << 31), "snk_stem_conv_bn_relu_f32: batch too large");
     StemArgs a = {d_x, d_w, d_scale, d_shift, d_out, (int)M, height, width};
-    k_stem_conv<<<(int)((M + ST_PX - 1) / ST_PX), 256, 0, (hipStream_t)stream>>>(a);
+    const size_t lds = (size_t)(height + 2) * (width + 2) * 3 * sizeof(float);
+    if (lds <= 64 * 1024) k_stem_conv_img<<<n_images, 256, lds, (hipStream_t)stream>>>(a);
+    else k_stem_conv<<<(int)((M + ST_PX - 1) / ST_PX), 256, 0, (hipStream_t)stream>>>(a);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -68,6 +68,7 @@ PROTOTYPES = {
     "snk_tt_status_sync": (i32, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(i32)]),
     "snk_tt_rebuild_sync": (i32, [vp, u64, i32, i32]),
     "snk_tt_lookup_insert": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
+    "snk_tt_find": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
     "snk_tt_set_priors": (i32, [vp, vp, vp, i32, vp, vp]),
     "snk_tt_read_q": (i32, [vp, vp, i32, i32, vp, vp]),
     "snk_mcts_select": (i32, [vp, vp, i32, C.c_float, vp, vp, C.c_int64, u64, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, i32, vp]),

@@ -4,7 +4,7 @@
 ``clear()``, ``softermax`` and ``argmaxs`` (agent.py:9-147).  The MCTS itself (sub-game clones,
 lock-step rollouts, cache de-duplication, batched net calls, in-rollout and terminal back-ups)
 runs on the GPU: see snake_engine/mcts.py and csrc/mcts.hip.  The four cache dicts of the reference
-live in one HBM hash table; ``cached_values`` etc. are read-only views that report its size.
+live in one HBM hash table; ``cached_values`` etc. are read-only dict-like views of it (len, in, [key]).
 """
 from collections.abc import Sequence
 
@@ -16,15 +16,90 @@ from snake_engine._lib import lib, check
 from snake_engine.mcts import DeviceMCTS
 
 
-class _CacheView:
-    """len() of the device transposition table (the reference's dict of the same name)"""
+_M64 = (1 << 64) - 1
 
-    def __init__(self, agent):
+
+def _sm64(x):
+    """splitmix64 finaliser on uint64 arrays (wrap-around arithmetic)"""
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
+def state_key(state):
+    """The 128-bit digest the device table is keyed on, computed on the host from an observation (an (h, w, 3) float32
+    array or the 5 292-byte string the reference uses as its dict key, agent.py:175): sum over the pixels that differ
+    from the wall default [0, 1.0, 0] of a splitmix64 mix of (pixel index, the three float bit patterns); the same
+    function k_observe evaluates from the compact game state (csrc/engine.hip)."""
+    if isinstance(state, (bytes, bytearray, memoryview)):
+        bits = np.frombuffer(state, np.uint32)
+    else:
+        bits = np.ascontiguousarray(state, np.float32).view(np.uint32)
+    bits = bits.reshape(-1, 3).astype(np.uint64)
+    p = np.arange(bits.shape[0], dtype=np.uint64)
+    b0, b1, b2 = bits[:, 0], bits[:, 1], bits[:, 2]
+    live = ~((b0 == 0) & (b1 == np.uint64(0x3F800000)) & (b2 == 0))
+    x = _sm64((p << np.uint64(32)) | b0)
+    x = _sm64(x ^ ((b1 << np.uint64(32)) | b2))
+    hi = _sm64(x ^ np.uint64(0xD6E8FEB86659FD93))
+    with np.errstate(over="ignore"):
+        return np.array([x[live].sum(dtype=np.uint64), hi[live].sum(dtype=np.uint64)], np.uint64)
+
+
+class _CacheView:
+    """One of the reference's four cache dicts (cached_values / total_rewards / visit_cnts / cache_hit, agent.py:16-19)
+    as a read-only view of the device transposition table: len(), `key in view`, view[key], view.get(key) with the
+    reference's keys (the observation's bytes, agent.py:175) or the observation array itself.  Values are host copies
+    ((3,) float32; an int for cache_hit).  The table stores digests, not the keys, so iteration is not possible."""
+    _FIELDS = {"cached_values": "q", "total_rewards": "total", "visit_cnts": "visit", "cache_hit": "age"}
+
+    def __init__(self, agent, field="q"):
         self._agent = agent
+        self._field = field
 
     def __len__(self):
         m = self._agent._mcts
         return 0 if m is None or m.tt is None else int(m.tt.status()[1])
+
+    def _probe(self, key):
+        m = self._agent._mcts
+        if m is None or m.tt is None:
+            return None
+        k = torch.as_tensor(state_key(key).view(np.int64).reshape(1, 2), device=m.device)
+        entry = torch.empty((1,), dtype=torch.int32, device=m.device)
+        stat = torch.empty((1, 7), dtype=torch.float32, device=m.device)
+        check(lib().snk_tt_find(m.tt.h, k.data_ptr(), 1, m.now, m.max_depth, entry.data_ptr(), stat.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream))
+        if int(entry.item()) == -1:
+            return None
+        return stat[0].cpu().numpy()
+
+    def __contains__(self, key):
+        return self._probe(key) is not None
+
+    def __getitem__(self, key):
+        st = self._probe(key)
+        if st is None:
+            raise KeyError("state not in the transposition cache")
+        if self._field == "q":
+            return (st[0:3] / st[3:6]).astype(np.float32)       # cached_values = total / visit (agent.py:72, 199, 220)
+        if self._field == "total":
+            return st[0:3].copy()
+        if self._field == "visit":
+            return st[3:6].copy()
+        return int(st[6])
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    def __iter__(self):
+        raise TypeError("the device transposition table stores 128-bit digests of the observations, not the observations: "
+                        "its keys cannot be enumerated (look states up with `state.tobytes() in agent.cached_values`)")
 
 
 class _Records(Sequence):
@@ -82,10 +157,10 @@ class Agent:
         self._seed = int(np.random.randint(1 << 62)) if seed is None else int(seed)
         self._sequential, self._tape_u, self._tt_capacity = sequential, tape_u, tt_capacity
         self._mcts = None
-        self.cached_values = _CacheView(self)
-        self.total_rewards = _CacheView(self)
-        self.visit_cnts = _CacheView(self)
-        self.cache_hit = _CacheView(self)
+        self.cached_values = _CacheView(self, "q")
+        self.total_rewards = _CacheView(self, "total")
+        self.visit_cnts = _CacheView(self, "visit")
+        self.cache_hit = _CacheView(self, "age")
         self._reset_records()
         # record data for training
         if training:

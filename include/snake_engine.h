@@ -232,6 +232,12 @@ int snk_tt_rebuild_sync(snk_tt *t, uint64_t new_capacity, int now_turn, int max_
  * (cache_hit[key] = 0, agent.py:185).                                                            */
 int snk_tt_lookup_insert(snk_tt *t, const uint64_t *d_key, const uint8_t *d_active, int m, int now_turn,
                          int max_age, uint32_t *d_entry, uint8_t *d_is_new, void *stream);
+/* Read-only probe -- `key in cached_values`, cached_values[key] / total_rewards[key] / visit_cnts[key] /
+ * cache_hit[key] of the reference's four dicts (agent.py:16-19): d_entry[i] = entry index of key i, or 0xFFFFFFFF
+ * when it does not exist (never inserted, or evicted: now_turn - touch > max_age + 1).  d_stat7 (optional)
+ * float[m][7] = total[3], visit[3], age in root turns.  Nothing is inserted or touched.                          */
+int snk_tt_find(snk_tt *t, const uint64_t *d_key, int m, int now_turn, int max_age, uint32_t *d_entry,
+                float *d_stat7, void *stream);
 /* new entries (agent.py:193-201): total = d_q[j], visit = 1,1,1 for entry d_entry[d_idx ? d_idx[j] : j] */
 int snk_tt_set_priors(snk_tt *t, const uint32_t *d_entry, const int32_t *d_idx, int n, const float *d_q,
                       void *stream);

@@ -449,3 +449,34 @@ def test_agent_accepts_a_net_with_only_the_reference_v_method(env):
     gr = MPGameRunner(11, 11, 4, 1, 2, seed=4)
     gr.run(alice, max_turns=2)
     assert VOnly.calls > 0 and gr.env_steps == 4 and not hasattr(alice, "records")
+
+
+def test_cache_views_are_dict_like(env):
+    """agent.cached_values / total_rewards / visit_cnts / cache_hit (agent.py:16-19) answer `in`, [key], get() with the
+    reference's keys: the observation's bytes (agent.py:175)"""
+    torch, se = env
+    from stubnet_device import DeviceStubNNet
+    from utils.agent import Agent
+    from utils.mp_game_runner import MPGameRunner
+    MPGameRunner.verbose = False
+    alice = Agent(DeviceStubNNet(), 2, True, 8, 16, seed=4)
+    assert len(alice.cached_values) == 0 and b"x" * 5292 not in alice.cached_values
+    gr = MPGameRunner(11, 11, 4, 1, 3, seed=6)
+    gr.run(alice, max_turns=1)
+    n = len(alice.records)
+    assert n == 12 and len(alice.cached_values) > 12
+    for i in range(n):
+        key = alice.records[i].tobytes()
+        assert key in alice.cached_values and alice.records[i] in alice.visit_cnts
+        assert np.array_equal(alice.cached_values[key], alice.values[i])             # root Q of this turn
+        tot, vis = alice.total_rewards[key], alice.visit_cnts[key]
+        assert vis.dtype == np.float32 and (vis >= 1).all() and np.allclose(tot / vis, alice.values[i], atol=1e-6)
+        assert alice.cache_hit[key] == 0                                             # touched this root turn
+    unseen = np.zeros((21, 21, 3), np.float32)
+    assert unseen.tobytes() not in alice.cached_values and alice.cached_values.get(unseen.tobytes()) is None
+    with pytest.raises(KeyError):
+        alice.cached_values[unseen.tobytes()]
+    with pytest.raises(TypeError, match="digests"):
+        iter(alice.cached_values)
+    alice.clear()
+    assert len(alice.cached_values) == 0 and alice.records is not None
