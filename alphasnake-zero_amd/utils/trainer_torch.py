@@ -2,8 +2,8 @@
 SURVEY.md section 8 row f-1 ("next").  Plain PyTorch (autograd, MIOpen convolutions on the GPU): this is the
 caller-side fit step that consumes the self-play samples, not part of the HIP hot path.
 
-Keras 2.x / TF 2.1 semantics restated (the formulas, not the code; cross-checked against an independent float64 NumPy
-restatement, oracle/train_ref.py):
+Keras 2.x / TF 2.1 semantics restated (the formulas, not the code; tests/test_trainer_cpu.py cross-checks them against
+an independent float64 NumPy restatement with a hand-written backward pass):
   loss   mean squared error over batch and the 3 outputs + 1e-5 * sum(kernel^2) over every Conv2D / Dense kernel
          (kernel_regularizer=l2(c), alpha_nnet.py:15, 21...)
   Adam   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t);
@@ -175,7 +175,7 @@ def fit(weights, input_shape, X, Y, epochs=32, batch_size=2048, lr_schedule=None
     rank = dist.get_rank() if dist is not None else 0
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
-    net = _Net(weights, device, dtype)        # float64 only for cross-checks against oracle/train_ref.py
+    net = _Net(weights, device, dtype)        # float64 only for the cross-checks in tests/test_trainer_cpu.py
     Xd = torch.as_tensor(np.ascontiguousarray(X), dtype=dtype, device=device)
     Yd = torch.as_tensor(np.ascontiguousarray(Y), dtype=dtype, device=device)
     n = Xd.shape[0]
