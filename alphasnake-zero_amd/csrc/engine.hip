@@ -54,7 +54,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
                                                        uint8_t *__restrict__ done_out,
                                                        int16_t *__restrict__ spawned_out,
                                                        uint64_t *__restrict__ empty_out, int health_dec,
-                                                       double chance, uint32_t seed_lo, uint32_t seed_hi)
+                                                       double chance, uint32_t seed_lo, uint32_t seed_hi,
+                                                       const uint8_t *__restrict__ active)
 {
     using cell_t = typename CellT<H * W>::type;
     constexpr int NC = H * W;
@@ -63,7 +64,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int sl = lane % GL, gq = lane / GL, gbase = lane - sl;
     const int gi = (blockIdx.x * WAVES_PER_BLOCK + wv) * GPW + gq;
-    const bool valid = gi < n;
+    // games whose `active` flag is 0 are frozen (a rollout sub-game that reached its depth cap, mp_game_runner.py:108):
+    // neither loaded nor stored; the flag load is independent of the record load (no slot indirection, one round trip)
+    const bool frozen = gi < n && active && !active[gi];
+    const bool valid = gi < n && !frozen;
     const int S = L.S, mask = L.cap_mask;
 #define GSHFL(v, o) __shfl((v), gbase + (o), 64)
 #define GBALLOT(pr) (GL == 64 ? __ballot(pr) : ((__ballot(pr) >> gbase) & ((1ull << (GL & 63)) - 1ull)))
@@ -241,6 +245,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
     if (!ended)
         for (int i = sl; i < L.stride / 16; i += GL) ((uint4 *)gsrc)[i] = ((const uint4 *)g)[i];
     if (done_out && valid && sl == 0) done_out[gi] = (uint8_t)(ended || n_alive <= 1);
+    if (done_out && frozen && sl == 0) done_out[gi] = 0;
 #undef GSHFL
 #undef GBALLOT
 }
@@ -717,14 +722,9 @@ extern "C" int snk_engine_clone(const snk_engine *src, const int32_t *d_src_slot
     return 0;
 }
 
-extern "C" int snk_engine_step(snk_engine *e, const int32_t *d_slots, int n, const uint8_t *d_moves,
-                               const int16_t *d_spawn_tape, uint8_t *d_done, int16_t *d_spawned,
-                               uint64_t *d_empty, void *stream)
+static int step_launch(snk_engine *e, const int32_t *d_slots, int n, const uint8_t *d_moves, const int16_t *d_spawn_tape,
+                       uint8_t *d_done, int16_t *d_spawned, uint64_t *d_empty, const uint8_t *d_active, void *stream)
 {
-    SNK_REQUIRE(e != nullptr, "snk_engine_step: engine is NULL");
-    SNK_REQUIRE(n >= 0 && (d_slots || n <= e->n_slots), "snk_engine_step: n=%d exceeds %d slots", n, e->n_slots);
-    if (n == 0) return 0;
-    SNK_REQUIRE(d_moves != nullptr, "snk_engine_step: d_moves is NULL");
     const Layout L = e->L;
     // four games per wavefront where the per-game LDS is small (11x11, 7x7), one per wavefront on 19x19
     if (L.H <= 11) {
@@ -733,19 +733,40 @@ extern "C" int snk_engine_step(snk_engine *e, const int32_t *d_slots, int n, con
         if (L.H == 11)
             k_step<11, 11, 16><<<grid, BLOCK_THREADS, lds, (hipStream_t)stream>>>(
                 e->d_state, L, d_slots, n, d_moves, d_spawn_tape, d_done, d_spawned, d_empty, e->health_dec,
-                e->food_chance, (uint32_t)e->seed, (uint32_t)(e->seed >> 32));
+                e->food_chance, (uint32_t)e->seed, (uint32_t)(e->seed >> 32), d_active);
         else
             k_step<7, 7, 16><<<grid, BLOCK_THREADS, lds, (hipStream_t)stream>>>(
                 e->d_state, L, d_slots, n, d_moves, d_spawn_tape, d_done, d_spawned, d_empty, e->health_dec,
-                e->food_chance, (uint32_t)e->seed, (uint32_t)(e->seed >> 32));
+                e->food_chance, (uint32_t)e->seed, (uint32_t)(e->seed >> 32), d_active);
     } else {
         const size_t lds = (size_t)WAVES_PER_BLOCK * lds_per_wave(L);
         k_step<19, 19, 64><<<wave_grid(n), BLOCK_THREADS, lds, (hipStream_t)stream>>>(
             e->d_state, L, d_slots, n, d_moves, d_spawn_tape, d_done, d_spawned, d_empty, e->health_dec,
-            e->food_chance, (uint32_t)e->seed, (uint32_t)(e->seed >> 32));
+            e->food_chance, (uint32_t)e->seed, (uint32_t)(e->seed >> 32), d_active);
     }
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int snk_engine_step(snk_engine *e, const int32_t *d_slots, int n, const uint8_t *d_moves,
+                               const int16_t *d_spawn_tape, uint8_t *d_done, int16_t *d_spawned,
+                               uint64_t *d_empty, void *stream)
+{
+    SNK_REQUIRE(e != nullptr, "snk_engine_step: engine is NULL");
+    SNK_REQUIRE(n >= 0 && (d_slots || n <= e->n_slots), "snk_engine_step: n=%d exceeds %d slots", n, e->n_slots);
+    if (n == 0) return 0;
+    SNK_REQUIRE(d_moves != nullptr, "snk_engine_step: d_moves is NULL");
+    return step_launch(e, d_slots, n, d_moves, d_spawn_tape, d_done, d_spawned, d_empty, nullptr, stream);
+}
+
+extern "C" int snk_engine_step_active(snk_engine *e, const uint8_t *d_active, int n, const uint8_t *d_moves, uint8_t *d_done,
+                                      void *stream)
+{
+    SNK_REQUIRE(e != nullptr, "snk_engine_step_active: engine is NULL");
+    SNK_REQUIRE(n >= 0 && n <= e->n_slots, "snk_engine_step_active: n=%d exceeds %d slots", n, e->n_slots);
+    if (n == 0) return 0;
+    SNK_REQUIRE(d_moves != nullptr && d_active != nullptr, "snk_engine_step_active: NULL argument");
+    return step_launch(e, nullptr, n, d_moves, nullptr, d_done, nullptr, nullptr, d_active, stream);
 }
 
 extern "C" int snk_engine_alive(const snk_engine *e, const int32_t *d_slots, int n, uint8_t *d_alive,

@@ -42,6 +42,7 @@ PROTOTYPES = {
     "snk_engine_reset": (i32, [vp, vp, i32, vp, vp]),
     "snk_engine_clone": (i32, [vp, vp, i32, vp, vp, i32, vp]),
     "snk_engine_step": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp]),
+    "snk_engine_step_active": (i32, [vp, vp, i32, vp, vp, vp]),
     "snk_engine_alive": (i32, [vp, vp, i32, vp, vp, vp]),
     "snk_engine_ids": (i32, [vp, vp, i32, vp, vp, vp, vp, vp]),
     "snk_engine_observe": (i32, [vp, vp, i32, i32, vp, vp, vp, i32, vp]),

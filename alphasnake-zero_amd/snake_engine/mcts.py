@@ -84,6 +84,7 @@ class DeviceMCTS:
         self._bufs_B = -1
         self.verbose = False              # print the reference's per-epoch line (agent.py:57-58)
         self.stats = dict(net_evals=0, rollout_ticks=0, sim_steps=0, lookups=0)
+        self._sim_steps_pending = []      # device counters of the sub-game tics, folded into stats at the turn's end
 
     # ---- buffers -------------------------------------------------------------------------------
     def _ensure(self, G, health_dec):
@@ -161,6 +162,7 @@ class DeviceMCTS:
             root.clone_to(self.roll, src_slots=live_slots, n=G, fanout=par)       # game.subgame (agent.py:46-50)
             self.path_len.zero_()
             sub_active = torch.ones((B,), dtype=torch.bool, device=self.device)
+            sim_steps_dev = torch.zeros((), dtype=torch.int64, device=self.device)
             for tick in range(1, n_ticks + 1):
                 self.roll.alive(n=B, out=self.alive_rows)
                 row_active = (self.alive_rows.bool() & sub_active[:, None]).reshape(-1).to(torch.uint8)
@@ -189,23 +191,15 @@ class DeviceMCTS:
                 self.tape_pos += n_rows
                 check(L.snk_mcts_backup(tt, _ptr(self.entry), m, _ptr(self.est), _ptr(self.pmf), _ptr(self.path_entry),
                                         _ptr(self.path_move), _ptr(self.path_len), D, seq, st))
-                # tic every live sub-game (mp_game_runner.py:104-106); retired ones are frozen by giving them
-                # to the kernel as already-inactive slots: stepping is harmless for ended games, and
-                # depth-retired games must not move, so step only the active ones.
-                act_idx = torch.nonzero(sub_active).to(torch.int32).reshape(-1)
-                if act_idx.numel() == B:
-                    self.roll.step(self.moves, n=B, done=self.done)
-                    done = self.done.bool()
-                else:
-                    mv = self.moves.view(B, S).index_select(0, act_idx).contiguous()
-                    dn = torch.empty((act_idx.numel(),), dtype=torch.uint8, device=self.device)
-                    if act_idx.numel():
-                        self.roll.step(mv, slots=act_idx.contiguous(), done=dn)
-                    done = torch.zeros((B,), dtype=torch.bool, device=self.device)
-                    done[act_idx.long()] = dn.bool()
-                self.stats["sim_steps"] += int(act_idx.numel())
+                # tic every live sub-game (mp_game_runner.py:104-106) in one launch over all B slots; sub-games retired by
+                # their depth cap must not move: their `active` flag is 0 and the kernel skips them (no host read-back)
+                act_u8 = sub_active.to(torch.uint8)
+                self.roll.step_active(act_u8, self.moves, B, done=self.done)
+                done = self.done.bool()
+                sim_steps_dev += act_u8.sum(dtype=torch.int64)
                 sub_active = sub_active & ~(done | (tick >= sub_depth))          # mp_game_runner.py:108-113
                 self.stats["rollout_ticks"] += 1
+            self._sim_steps_pending.append(sim_steps_dev)
             check(L.snk_engine_rewards(self.roll.h, None, B, _ptr(self.rewards), st))
             check(L.snk_mcts_terminal_backup(tt, _ptr(self.rewards), m, _ptr(self.path_entry), _ptr(self.path_move),
                                              _ptr(self.path_len), D, seq, st))   # agent.py:60-72
@@ -243,6 +237,9 @@ class DeviceMCTS:
         physically when the table is more than half full (and the table doubles if the survivors still
         fill more than half of it)."""
         cap, occ, ovf = self.tt.status()
+        if self._sim_steps_pending:
+            self.stats["sim_steps"] += int(torch.stack(self._sim_steps_pending).sum().item())
+            self._sim_steps_pending = []
         if ovf:
             raise EngineError("transposition table overflowed; raise tt_capacity")
         if occ * 2 > cap:

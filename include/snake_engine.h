@@ -93,6 +93,11 @@ int snk_engine_clone(const snk_engine *src, const int32_t *d_src_slots, int n, s
 int snk_engine_step(snk_engine *e, const int32_t *d_slots, int n, const uint8_t *d_moves,
                     const int16_t *d_spawn_tape, uint8_t *d_done, int16_t *d_spawned,
                     uint64_t *d_empty, void *stream);
+/* The lock-step form of MCTSMPGameRunner.run (mp_game_runner.py:104-113): slots 0..n-1, of which only those with
+ * d_active[i] != 0 are stepped; the others (sub-games retired by their depth cap) are neither read nor written and
+ * report d_done[i] = 0.  Food spawning follows the engine's food_spawn_chance (0 for sub-games, game.py:268).   */
+int snk_engine_step_active(snk_engine *e, const uint8_t *d_active, int n, const uint8_t *d_moves,
+                           uint8_t *d_done, void *stream);
 
 /* ---- Game.get_ids / alive bookkeeping (game.py:76-77) -----------------------------------
  * d_alive: uint8[n][S] (1 = snake alive), d_n_alive (optional): int32[n].                     */

@@ -118,6 +118,40 @@ def test_ended_games_are_left_untouched(se):
         assert_state_equal(compact_from_state(out[k]), golden_state(z, i), f"ended game {k}")
 
 
+@pytest.mark.parametrize("hw,S", [(11, 4), (7, 2), (19, 8)])
+def test_step_active_freezes_the_masked_games(se, hw, S):
+    """snk_engine_step_active (the rollout loop's form): flagged games take the same step as snk_engine_step with the
+    compacted slot list, the others keep their bytes and report done = 0"""
+    import torch
+    from snake_engine.engine import compact_from_state
+    n = 203
+    a = se.Engine(n, hw, hw, S, 1, 0.0, seed=5)
+    a.reset()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for _ in range(5):
+        a.step(torch.randint(0, 3, (n, S), device="cuda", generator=g, dtype=torch.int32).to(torch.uint8))
+    b = se.Engine(n, hw, hw, S, 1, 0.0, seed=5)
+    a.clone_to(b)
+    c = se.Engine(n, hw, hw, S, 1, 0.0, seed=5)
+    a.clone_to(c)
+    mv = torch.randint(0, 3, (n, S), device="cuda", generator=g, dtype=torch.int32).to(torch.uint8)
+    active = (torch.rand(n, device="cuda", generator=g) < 0.6).to(torch.uint8)
+    done_b = b.new((n,), torch.uint8, 7)
+    b.step_active(active, mv, n, done=done_b)
+    idx = torch.nonzero(active).reshape(-1).to(torch.int32)
+    done_c = c.new((idx.numel(),), torch.uint8, 7)
+    c.step(mv[idx.long()].contiguous(), slots=idx.contiguous(), done=done_c)
+    sb, sc = b.export(), c.export()
+    for i in range(n):
+        x, y = compact_from_state(sb[i]), compact_from_state(sc[i])
+        for k in x:
+            assert np.array_equal(x[k], y[k]), (i, k)
+    db = done_b.cpu().numpy()
+    assert np.array_equal(db[active.cpu().numpy().astype(bool)], done_c.cpu().numpy())
+    assert (db[~active.cpu().numpy().astype(bool)] == 0).all()
+    assert int(active.sum()) not in (0, n)
+
+
 @pytest.mark.parametrize("cfg", TIC_CFGS)
 def test_reset_with_init_tape(se, cfg):
     from snake_engine.engine import compact_from_state
