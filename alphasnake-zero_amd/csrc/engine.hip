@@ -25,9 +25,18 @@ extern "C" int snk_version(void) { return 100; }
 #define WAVES_PER_BLOCK 4
 #define BLOCK_THREADS (WAVES_PER_BLOCK * 64)
 
+// Kernels are templated on the board side: 11x11, 7x7 and 19x19 (the BASELINE configs) get compile-time geometry; any
+// other square board runs the same code with the geometry read from the Layout: <0, 0> for boards of at most 255 cells
+// (8-bit ring entries), <-1, -1> for larger ones (16-bit entries; CellT<(-1) * (-1)> is the primary template).
 template <int NC> struct CellT { using type = uint16_t; };
 template <> struct CellT<121> { using type = uint8_t; };
 template <> struct CellT<49> { using type = uint8_t; };
+template <> struct CellT<0> { using type = uint8_t; };
+#define BOARD_DIMS(L)                                                                                   \
+    const int HH = H > 0 ? H : (L).H, WW = W > 0 ? W : (L).W;                                           \
+    const int NC = HH * WW;                                                                             \
+    constexpr int MAXFW = H > 0 ? (H * W + 63) / 64 : (SNK_MAX_CELLS + 63) / 64;                        \
+    (void)HH; (void)WW; (void)NC; (void)MAXFW;
 
 __device__ static inline bool food_bit(const uint64_t *food, int c) { return (food[c >> 6] >> (c & 63)) & 1ull; }
 
@@ -58,7 +67,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
                                                        const uint8_t *__restrict__ active)
 {
     using cell_t = typename CellT<H * W>::type;
-    constexpr int NC = H * W;
+    BOARD_DIMS(L)
     constexpr int GPW = 64 / GL;                       // games per wavefront
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -107,11 +116,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
         m.dir = (uint8_t)d;
         const int hi = (m.tail + m.len - 1) & mask;
         const int hc = ring[hi];
-        int y = hc / W, x = hc - y * W;
+        int y = hc / WW, x = hc - y * WW;
         y += (d == 2) - (d == 0);
         x += (d == 1) - (d == 3);
-        oob = (y < 0) | (y >= H) | (x < 0) | (x >= W);
-        head_cell = oob ? -1 : y * W + x;
+        oob = (y < 0) | (y >= HH) | (x < 0) | (x >= WW);
+        head_cell = oob ? -1 : y * WW + x;
         m.tail = (uint16_t)((m.tail + 1) & mask);      // pop the tail node, push the new head
         if (!oob) ring[(hi + 1) & mask] = (cell_t)head_cell;
         m.health = (int16_t)(m.health - health_dec);
@@ -157,9 +166,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
     if (chance > 0.0 && !ended) {
         int n_food = 0;
         for (int w = 0; w < L.FW; ++w) n_food += __popcll(food[w]);
-        uint64_t emk[(NC + 63) / 64];
+        uint64_t emk[MAXFW];
         int n_empty = 0;
-        for (int w = 0; w < (NC + 63) / 64; ++w) {
+#pragma unroll
+        for (int w = 0; w < MAXFW; ++w) {
+            if (w >= L.FW) { emk[w] = 0ull; continue; }
             uint64_t mk = 0ull;
 #pragma unroll
             for (int q = 0; q < GPW; ++q) {
@@ -180,7 +191,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
             const double u1 = ((double)r[0] + 0.5) * (1.0 / 4294967296.0);
             if ((n_food == 0 || u1 <= chance) && n_empty > 0) {
                 int k = (int)(((uint64_t)r[1] * (uint64_t)n_empty) >> 32);   // uniform in [0, n_empty)
-                for (int w = 0; w < (NC + 63) / 64; ++w) {
+#pragma unroll
+                for (int w = 0; w < MAXFW; ++w) {
                     const uint64_t mk = emk[w];
                     const int pc = __popcll(mk);
                     if (spawn < 0) {
@@ -260,6 +272,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_reset(uint8_t *__restrict__ s
                                                         uint32_t seed_lo, uint32_t seed_hi)
 {
     using cell_t = typename CellT<H * W>::type;
+    BOARD_DIMS(L)
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int gi = blockIdx.x * WAVES_PER_BLOCK + wv;
@@ -269,8 +282,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_reset(uint8_t *__restrict__ s
     for (int i = lane; i < L.stride / 16; i += 64) ((uint4 *)g)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     if (valid && lane == 0) {
-        const int sy[8] = {1, H - 2, H - 2, 1, 1, H / 2, H - 2, H / 2};
-        const int sx[8] = {1, W - 2, 1, W - 2, W / 2, W - 2, W / 2, 1};
+        const int sy[8] = {1, HH - 2, HH - 2, 1, 1, HH / 2, HH - 2, HH / 2};
+        const int sx[8] = {1, WW - 2, 1, WW - 2, WW / 2, WW - 2, WW / 2, 1};
         uint8_t pos[8], dirs[8], fc[8];
         const uint32_t uid = uid_base + (uint32_t)gi;
         if (tape) {
@@ -293,15 +306,15 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_reset(uint8_t *__restrict__ s
         }
         SnakeMeta *meta = (SnakeMeta *)(g + L.meta_off);
         uint64_t *food = (uint64_t *)(g + L.food_off);
-        const int center = (H / 2) * W + W / 2;
+        const int center = (HH / 2) * WW + WW / 2;
         food[center >> 6] |= 1ull << (center & 63);
         for (int s = 0; s < S; ++s) {
             const int y = sy[pos[s]], x = sx[pos[s]];
             cell_t *ring = (cell_t *)(g + s * L.ring_bytes);
-            ring[0] = ring[1] = ring[2] = (cell_t)(y * W + x);      // 3 stacked nodes (game.py:37)
+            ring[0] = ring[1] = ring[2] = (cell_t)(y * WW + x);     // 3 stacked nodes (game.py:37)
             meta[s].tail = 0; meta[s].len = 3; meta[s].health = 100; meta[s].dir = dirs[s]; meta[s].alive = 1;
             const int fy = y + ((fc[s] & 2) ? 1 : -1), fx = x + ((fc[s] & 1) ? 1 : -1);
-            const int c = fy * W + fx;
+            const int c = fy * WW + fx;
             food[c >> 6] |= 1ull << (c & 63);
         }
         *(uint32_t *)(g + L.uid_off) = uid;
@@ -391,7 +404,8 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
                                                           uint64_t *__restrict__ key_out, int legacy_mask)
 {
     using cell_t = typename CellT<H * W>::type;
-    constexpr int NC = H * W, N = 2 * H - 1, NPIX = N * N, NEL = NPIX * 3;
+    BOARD_DIMS(L)
+    const int N = 2 * HH - 1, NPIX = N * N, NEL = NPIX * 3;
     static_assert(H == W, "only square boards batch (rot90 transposes odd-k shapes)");
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr int GPW = 64 / GL;                       // observations per wavefront
@@ -437,7 +451,7 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
     __syncthreads();
 
     const int my_head = (int)((const cell_t *)(g + you * L.ring_bytes))[(me.tail + me.len - 1) & mask];
-    const int hy = my_head / W, hx = my_head - hy * W;
+    const int hy = my_head / WW, hx = my_head - hy * WW;
     const int k = me.dir & 3;
     const float fval = (float)((double)(101 - (int)me.health) * 0.01);   // game.py:243-244
 
@@ -476,8 +490,8 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
         __syncthreads();
         if (live)
             for (int c = sl; c < NC; c += GL) {
-                const int y = c / W, x = c - y * W;
-                const int si = y - hy + (H - 1), sj = x - hx + (W - 1);
+                const int y = c / WW, x = c - y * WW;
+                const int si = y - hy + (HH - 1), sj = x - hx + (WW - 1);
                 int i, j;                              // numpy.rot90(grid, k): out[i][j] = grid[si][sj], inverted
                 if (k == 0) { i = si; j = sj; }
                 else if (k == 1) { i = N - 1 - sj; j = si; }
@@ -515,7 +529,7 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
             const int ad = (k + 3 + sl) & 3;           // left / straight / right of the heading
             const int y = hy + (ad == 2) - (ad == 0), x = hx + (ad == 1) - (ad == 3);
             float v = 1.0f;
-            if (y >= 0 && y < H && x >= 0 && x < W) v = cell_val(y * W + x, 1);
+            if (y >= 0 && y < HH && x >= 0 && x < WW) v = cell_val(y * WW + x, 1);
             b = legacy_mask ? ((double)v >= 0.04) : (v >= 0.04f);          // alpha_nnet.py:75-76
         }
         mask_out[(size_t)pi * 3 + sl] = b;
@@ -527,8 +541,8 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
                 const uint32_t b0 = __float_as_uint(cell_val(c, 0)), b1 = __float_as_uint(cell_val(c, 1)),
                                b2 = __float_as_uint(cell_val(c, 2));
                 if (b0 == 0u && b1 == 0x3F800000u && b2 == 0u) continue;   // indistinguishable from a wall
-                const int y = c / W, x = c - y * W;
-                const int si = y - hy + (H - 1), sj = x - hx + (W - 1);
+                const int y = c / WW, x = c - y * WW;
+                const int si = y - hy + (HH - 1), sj = x - hx + (WW - 1);
                 int i, j;                                // inverse of the rot90 map above
                 if (k == 0) { i = si; j = sj; }
                 else if (k == 1) { i = N - 1 - sj; j = si; }
@@ -613,20 +627,24 @@ __global__ __launch_bounds__(CMP_THREADS) void k_cmp_scatter(const uint8_t *__re
 }
 
 // ------------------------------------------------------------------------------------------ C ABI
-static bool supported_board(int H, int W) { return (H == 11 && W == 11) || (H == 7 && W == 7) || (H == 19 && W == 19); }
+// square boards of 5x5 (the eight standard start cells are distinct from there on, game.py:25-29) to 19x19 (SNK_MAX_CELLS);
+// the reference's observation is a rot90 of a (2H-1)x(2W-1) canvas, so only square boards batch (game.py:257)
+static bool supported_board(int H, int W) { return H == W && H >= 5 && H * W <= SNK_MAX_CELLS; }
 
-#define DISPATCH_BOARD(L, CALL)                                         \
-    do {                                                                \
-        if ((L).H == 11) { constexpr int BH = 11, BW = 11; CALL; }      \
-        else if ((L).H == 7) { constexpr int BH = 7, BW = 7; CALL; }    \
-        else { constexpr int BH = 19, BW = 19; CALL; }                  \
+#define DISPATCH_BOARD(L, CALL)                                                 \
+    do {                                                                        \
+        if ((L).H == 11) { constexpr int BH = 11, BW = 11; CALL; }              \
+        else if ((L).H == 7) { constexpr int BH = 7, BW = 7; CALL; }            \
+        else if ((L).H == 19) { constexpr int BH = 19, BW = 19; CALL; }         \
+        else if ((L).NC <= 255) { constexpr int BH = 0, BW = 0; CALL; }         \
+        else { constexpr int BH = -1, BW = -1; CALL; }                          \
     } while (0)
 
 extern "C" int snk_engine_create(snk_engine **out, int n_slots, int H, int W, int S, int health_dec,
                                  double food_spawn_chance, uint64_t seed, int device)
 {
     SNK_REQUIRE(out != nullptr, "snk_engine_create: out is NULL");
-    SNK_REQUIRE(supported_board(H, W), "snk_engine_create: unsupported board %dx%d (11x11, 7x7, 19x19)", H, W);
+    SNK_REQUIRE(supported_board(H, W), "snk_engine_create: unsupported board %dx%d (square boards from 5x5 to 19x19)", H, W);
     SNK_REQUIRE(S >= 2 && S <= SNK_MAX_SNAKES, "snk_engine_create: snake count %d outside 2..8", S);
     SNK_REQUIRE(n_slots > 0, "snk_engine_create: n_slots must be positive");
     SNK_CHECK_HIP(hipSetDevice(device));
@@ -727,23 +745,21 @@ static int step_launch(snk_engine *e, const int32_t *d_slots, int n, const uint8
 {
     const Layout L = e->L;
     // four games per wavefront where the per-game LDS is small (11x11, 7x7), one per wavefront on 19x19
+#define STEP_ARGS e->d_state, L, d_slots, n, d_moves, d_spawn_tape, d_done, d_spawned, d_empty, e->health_dec, e->food_chance, \
+                  (uint32_t)e->seed, (uint32_t)(e->seed >> 32), d_active
     if (L.H <= 11) {
         const size_t lds = (size_t)WAVES_PER_BLOCK * 4 * lds_per_wave(L);
         const int grid = (n + WAVES_PER_BLOCK * 4 - 1) / (WAVES_PER_BLOCK * 4);
-        if (L.H == 11)
-            k_step<11, 11, 16><<<grid, BLOCK_THREADS, lds, (hipStream_t)stream>>>(
-                e->d_state, L, d_slots, n, d_moves, d_spawn_tape, d_done, d_spawned, d_empty, e->health_dec,
-                e->food_chance, (uint32_t)e->seed, (uint32_t)(e->seed >> 32), d_active);
-        else
-            k_step<7, 7, 16><<<grid, BLOCK_THREADS, lds, (hipStream_t)stream>>>(
-                e->d_state, L, d_slots, n, d_moves, d_spawn_tape, d_done, d_spawned, d_empty, e->health_dec,
-                e->food_chance, (uint32_t)e->seed, (uint32_t)(e->seed >> 32), d_active);
+        if (L.H == 11) k_step<11, 11, 16><<<grid, BLOCK_THREADS, lds, (hipStream_t)stream>>>(STEP_ARGS);
+        else if (L.H == 7) k_step<7, 7, 16><<<grid, BLOCK_THREADS, lds, (hipStream_t)stream>>>(STEP_ARGS);
+        else k_step<0, 0, 16><<<grid, BLOCK_THREADS, lds, (hipStream_t)stream>>>(STEP_ARGS);
     } else {
         const size_t lds = (size_t)WAVES_PER_BLOCK * lds_per_wave(L);
-        k_step<19, 19, 64><<<wave_grid(n), BLOCK_THREADS, lds, (hipStream_t)stream>>>(
-            e->d_state, L, d_slots, n, d_moves, d_spawn_tape, d_done, d_spawned, d_empty, e->health_dec,
-            e->food_chance, (uint32_t)e->seed, (uint32_t)(e->seed >> 32), d_active);
+        if (L.H == 19) k_step<19, 19, 64><<<wave_grid(n), BLOCK_THREADS, lds, (hipStream_t)stream>>>(STEP_ARGS);
+        else if (L.NC <= 255) k_step<0, 0, 64><<<wave_grid(n), BLOCK_THREADS, lds, (hipStream_t)stream>>>(STEP_ARGS);
+        else k_step<-1, -1, 64><<<wave_grid(n), BLOCK_THREADS, lds, (hipStream_t)stream>>>(STEP_ARGS);
     }
+#undef STEP_ARGS
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -796,7 +812,8 @@ extern "C" int snk_engine_observe(const snk_engine *e, const int32_t *d_pairs, i
         const size_t lds = (size_t)WPB * 4 * lds_per_wave(L);
         const int grid = (m + WPB * 4 - 1) / (WPB * 4);
         if (L.H == 11) k_observe<11, 11, 16, WPB><<<grid, WPB * 64, lds, (hipStream_t)stream>>>(e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask);
-        else k_observe<7, 7, 16, WPB><<<grid, WPB * 64, lds, (hipStream_t)stream>>>(e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask);
+        else if (L.H == 7) k_observe<7, 7, 16, WPB><<<grid, WPB * 64, lds, (hipStream_t)stream>>>(e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask);
+        else k_observe<0, 0, 16, WPB><<<grid, WPB * 64, lds, (hipStream_t)stream>>>(e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask);
     } else {
         const size_t lds = (size_t)WAVES_PER_BLOCK * (d_planes ? lds_per_wave_obs(L) : lds_per_wave(L));
         DISPATCH_BOARD(L, (k_observe<BH, BW, 64, WAVES_PER_BLOCK><<<wave_grid(m), BLOCK_THREADS, lds, (hipStream_t)stream>>>(

@@ -738,12 +738,17 @@ def record_replay(seed=31, H=11, W=11, S=4, hd=9):
 
 if __name__ == "__main__":
     os.chdir("/tmp")
-    which = set(sys.argv[1:]) or {"tic", "corner", "tables", "mcts", "runner", "pit", "replay"}
+    which = set(sys.argv[1:]) or {"tic", "tic_more", "corner", "tables", "mcts", "runner", "pit", "replay"}
     if "tic" in which:
         record_trajectories("11x11x4", 11, 11, 4, 1, 40, seed=1, p_legal=0.92, max_ticks=400, raw_every=23)
         record_trajectories("11x11x4_dec9", 11, 11, 4, 9, 10, seed=2, p_legal=0.97, max_ticks=400, raw_every=29)
         record_trajectories("7x7x2", 7, 7, 2, 3, 16, seed=3, p_legal=0.9, max_ticks=300, raw_every=17)
         record_trajectories("19x19x8", 19, 19, 8, 1, 6, seed=4, p_legal=0.95, max_ticks=300, raw_every=61)
+    if "tic_more" in which:      # board sizes outside the BASELINE configs (the engine's run-time-geometry kernels)
+        record_trajectories("9x9x3", 9, 9, 3, 1, 8, seed=5, p_legal=0.9, max_ticks=200, raw_every=19)
+        record_trajectories("15x15x5", 15, 15, 5, 3, 4, seed=6, p_legal=0.93, max_ticks=200, raw_every=37)
+        record_trajectories("16x16x6", 16, 16, 6, 1, 3, seed=7, p_legal=0.93, max_ticks=160, raw_every=41)
+        record_trajectories("5x5x2", 5, 5, 2, 1, 8, seed=8, p_legal=0.9, max_ticks=100, raw_every=13)
     if "corner" in which:
         record_corner_cases()
     if "tables" in which:

@@ -7,7 +7,7 @@ import pytest
 
 from conftest import load_golden, golden_state
 
-TIC_CFGS = ["11x11x4", "11x11x4_dec9", "7x7x2", "19x19x8"]
+TIC_CFGS = ["11x11x4", "11x11x4_dec9", "7x7x2", "19x19x8", "9x9x3", "15x15x5", "16x16x6", "5x5x2"]
 KEYS = ("alive", "health", "length", "dir", "food", "rewards", "counters")
 
 
