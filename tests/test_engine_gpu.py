@@ -418,7 +418,8 @@ def test_error_codes_and_empty_inputs(se):
     from snake_engine._lib import lib, EngineError
     L = lib()
     h = C.c_void_p()
-    assert L.snk_engine_create(C.byref(h), 4, 12, 12, 4, 1, 0.15, 1, 0) < 0 and b"unsupported board" in L.snk_last_error()
+    for hh, ww in ((12, 11), (4, 4), (20, 20)):          # non-square (rot90 of the observation), below 5x5, above 361 cells
+        assert L.snk_engine_create(C.byref(h), 4, hh, ww, 4, 1, 0.15, 1, 0) < 0 and b"unsupported board" in L.snk_last_error()
     assert L.snk_engine_create(C.byref(h), 4, 11, 11, 9, 1, 0.15, 1, 0) < 0 and b"snake count" in L.snk_last_error()
     assert L.snk_engine_create(C.byref(h), 0, 11, 11, 4, 1, 0.15, 1, 0) < 0
     with pytest.raises(EngineError):
