@@ -5,6 +5,7 @@ for buffers, index plumbing (gather / cumsum) and the single host read-back per 
 number of cache misses, which sizes the net batch).
 """
 import ctypes as C
+import os
 from time import time
 
 import numpy as np
@@ -14,6 +15,11 @@ from ._lib import lib, check, EngineError
 from .engine import Engine, _ptr, _stream
 
 PARALLEL = 8     # agent.py:32
+# Rollout batches of at most this many rows (sub-games x snakes) run the fixed-shape tick: every row is observed and
+# evaluated, no compaction, no device-to-host count -- so the tick is a fixed sequence of launches that is captured once
+# per root turn in a HIP graph and replayed (one host call per tick instead of ~25; below ~500 states a net forward costs
+# the same whatever the batch, the launches and the host are what such a run waits for).  0 disables it.
+GRAPH_ROWS = int(os.environ.get("SNK_GRAPH_ROWS", "1024"))
 
 
 def _pow2_at_least(v):
@@ -59,7 +65,7 @@ class TranspositionTable:
 class DeviceMCTS:
     def __init__(self, evaluate, height, width, snake_cnt, softmax_base=100, training=False, max_depth=8,
                  max_breadth=128, seed=1234, device=None, sequential=False, tape_u=None, tt_capacity=None,
-                 legacy_mask=False):
+                 legacy_mask=False, graph_ticks=None):
         """evaluate(planes[n,h,w,3] cuda f32, mask[n,3] cuda u8) -> cuda f32 [n,3]  (= AlphaNNet.v)"""
         if not torch.cuda.is_available():
             raise EngineError("DeviceMCTS needs an MI355X; there is no CPU fallback")
@@ -83,8 +89,15 @@ class DeviceMCTS:
         self.roll = None                  # rollout engine (sub-games; food_spawn_chance 0, game.py:268)
         self._bufs_B = -1
         self.verbose = False              # print the reference's per-epoch line (agent.py:57-58)
-        self.stats = dict(net_evals=0, rollout_ticks=0, sim_steps=0, lookups=0)
+        # fixed-shape / graph-captured tick for small batches: needs an evaluate() made of stream-ordered device work only
+        # (AlphaNNet.v_device is; a net that goes through the host is not).  None = decide per call from `graph_safe`.
+        self.graph_ticks = graph_ticks
+        self.graph_safe = False           # set by the owner (utils.agent.Agent) when evaluate() never touches the host
+        self._graph = None
+        self.stats = dict(net_evals=0, rollout_ticks=0, sim_steps=0, lookups=0, graph_replays=0, graph_captures=0)
         self._sim_steps_pending = []      # device counters of the sub-game tics, folded into stats at the turn's end
+        self._evals_pending = []
+        self.graph_capture = os.environ.get("SNK_GRAPH_CAPTURE", "1") != "0"     # 0: fixed-shape tick launched eagerly
 
     # ---- buffers -------------------------------------------------------------------------------
     def _ensure(self, G, health_dec):
@@ -122,6 +135,14 @@ class DeviceMCTS:
             self.cmp_cnt = torch.empty((1,), dtype=torch.int32, device=dev)
             self.cmp_scratch = torch.empty((self.L.snk_compact_scratch_elems(m),), dtype=torch.int32, device=dev)
             self.planes = None
+            # persistent state of the fixed-shape tick (a replayed graph reads and writes the same addresses)
+            self.sub_active = torch.ones((B,), dtype=torch.bool, device=dev)
+            self.sub_depth = torch.zeros((B,), dtype=torch.int32, device=dev)
+            self.tick_dev = torch.zeros((), dtype=torch.int32, device=dev)
+            self.ctr_dev = torch.zeros((1,), dtype=torch.int64, device=dev)       # Philox counter: uint32[2] to the kernel
+            self.evals_dev = torch.zeros((), dtype=torch.int64, device=dev)
+            self.sims_dev = torch.zeros((), dtype=torch.int64, device=dev)
+            self._graph = None
             self._bufs_B = B
         return par, B
 
@@ -134,6 +155,47 @@ class DeviceMCTS:
     def _next_ctr(self):
         self.draw_ctr += 1
         return self.draw_ctr & 0xFFFFFFFF, (self.draw_ctr >> 32) & 0xFFFFFFFF
+
+    # ---- the fixed-shape rollout tick (small batches) ------------------------------------------------
+    def _tick_fixed(self, B, m, D):
+        """One rollout tick (agent.py:161-223 + mp_game_runner.py:99-113) as a fixed sequence of launches over all m rows:
+        state that changes from tick to tick (active flags, tick number, draw counter, statistics) lives in device
+        tensors that are updated in place, so the same sequence can be replayed from a HIP graph."""
+        L, st, tt = self.L, _stream(), self.tt.h
+        self.roll.alive(n=B, out=self.alive_rows)
+        row_active = (self.alive_rows.bool() & self.sub_active[:, None]).reshape(-1).to(torch.uint8)
+        planes = self.planes[:m]
+        self.roll.observe(self.pairs, m, planes, self.mask, self.key, legacy_mask=self.legacy_mask)
+        check(L.snk_tt_lookup_insert(tt, _ptr(self.key), _ptr(row_active), m, self.now, self.max_depth,
+                                     _ptr(self.entry), _ptr(self.is_new), st))
+        q = self.evaluate(planes, self.mask).contiguous()            # every row; only the new keys keep their evaluation
+        check(L.snk_tt_set_priors_flagged(tt, _ptr(self.entry), _ptr(self.is_new), m, _ptr(q), st))
+        self.evals_dev += self.is_new.sum(dtype=torch.int64)
+        check(L.snk_mcts_select_dctr(tt, _ptr(self.entry), m, self.base, self.seed, _ptr(self.ctr_dev), _ptr(self.moves),
+                                     _ptr(self.est), _ptr(self.pmf), _ptr(self.path_entry), _ptr(self.path_move),
+                                     _ptr(self.path_len), D, st))
+        self.ctr_dev += 1
+        check(L.snk_mcts_backup(tt, _ptr(self.entry), m, _ptr(self.est), _ptr(self.pmf), _ptr(self.path_entry),
+                                _ptr(self.path_move), _ptr(self.path_len), D, 0, st))
+        act_u8 = self.sub_active.to(torch.uint8)
+        self.roll.step_active(act_u8, self.moves, B, done=self.done)
+        self.sims_dev += act_u8.sum(dtype=torch.int64)
+        self.tick_dev += 1
+        self.sub_active &= ~(self.done.bool() | (self.sub_depth <= self.tick_dev))      # mp_game_runner.py:108-113
+
+    def _capture_tick(self, B, m, D):
+        """captures _tick_fixed in a HIP graph (torch.cuda.CUDAGraph: every launch of the tick, ours and torch's, goes to
+        the capturing stream).  `now` and the table handle are baked in, so the graph lives for one root turn; the tick
+        is run once eagerly on a side stream first (allocations, lazy initialisation), as capture requires."""
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._tick_fixed(B, m, D)              # warm-up on real state: it IS the first tick of the epoch
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.cuda.graph(g, stream=side):
+            self._tick_fixed(B, m, D)
+        return g
 
     def clear(self):
         """Agent.clear (agent.py:140-147)"""
@@ -157,13 +219,38 @@ class DeviceMCTS:
         epochs = self.max_breadth // par                        # agent.py:37
         tt = self.tt.h
         seq = int(self.sequential)
+        # small batches: fixed-shape tick, captured in a HIP graph for this root turn (see GRAPH_ROWS)
+        fixed = (0 < m <= GRAPH_ROWS and self.tape is None and not self.sequential
+                 and (self.graph_safe if self.graph_ticks is None else self.graph_ticks))
+        if fixed:
+            self.sub_depth.copy_(sub_depth)
+            self.ctr_dev.fill_(self.draw_ctr + 1)               # the counter the next eager draw would use
+            self.evals_dev.zero_(); self.sims_dev.zero_()
+            self._planes(m)
+            graph, n_replayed = None, 0
         for ep in range(epochs):
             t_epoch = time()
             root.clone_to(self.roll, src_slots=live_slots, n=G, fanout=par)       # game.subgame (agent.py:46-50)
             self.path_len.zero_()
-            sub_active = torch.ones((B,), dtype=torch.bool, device=self.device)
-            sim_steps_dev = torch.zeros((), dtype=torch.int64, device=self.device)
-            for tick in range(1, n_ticks + 1):
+            if fixed:
+                self.sub_active.fill_(True)
+                self.tick_dev.zero_()
+                for tick in range(1, n_ticks + 1):
+                    if graph is not None:
+                        graph.replay()
+                        self.stats["graph_replays"] += 1
+                    elif self.graph_capture and n_ticks * epochs >= 4:
+                        graph = self._capture_tick(B, m, D)     # runs this tick eagerly (warm-up), then records the graph
+                        self.stats["graph_captures"] += 1
+                    else:
+                        self._tick_fixed(B, m, D)
+                    n_replayed += 1
+                    self.stats["rollout_ticks"] += 1
+                sim_steps_dev = None
+            else:
+                sub_active = torch.ones((B,), dtype=torch.bool, device=self.device)
+                sim_steps_dev = torch.zeros((), dtype=torch.int64, device=self.device)
+            for tick in (range(1, n_ticks + 1) if not fixed else ()):
                 self.roll.alive(n=B, out=self.alive_rows)
                 row_active = (self.alive_rows.bool() & sub_active[:, None]).reshape(-1).to(torch.uint8)
                 self.roll.observe(self.pairs, m, None, self.mask, self.key, legacy_mask=self.legacy_mask)
@@ -199,7 +286,8 @@ class DeviceMCTS:
                 sim_steps_dev += act_u8.sum(dtype=torch.int64)
                 sub_active = sub_active & ~(done | (tick >= sub_depth))          # mp_game_runner.py:108-113
                 self.stats["rollout_ticks"] += 1
-            self._sim_steps_pending.append(sim_steps_dev)
+            if sim_steps_dev is not None:
+                self._sim_steps_pending.append(sim_steps_dev)
             check(L.snk_engine_rewards(self.roll.h, None, B, _ptr(self.rewards), st))
             check(L.snk_mcts_terminal_backup(tt, _ptr(self.rewards), m, _ptr(self.path_entry), _ptr(self.path_move),
                                              _ptr(self.path_len), D, seq, st))   # agent.py:60-72
@@ -214,6 +302,12 @@ class DeviceMCTS:
                 if occ * 2 > cap:
                     self.tt.rebuild(cap * 2, self.now, 1 << 30)
                     tt = self.tt.h
+                    graph = None                                 # the captured launches point into the old table
+        if fixed:
+            self.draw_ctr += n_replayed                          # the draws the ticks consumed
+            self._sim_steps_pending.append(self.sims_dev.clone())
+            self._evals_pending.append(self.evals_dev.clone())
+            graph = None                                         # `now` is baked in: a graph lives for one root turn
         # V[i] = cached_values[first_key] (agent.py:74-87): the root observation's entry, from clone 0 of each game
         first = self.path_entry.view(G, par, S, D)[:, 0, :, 0].contiguous().reshape(-1)
         root_rows_alive = root_alive.reshape(-1).contiguous()
@@ -240,6 +334,9 @@ class DeviceMCTS:
         if self._sim_steps_pending:
             self.stats["sim_steps"] += int(torch.stack(self._sim_steps_pending).sum().item())
             self._sim_steps_pending = []
+        if self._evals_pending:
+            self.stats["net_evals"] += int(torch.stack(self._evals_pending).sum().item())
+            self._evals_pending = []
         if ovf:
             raise EngineError("transposition table overflowed; raise tt_capacity")
         if occ * 2 > cap:

@@ -266,6 +266,15 @@ int snk_mcts_select(snk_tt *t, const uint32_t *d_entry, int m, float softmax_bas
                     const int32_t *d_rank, int64_t tape_base, uint64_t seed, uint32_t ctr0, uint32_t ctr1,
                     uint8_t *d_moves, float *d_est, float *d_pmf, uint32_t *d_path_entry,
                     uint8_t *d_path_move, int32_t *d_path_len, int path_depth, void *stream);
+/* The two entry points the fixed-shape rollout tick uses so that it can be captured once in a HIP graph and replayed
+ * (snake_engine/mcts.py, batches of at most SNK_GRAPH_ROWS rows): the Philox draw counter is read from device memory
+ * (uint32[2], advanced by the caller inside the graph) instead of being a launch argument, and the priors are written
+ * for the rows flagged d_is_new of a batch in which EVERY row was evaluated (no compaction, no device-to-host count). */
+int snk_mcts_select_dctr(snk_tt *t, const uint32_t *d_entry, int m, float softmax_base, uint64_t seed,
+                         const uint32_t *d_ctr, uint8_t *d_moves, float *d_est, float *d_pmf, uint32_t *d_path_entry,
+                         uint8_t *d_path_move, int32_t *d_path_len, int path_depth, void *stream);
+int snk_tt_set_priors_flagged(snk_tt *t, const uint32_t *d_entry, const uint8_t *d_is_new, int m, const float *d_q,
+                              void *stream);
 int snk_mcts_backup(snk_tt *t, const uint32_t *d_entry, int m, const float *d_est, const float *d_pmf,
                     uint32_t *d_path_entry, uint8_t *d_path_move, int32_t *d_path_len, int path_depth,
                     int sequential, void *stream);

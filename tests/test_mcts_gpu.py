@@ -480,3 +480,52 @@ def test_cache_views_are_dict_like(env):
         iter(alice.cached_values)
     alice.clear()
     assert len(alice.cached_values) == 0 and alice.records is not None
+
+
+def test_graph_captured_tick_equals_the_eager_ticks(env):
+    """small rollout batches: the fixed-shape tick replayed from a HIP graph, the same tick launched eagerly, and the
+    compacted tick of the large-batch path draw the same Philox numbers and evaluate the same new keys -> same root moves,
+    same evaluation counts, root Q equal to float32 summation order"""
+    torch, se = env
+    from snake_engine.mcts import DeviceMCTS
+    from stubnet_device import stub_q_device
+
+    def mk(graph_ticks, capture):
+        def f():
+            m = DeviceMCTS(stub_q_device, 11, 11, 4, 2, True, 8, 24, seed=77, graph_ticks=graph_ticks)
+            m.graph_capture = capture
+            made.append(m)
+            return m
+        return f
+    made = []
+    VA, VB, MA, MB = _paired_search(se, torch, 8, 5, 24, mk(True, True), mk(False, False), seed=31)
+    g, e = made
+    assert g.stats["graph_captures"] == 5 and g.stats["graph_replays"] > 5 * 10 and e.stats["graph_replays"] == 0
+    g.end_of_turn(); e.end_of_turn()
+    assert g.stats["net_evals"] == e.stats["net_evals"] and g.stats["sim_steps"] == e.stats["sim_steps"]
+    assert g.stats["rollout_ticks"] == e.stats["rollout_ticks"] and g.draw_ctr == e.draw_ctr
+    assert np.array_equal(MA, MB)
+    assert np.abs(VA - VB).max() <= 2e-6, np.abs(VA - VB).max()
+    made.clear()
+    VA2, VC, MA2, MC = _paired_search(se, torch, 8, 5, 24, mk(True, True), mk(True, False), seed=31)
+    assert np.array_equal(MA2, MC) and np.abs(VA2 - VC).max() <= 2e-6 and np.array_equal(MA2, MA)
+    assert made[1].stats["graph_captures"] == 0
+
+
+def test_small_self_play_runs_on_graphs_with_the_real_net(env):
+    """BASELINE configs[0]-sized run through the drop-in classes with the MFMA Q-net: the rollout ticks are graph replays"""
+    torch, se = env
+    from snake_engine import net
+    from utils.agent import Agent
+    from utils.alpha_nnet import AlphaNNet
+    from utils.mp_game_runner import MPGameRunner
+    MPGameRunner.verbose = False
+    nn_ = AlphaNNet(input_shape=(21, 21, 3), _weights=net.glorot_uniform_weights((21, 21, 3), 4, seed=0))
+    alice = Agent(nn_, 2, True, 8, 25, seed=5)
+    gr = MPGameRunner(11, 11, 4, 1, 8, seed=6)
+    gr.run(alice, max_turns=3)
+    st = alice._mcts.stats
+    assert gr.env_steps == 24 and st["graph_captures"] == 3 and st["graph_replays"] >= 3 * (3 * 4 - 1)
+    assert st["net_evals"] > 24 * 20 and len(alice.records) == 96
+    v = np.array(alice.values[:96])
+    assert np.isfinite(v).all() and (np.abs(v) <= 1).all()
