@@ -217,6 +217,9 @@ def main():
     ap.add_argument("--snakes", type=int, default=4)
     ap.add_argument("--blocks", type=int, default=4, help="residual blocks of the Q-net")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-conv-timing", action="store_true",
+                    help="no HIP events around the conv launches (roofline.achieved is then null): lets small runs "
+                         "(games x 8 x snakes <= SNK_GRAPH_ROWS rows) replay their rollout ticks from HIP graphs")
     ap.add_argument("--no-kernel-rooflines", action="store_true")
     args = ap.parse_args()
 
@@ -278,7 +281,7 @@ def main():
     log(f"[rank {rank}] warmup {args.warmup} turns in {time.time() - t_w:.1f} s")
     m = alice._mcts
     ev0, sim0 = (m.stats["net_evals"], m.stats["sim_steps"]) if m is not None else (0, 0)     # --warmup 0: nothing ran yet
-    nnet._qnet.conv_timing = []
+    nnet._qnet.conv_timing = None if args.no_conv_timing else []
     barrier()
     t0 = time.time()
     gr.run(alice, max_turns=args.steps)
@@ -306,11 +309,11 @@ def main():
     sims = m.stats["sim_steps"] - sim0
 
     if rank == 0:
-        tm = nnet._qnet.conv_timing
+        tm = nnet._qnet.conv_timing or []
         nnet._qnet.conv_timing = None
         conv_s = sum(a.elapsed_time(b) for a, b, _ in tm) * 1e-3
         conv_flops = sum(f for _, _, f in tm)
-        achieved = conv_flops / conv_s / 1e12 if conv_s > 0 else 0.0
+        achieved = conv_flops / conv_s / 1e12 if conv_s > 0 else None      # None: --no-conv-timing
         algo = nnet._qnet.conv_algo
         peak = 2500.0 if algo in ("bf16", "f16s", "f16") else 157.3      # dense MFMA peaks (bf16 / f16, f32), MI355X_MICROARCH.md
         # MFMA flops the kernel executes per algorithmic (direct-convolution) flop
@@ -334,14 +337,15 @@ def main():
                                    "training=True, gen-0 Glorot net (seed 0), fp32 Q-net",
                        "games_per_gpu": args.games, "breadth": args.breadth, "parallelism": f"games sharded x{world}", "dist_backend": backend if world > 1 else None,
                        "net_evals_per_env_step": evals / max(1, gr.env_steps), "sim_steps_per_env_step": sims / max(1, gr.env_steps),
-                       "net_evals_per_s_rank0": evals / dt, "sample_rows_gathered": int(Xg.shape[0])},
+                       "net_evals_per_s_rank0": evals / dt, "sample_rows_gathered": int(Xg.shape[0]),
+                       "graph_replays": m.stats.get("graph_replays", 0)},
             "roofline": {"bound": "mfma",
                          "kernel": {"winograd": "k_conv3x3_wino_f32", "bf16": "k_conv3x3_bf16", "f16s": "k_conv3x3_f16s",
                                     "f16": "k_conv3x3_f16s<SPLIT = false>"}.get(algo, "k_conv3x3_f32"),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic, "launches": len(tm),
+                         "frac": achieved / peak if achieved else None, "traffic": traffic, "launches": len(tm),
                          "flops_convention": "algorithmic = direct 3x3 convolution, 2*441*1152*128 per state and layer (SURVEY 8d)",
-                         "executed_frac": achieved / peak * executed,
+                         "executed_frac": achieved / peak * executed if achieved else None,
                          "algorithm": {"winograd": "Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: executes 16*121/(441*9) = 0.488 of the "
                                                    "algorithmic flops, fp32 throughout",
                                        "bf16": "implicit GEMM on v_mfma_f32_32x32x16_bf16",
