@@ -34,10 +34,12 @@ __device__ static inline unsigned long long ld_u64(const unsigned long long *p)
 // MCTSAgent.make_moves, "get states without duplicates" (agent.py:170-186)
 // ------------------------------------------------------------------------------------------
 __global__ void k_tt_lookup_insert(snk_tt T, const unsigned long long *__restrict__ key, const uint8_t *__restrict__ active,
-                                   int m, int now, int max_age, uint32_t *__restrict__ entry, uint8_t *__restrict__ is_new)
+                                   int m, int now, int max_age, uint32_t *__restrict__ entry, uint8_t *__restrict__ is_new,
+                                   const int *__restrict__ d_now)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
+    if (d_now) now = d_now[0];            // root-turn clock kept on the device (replayed HIP graphs cannot change an argument)
     unsigned long long klo = key[2 * (size_t)i], khi = key[2 * (size_t)i + 1];
     if ((active && !active[i]) || (klo == 0ull && khi == 0ull)) { entry[i] = TT_NONE; is_new[i] = 0; return; }
     if (klo == 0ull) klo = 1ull;          // 0 is the "empty" / "unpublished" sentinel of both words
@@ -452,7 +454,18 @@ extern "C" int snk_tt_lookup_insert(snk_tt *t, const uint64_t *d_key, const uint
     SNK_REQUIRE(t && d_key && d_entry && d_is_new, "snk_tt_lookup_insert: NULL argument");
     if (m <= 0) return 0;
     k_tt_lookup_insert<<<(m + 255) / 256, 256, 0, (hipStream_t)stream>>>(*t, (const unsigned long long *)d_key, d_active, m, now_turn,
-                                                                         max_age, d_entry, d_is_new);
+                                                                         max_age, d_entry, d_is_new, nullptr);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int snk_tt_lookup_insert_dnow(snk_tt *t, const uint64_t *d_key, const uint8_t *d_active, int m, const int32_t *d_now_turn,
+                                         int max_age, uint32_t *d_entry, uint8_t *d_is_new, void *stream)
+{
+    SNK_REQUIRE(t && d_key && d_entry && d_is_new && d_now_turn, "snk_tt_lookup_insert_dnow: NULL argument");
+    if (m <= 0) return 0;
+    k_tt_lookup_insert<<<(m + 255) / 256, 256, 0, (hipStream_t)stream>>>(*t, (const unsigned long long *)d_key, d_active, m, 0,
+                                                                         max_age, d_entry, d_is_new, d_now_turn);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }

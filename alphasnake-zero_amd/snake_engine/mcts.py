@@ -38,6 +38,7 @@ class TranspositionTable:
         h = C.c_void_p()
         check(self.L.snk_tt_create(C.byref(h), int(capacity), device))
         self.h = h
+        self.generation = 0          # bumped whenever the table's device buffers are replaced (rebuild)
 
     def close(self):
         if getattr(self, "h", None):
@@ -60,6 +61,7 @@ class TranspositionTable:
 
     def rebuild(self, new_capacity, now, max_age):
         check(self.L.snk_tt_rebuild_sync(self.h, int(new_capacity), int(now), int(max_age)))
+        self.generation += 1
 
 
 class DeviceMCTS:
@@ -93,7 +95,8 @@ class DeviceMCTS:
         # (AlphaNNet.v_device is; a net that goes through the host is not).  None = decide per call from `graph_safe`.
         self.graph_ticks = graph_ticks
         self.graph_safe = False           # set by the owner (utils.agent.Agent) when evaluate() never touches the host
-        self._graph = None
+        self._graph = None                # (graph, B, table handle value) of the captured tick
+        self._side = None
         self.stats = dict(net_evals=0, rollout_ticks=0, sim_steps=0, lookups=0, graph_replays=0, graph_captures=0)
         self._sim_steps_pending = []      # device counters of the sub-game tics, folded into stats at the turn's end
         self._evals_pending = []
@@ -140,6 +143,7 @@ class DeviceMCTS:
             self.sub_depth = torch.zeros((B,), dtype=torch.int32, device=dev)
             self.tick_dev = torch.zeros((), dtype=torch.int32, device=dev)
             self.ctr_dev = torch.zeros((1,), dtype=torch.int64, device=dev)       # Philox counter: uint32[2] to the kernel
+            self.now_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
             self.evals_dev = torch.zeros((), dtype=torch.int64, device=dev)
             self.sims_dev = torch.zeros((), dtype=torch.int64, device=dev)
             self._graph = None
@@ -166,8 +170,8 @@ class DeviceMCTS:
         row_active = (self.alive_rows.bool() & self.sub_active[:, None]).reshape(-1).to(torch.uint8)
         planes = self.planes[:m]
         self.roll.observe(self.pairs, m, planes, self.mask, self.key, legacy_mask=self.legacy_mask)
-        check(L.snk_tt_lookup_insert(tt, _ptr(self.key), _ptr(row_active), m, self.now, self.max_depth,
-                                     _ptr(self.entry), _ptr(self.is_new), st))
+        check(L.snk_tt_lookup_insert_dnow(tt, _ptr(self.key), _ptr(row_active), m, _ptr(self.now_dev), self.max_depth,
+                                          _ptr(self.entry), _ptr(self.is_new), st))
         q = self.evaluate(planes, self.mask).contiguous()            # every row; only the new keys keep their evaluation
         check(L.snk_tt_set_priors_flagged(tt, _ptr(self.entry), _ptr(self.is_new), m, _ptr(q), st))
         self.evals_dev += self.is_new.sum(dtype=torch.int64)
@@ -185,16 +189,21 @@ class DeviceMCTS:
 
     def _capture_tick(self, B, m, D):
         """captures _tick_fixed in a HIP graph (torch.cuda.CUDAGraph: every launch of the tick, ours and torch's, goes to
-        the capturing stream).  `now` and the table handle are baked in, so the graph lives for one root turn; the tick
-        is run once eagerly on a side stream first (allocations, lazy initialisation), as capture requires."""
+        the capturing stream).  Everything that changes between ticks and between root turns is device state (clock,
+        draw counter, tick number, active flags), so the graph is replayed until the batch shape or the table's buffers
+        change.  The tick is run once eagerly on the side stream first (allocations, lazy initialisation), as capture
+        requires -- on real state: it IS a tick of the search."""
         g = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream())
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side, main = self._side, torch.cuda.current_stream()
+        side.wait_stream(main)
         with torch.cuda.stream(side):
-            self._tick_fixed(B, m, D)              # warm-up on real state: it IS the first tick of the epoch
-        torch.cuda.current_stream().wait_stream(side)
-        with torch.cuda.graph(g, stream=side):
             self._tick_fixed(B, m, D)
+            g.capture_begin()
+            self._tick_fixed(B, m, D)
+            g.capture_end()
+        main.wait_stream(side)
         return g
 
     def clear(self):
@@ -226,8 +235,13 @@ class DeviceMCTS:
             self.sub_depth.copy_(sub_depth)
             self.ctr_dev.fill_(self.draw_ctr + 1)               # the counter the next eager draw would use
             self.evals_dev.zero_(); self.sims_dev.zero_()
+            self.now_dev.fill_(self.now)
             self._planes(m)
-            graph, n_replayed = None, 0
+            n_replayed = 0
+            key = (B, id(self.tt), self.tt.generation, self.planes.data_ptr(), id(self.roll))
+            graph = self._graph[0] if self._graph is not None and self._graph[1] == key else None
+            if graph is None:
+                self._graph = None
         for ep in range(epochs):
             t_epoch = time()
             root.clone_to(self.roll, src_slots=live_slots, n=G, fanout=par)       # game.subgame (agent.py:46-50)
@@ -241,6 +255,7 @@ class DeviceMCTS:
                         self.stats["graph_replays"] += 1
                     elif self.graph_capture and n_ticks * epochs >= 4:
                         graph = self._capture_tick(B, m, D)     # runs this tick eagerly (warm-up), then records the graph
+                        self._graph = (graph, key)
                         self.stats["graph_captures"] += 1
                     else:
                         self._tick_fixed(B, m, D)
@@ -302,12 +317,12 @@ class DeviceMCTS:
                 if occ * 2 > cap:
                     self.tt.rebuild(cap * 2, self.now, 1 << 30)
                     tt = self.tt.h
-                    graph = None                                 # the captured launches point into the old table
+                    graph, self._graph = None, None              # the captured launches point into the old table
+                    key = (B, id(self.tt), self.tt.generation, self.planes.data_ptr(), id(self.roll))
         if fixed:
             self.draw_ctr += n_replayed                          # the draws the ticks consumed
             self._sim_steps_pending.append(self.sims_dev.clone())
             self._evals_pending.append(self.evals_dev.clone())
-            graph = None                                         # `now` is baked in: a graph lives for one root turn
         # V[i] = cached_values[first_key] (agent.py:74-87): the root observation's entry, from clone 0 of each game
         first = self.path_entry.view(G, par, S, D)[:, 0, :, 0].contiguous().reshape(-1)
         root_rows_alive = root_alive.reshape(-1).contiguous()

@@ -198,6 +198,10 @@ class QNet:
 
     # ---- forward -------------------------------------------------------------------------------
     def _workspace(self, n, k=0):
+        if torch.cuda.is_current_stream_capturing():
+            # inside a HIP-graph capture the activations come from the graph's own memory pool: they stay valid for as long
+            # as the graph is replayed, whatever later (larger) eager forwards do to the cached workspaces
+            return [torch.empty((n, self.h, self.w, 128), dtype=torch.float32, device=self.device) for _ in range(3)]
         if self._ws is None:
             self._ws = {}
         if k not in self._ws or self._ws[k][0].shape[0] < n:
@@ -264,6 +268,8 @@ class QNet:
                              0 if mk is None else mk.data_ptr(), out[s0:s0 + m].data_ptr(), m, h, w, st))
 
     def _h1_workspace(self, n, k=0):
+        if torch.cuda.is_current_stream_capturing():
+            return torch.empty((n, self.h * self.w), dtype=torch.float32, device=self.device)
         key = ("h1", k)
         if key not in self._ws or self._ws[key].shape[0] < n:
             self._ws[key] = torch.empty((n, self.h * self.w), dtype=torch.float32, device=self.device)

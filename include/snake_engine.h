@@ -275,6 +275,10 @@ int snk_mcts_select_dctr(snk_tt *t, const uint32_t *d_entry, int m, float softma
                          uint8_t *d_path_move, int32_t *d_path_len, int path_depth, void *stream);
 int snk_tt_set_priors_flagged(snk_tt *t, const uint32_t *d_entry, const uint8_t *d_is_new, int m, const float *d_q,
                               void *stream);
+/* snk_tt_lookup_insert with the root-turn clock read from device memory (int32[1]): the third graph-replayable entry */
+int snk_tt_lookup_insert_dnow(snk_tt *t, const uint64_t *d_key, const uint8_t *d_active, int m,
+                              const int32_t *d_now_turn, int max_age, uint32_t *d_entry, uint8_t *d_is_new,
+                              void *stream);
 int snk_mcts_backup(snk_tt *t, const uint32_t *d_entry, int m, const float *d_est, const float *d_pmf,
                     uint32_t *d_path_entry, uint8_t *d_path_move, int32_t *d_path_len, int path_depth,
                     int sequential, void *stream);

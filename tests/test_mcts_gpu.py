@@ -500,7 +500,9 @@ def test_graph_captured_tick_equals_the_eager_ticks(env):
     made = []
     VA, VB, MA, MB = _paired_search(se, torch, 8, 5, 24, mk(True, True), mk(False, False), seed=31)
     g, e = made
-    assert g.stats["graph_captures"] == 5 and g.stats["graph_replays"] > 5 * 10 and e.stats["graph_replays"] == 0
+    # one capture per batch shape (a root game that ends shrinks the batch), every other tick is a replay
+    assert 1 <= g.stats["graph_captures"] <= 5 and g.stats["graph_replays"] > 5 * 10 and e.stats["graph_replays"] == 0
+    assert g.stats["graph_captures"] + g.stats["graph_replays"] == g.stats["rollout_ticks"]
     g.end_of_turn(); e.end_of_turn()
     assert g.stats["net_evals"] == e.stats["net_evals"] and g.stats["sim_steps"] == e.stats["sim_steps"]
     assert g.stats["rollout_ticks"] == e.stats["rollout_ticks"] and g.draw_ctr == e.draw_ctr
@@ -525,7 +527,7 @@ def test_small_self_play_runs_on_graphs_with_the_real_net(env):
     gr = MPGameRunner(11, 11, 4, 1, 8, seed=6)
     gr.run(alice, max_turns=3)
     st = alice._mcts.stats
-    assert gr.env_steps == 24 and st["graph_captures"] == 3 and st["graph_replays"] >= 3 * (3 * 4 - 1)
+    assert gr.env_steps == 24 and 1 <= st["graph_captures"] <= 3 and st["graph_replays"] >= 3 * 3 * 4 - 3
     assert st["net_evals"] > 24 * 20 and 80 <= len(alice.records) <= 96
     v = np.array(alice.values[:80])
     assert np.isfinite(v).all() and (np.abs(v) <= 1).all()
