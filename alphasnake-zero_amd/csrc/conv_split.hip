@@ -28,6 +28,7 @@
 // epilogue also reduces the head's 1x1 convolution per pixel and skips the layer output.  Workgroups map to (image,
 // part) XCD-aware: the parts of an image, which share halo rows, run on the same XCD (same L2) back to back.
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -403,7 +404,8 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
     // very small batches (measured: up to ~40 images at 21x21): cut the images finer so that the grid covers more of the
     // chip's block slots -- a block's duration, not the throughput, is what such a launch costs (16 states: 31 -> 14 us);
     // from ~48 images on the 7-tile blocks with their compile-time epilogues are faster again
-    if (n_images <= 40 && n_images * n_blk < 512) {
+    static const int fine_max = getenv("SNK_CONV_FINE_MAX") ? atoi(getenv("SNK_CONV_FINE_MAX")) : 40;
+    if (n_images <= fine_max && n_images * n_blk < 512) {
         n_blk = min(T, max(n_blk, (512 + n_images - 1) / n_images));
         tiles_max = (T + n_blk - 1) / n_blk;
     }

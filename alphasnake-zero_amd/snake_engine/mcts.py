@@ -15,11 +15,15 @@ from ._lib import lib, check, EngineError
 from .engine import Engine, _ptr, _stream
 
 PARALLEL = 8     # agent.py:32
-# Rollout batches of at most this many rows (sub-games x snakes) run the fixed-shape tick: every row is observed and
-# evaluated, no compaction, no device-to-host count -- so the tick is a fixed sequence of launches that is captured once
-# per root turn in a HIP graph and replayed (one host call per tick instead of ~25; below ~500 states a net forward costs
-# the same whatever the batch, the launches and the host are what such a run waits for).  0 disables it.
-GRAPH_ROWS = int(os.environ.get("SNK_GRAPH_ROWS", "1024"))
+# Optional fixed-shape rollout tick for batches of at most this many rows (sub-games x snakes): every row is observed and
+# evaluated (no compaction, no device-to-host count), so the tick is a fixed launch sequence that is captured once in a HIP
+# graph and replayed, with the clock, the draw counter and the active flags in device memory.  OFF by default (0): measured
+# on MI355X it loses to the compacted tick at every size tried (8 games / 256 rows: 419 vs 609 env-steps/s; 32 games / 1024
+# rows: 254 vs 570) -- the cache de-duplication leaves only 20-40 % of the rows to evaluate, and a small batch's forward is
+# bound by the duration of one convolution block per layer (~50 us), not by launches: the GPU is busy 70-85 % of the wall
+# time in the eager small run already (profiles/r2_small_config_kernel_stats.csv).  Kept as an option and as the test bed
+# of the graph-replayable entry points (snk_mcts_select_dctr, snk_tt_lookup_insert_dnow, snk_tt_set_priors_flagged).
+GRAPH_ROWS = int(os.environ.get("SNK_GRAPH_ROWS", "0"))
 
 
 def _pow2_at_least(v):

@@ -482,13 +482,16 @@ def test_cache_views_are_dict_like(env):
     assert len(alice.cached_values) == 0 and alice.records is not None
 
 
-def test_graph_captured_tick_equals_the_eager_ticks(env):
+def test_graph_captured_tick_equals_the_eager_ticks(env, monkeypatch):
     """small rollout batches: the fixed-shape tick replayed from a HIP graph, the same tick launched eagerly, and the
     compacted tick of the large-batch path draw the same Philox numbers and evaluate the same new keys -> same root moves,
     same evaluation counts, root Q equal to float32 summation order"""
     torch, se = env
     from snake_engine.mcts import DeviceMCTS
     from stubnet_device import stub_q_device
+
+    import snake_engine.mcts as mcts_mod
+    monkeypatch.setattr(mcts_mod, "GRAPH_ROWS", 1024)
 
     def mk(graph_ticks, capture):
         def f():
@@ -514,14 +517,16 @@ def test_graph_captured_tick_equals_the_eager_ticks(env):
     assert made[1].stats["graph_captures"] == 0
 
 
-def test_small_self_play_runs_on_graphs_with_the_real_net(env):
+def test_small_self_play_runs_on_graphs_with_the_real_net(env, monkeypatch):
     """BASELINE configs[0]-sized run through the drop-in classes with the MFMA Q-net: the rollout ticks are graph replays"""
     torch, se = env
     from snake_engine import net
     from utils.agent import Agent
     from utils.alpha_nnet import AlphaNNet
     from utils.mp_game_runner import MPGameRunner
+    import snake_engine.mcts as mcts_mod
     MPGameRunner.verbose = False
+    monkeypatch.setattr(mcts_mod, "GRAPH_ROWS", 1024)         # the graph tick is opt-in (SNK_GRAPH_ROWS)
     nn_ = AlphaNNet(input_shape=(21, 21, 3), _weights=net.glorot_uniform_weights((21, 21, 3), 4, seed=0))
     alice = Agent(nn_, 2, True, 8, 25, seed=5)
     gr = MPGameRunner(11, 11, 4, 1, 8, seed=6)

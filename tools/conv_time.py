@@ -12,8 +12,8 @@ sizes = [int(v) for v in sys.argv[3:]] or [64, 512, 4096]
 prep, conv, wbytes = {"winograd": (L.snk_conv3x3_prepare_weights_winograd, L.snk_conv3x3_bn_f32_winograd, 16 * 128 * 128 * 4),
                       "direct": (L.snk_conv3x3_prepare_weights, L.snk_conv3x3_bn_f32, 9 * 128 * 128 * 4),
                       "bf16": (L.snk_conv3x3_prepare_weights_bf16, L.snk_conv3x3_bn_bf16, 9 * 128 * 128 * 2),
-                      "f16s": (L.snk_conv3x3_prepare_weights_f16s, L.snk_conv3x3_bn_f16s, 9 * 128 * 128 * 4 + 16),
-                      "f16": (L.snk_conv3x3_prepare_weights_f16s, L.snk_conv3x3_bn_f16, 9 * 128 * 128 * 4 + 16)}[algo]
+                      "f16s": (L.snk_conv3x3_prepare_weights_f16s, L.snk_conv3x3_bn_f16s, 9 * 128 * 128 * 4 + 32),
+                      "f16": (L.snk_conv3x3_prepare_weights_f16s, L.snk_conv3x3_bn_f16, 9 * 128 * 128 * 4 + 32)}[algo]
 torch.manual_seed(0)
 for n in sizes:
     for mag in (1.0, 1e-3) if n <= 64 else (1.0,):

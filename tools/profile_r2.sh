@@ -14,3 +14,6 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write --
 python3 $R/tools/pmc_summary.py $O/pmc_fetch FETCH_SIZE k_conv3x3_f16s
 python3 $R/tools/pmc_summary.py $O/pmc_write WRITE_SIZE k_conv3x3_f16s
 find $O -name "*kernel_stats.csv" | head -3
+# 3. BASELINE configs[0] (8 games, 25 sims; eager compacted tick) under the kernel trace: GPU-busy time per rollout tick
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/small -- python3 $R/bench.py --games 8 --breadth 25 --steps 30 --warmup 5 --no-cpu-baseline --no-kernel-rooflines --no-conv-timing > $O/small_under_rocprof.json 2> /dev/null
+find $O -name "*kernel_stats.csv"
