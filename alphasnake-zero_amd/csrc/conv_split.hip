@@ -81,9 +81,15 @@ extern "C" int snk_dbg_conv_stamps(unsigned long long *h_out, int n_blocks)
 #define hs_dpp(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
 // SPLIT = false: the reduced-precision form for BASELINE configs[4] ("bf16 MFMA conv"): the same kernel with the hi parts
 //   only, one MFMA per product instead of three (f16 operands: 11 significand bits against bf16's 8, float32 accumulate).
-template <int NI, int MODE, bool SPLIT = true>
+// IO16 (reduced-precision form only): bit 0 = the input and the residual are f16 arrays [n][H][W][128], bit 1 = the output
+//   is written as f16.  The activations of BASELINE configs[4]'s tower then cost 2 bytes in HBM instead of 4 (the f16 form
+//   with float32 activations is HBM-bound), staging is a plain copy (the values are f16 already: no scale, no clamp, no
+//   conversion) and the range guard has nothing to watch.
+template <int NI, int MODE, bool SPLIT = true, int IO16 = 0>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
 {
+    static_assert(IO16 == 0 || !SPLIT, "f16 activations only exist in the reduced-precision form");
+    constexpr bool IN16 = (IO16 & 1) != 0, OUT16 = (IO16 & 2) != 0;
     const bool has_res = MODE == 0 ? p.res != nullptr : MODE >= 2;
     const bool has_head = MODE == 0 ? p.w1x1 != nullptr : MODE == 3;
     const bool has_out = MODE == 0 ? p.out != nullptr : MODE != 3;
@@ -111,6 +117,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
     const int ry_lo = y_first == 0 ? 1 : 0, ry_hi = min(y_last + 1, p.Hd - 1) - (y_first - 1);   // LDS rows that exist in the image
     const int npx = (ry_hi - ry_lo + 1) * p.Wd;
     const float *xrow = p.x + ((long)img * p.Hd + (y_first - 1 + ry_lo)) * p.Wd * HS_C + 4 * (tid & 3);
+    const _Float16 *xrow16 = (const _Float16 *)p.x + ((long)img * p.Hd + (y_first - 1 + ry_lo)) * p.Wd * HS_C + 4 * (tid & 3);
     const int pix0 = tid >> 2;
     const float xs = p.wscale_inv[2];                      // activations are multiplied by this power of two before the split
     unsigned ldo[HS_NST];                                  // LDS byte offset (inside a buffer) of the thread's items
@@ -124,15 +131,19 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
         gof[k] = pix_ * HS_C;
     }
     float4 st[HS_NST];
+    f16x4 st16[HS_NST];
     f16x4 hi_t;
     float4 d_t;
     float amax = 0.f;                                      // largest |scaled input| this thread staged: 65504 = something was clamped
-#define HS_LOAD(c) _Pragma("unroll") for (int k_ = 0; k_ < HS_NST; ++k_) st[k_] = *(const float4 *)(xrow + gof[k_] + HS_KC * (c));
+#define HS_LOAD(c) _Pragma("unroll") for (int k_ = 0; k_ < HS_NST; ++k_) {                      \
+        if (IN16) st16[k_] = *(const f16x4 *)(xrow16 + gof[k_] + HS_KC * (c));                  \
+        else st[k_] = *(const float4 *)(xrow + gof[k_] + HS_KC * (c)); }
 // split of one staged float4 in two halves that sit in different MFMA regions (a region hides about 15 VALU instructions):
 //   A: clamp to the f16 range, hi = f16(v), d = v - hi;   B: lo = f16(d), both written to LDS
-#define HS_SPLIT_A(src)                                                                         \
+#define HS_SPLIT_A(kk)                                                                          \
+    if (IN16) { hi_t = st16[kk]; } else                                                         \
     {                                                                                           \
-        float4 v_ = src;                                                                        \
+        float4 v_ = st[kk];                                                                     \
         v_.x *= xs; v_.y *= xs; v_.z *= xs; v_.w *= xs;                                         \
         v_.x = __builtin_amdgcn_fmed3f(v_.x, -65504.f, 65504.f); v_.y = __builtin_amdgcn_fmed3f(v_.y, -65504.f, 65504.f); \
         v_.z = __builtin_amdgcn_fmed3f(v_.z, -65504.f, 65504.f); v_.w = __builtin_amdgcn_fmed3f(v_.w, -65504.f, 65504.f); \
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < HS_NST; ++k) { HS_SPLIT_A(st[k]) HS_SPLIT_B(k, 0) }
+    for (int k = 0; k < HS_NST; ++k) { HS_SPLIT_A(k) HS_SPLIT_B(k, 0) }
     __syncthreads();
 
     unsigned la[NI];                                       // LDS byte address (buffer 0, centre tap) of the lane's pixel in M tile i
@@ -206,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
                 {                                                                               \
                     const int tl_ = (s) * NI + i - (9 * NI - 2 * HS_NST);                       \
                     if (MORE && 9 * NI >= 2 * HS_NST && tl_ >= 0) {                             \
-                        if ((tl_ & 1) == 0) { HS_SPLIT_A(st[tl_ < 0 ? 0 : tl_ >> 1]) }          \
+                        if ((tl_ & 1) == 0) { HS_SPLIT_A((tl_ < 0 ? 0 : tl_ >> 1)) }            \
                         else { HS_SPLIT_B((tl_ < 0 ? 0 : tl_ >> 1), wb) }                       \
                     }                                                                           \
                 }                                                                               \
@@ -229,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
         HS_TAP(0, MORE) HS_TAP(1, MORE) HS_TAP(2, MORE) HS_TAP(3, MORE) HS_TAP(4, MORE)         \
         HS_TAP(5, MORE) HS_TAP(6, MORE) HS_TAP(7, MORE) HS_TAP(8, MORE)                         \
         if (MORE && 9 * NI < 2 * HS_NST) {              /* too few regions to spread the split over: do it here */ \
-            _Pragma("unroll") for (int k = 0; k < HS_NST; ++k) { HS_SPLIT_A(st[k]) HS_SPLIT_B(k, wb) } \
+            _Pragma("unroll") for (int k = 0; k < HS_NST; ++k) { HS_SPLIT_A(k) HS_SPLIT_B(k, wb) } \
         }                                                                                       \
         __syncthreads();                                                                        \
     }
@@ -279,8 +290,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
             off[(pass) & 1][j] = m_ < m1 ? m_ * HS_C : -1;                                      \
         }                                                                                       \
         if (has_res) {                                                                          \
-            _Pragma("unroll") for (int j = 0; j < HS_ROWS(pass) / 8; ++j)                       \
-                rv[(pass) & 1][j] = *(const float4 *)(p.res + obase + max(off[(pass) & 1][j], 0)); \
+            _Pragma("unroll") for (int j = 0; j < HS_ROWS(pass) / 8; ++j) {                     \
+                if (IN16) {                                                                     \
+                    const f16x4 r16_ = *(const f16x4 *)((const _Float16 *)p.res + obase + max(off[(pass) & 1][j], 0)); \
+                    rv[(pass) & 1][j] = make_float4((float)r16_[0], (float)r16_[1], (float)r16_[2], (float)r16_[3]); \
+                } else rv[(pass) & 1][j] = *(const float4 *)(p.res + obase + max(off[(pass) & 1][j], 0)); \
+            }                                                                                   \
         }                                                                                       \
     }
     HS_EPI_PREP(0)
@@ -309,7 +324,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
                 v.x += r_.x; v.y += r_.y; v.z += r_.z; v.w += r_.w;
             }
             v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
-            if (has_out && off[pass & 1][j] >= 0) *(float4 *)(p.out + obase + off[pass & 1][j]) = v;
+            if (has_out && off[pass & 1][j] >= 0) {
+                if (OUT16) {
+                    f16x4 o16_;
+                    o16_[0] = (_Float16)v.x; o16_[1] = (_Float16)v.y; o16_[2] = (_Float16)v.z; o16_[3] = (_Float16)v.w;
+                    *(f16x4 *)((_Float16 *)p.out + obase + off[pass & 1][j]) = o16_;
+                } else *(float4 *)(p.out + obase + off[pass & 1][j]) = v;
+            }
             if (has_head) {                 // the 32 lanes of this row hold its 128 outputs: reduce their dot product with w1x1
                 float d_ = (v.x * wh.x + v.y * wh.y) + (v.z * wh.z + v.w * wh.w);
                 // butterfly inside each 16-lane DPP row (quad swaps, half-row mirror, row mirror), then the other row of the 32
@@ -383,7 +404,7 @@ extern "C" int snk_conv3x3_prepare_weights_f16s(const float *d_w_hwio, void *d_w
 
 static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
                             const float *d_residual, float *d_out, const float *d_w1x1, float s1, float b1, float *d_h1,
-                            int n_images, int height, int width, int relu, bool split, void *stream)
+                            int n_images, int height, int width, int relu, bool split, void *stream, int io16 = 0)
 {
     SNK_REQUIRE(n_images >= 0 && height >= 1 && width >= 3, "snk_conv3x3_bn_f16s: bad shape %d x %d x %d", n_images, height, width);
     SNK_REQUIRE(d_out != d_x, "snk_conv3x3_bn_f16s: in-place convolution is not possible (blocks read their neighbours' input rows)");
@@ -417,6 +438,23 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
     hipStream_t st = (hipStream_t)stream;
     // the three epilogue shapes the net wrapper uses get compile-time versions at the 21x21 tile count; everything else
     // takes the generic version
+    if (!split && io16) {        // f16 activations in HBM (io16: 1 = f16 in, f32 out; 3 = f16 in and out)
+#define HS_LAUNCH_IO(NI_)                                                                       \
+    case NI_:                                                                                   \
+        if (io16 == 3) k_conv3x3_f16s<NI_, 0, false, 3><<<grid, 256, 0, st>>>(a);               \
+        else k_conv3x3_f16s<NI_, 0, false, 1><<<grid, 256, 0, st>>>(a);                         \
+        break;
+        switch (n_mt) {
+            HS_LAUNCH_IO(1) HS_LAUNCH_IO(2) HS_LAUNCH_IO(3) HS_LAUNCH_IO(4) HS_LAUNCH_IO(5) HS_LAUNCH_IO(6) HS_LAUNCH_IO(7)
+        default:
+            if (io16 == 3) k_conv3x3_f16s<8, 0, false, 3><<<grid, 256, 0, st>>>(a);
+            else k_conv3x3_f16s<8, 0, false, 1><<<grid, 256, 0, st>>>(a);
+            break;
+        }
+#undef HS_LAUNCH_IO
+        SNK_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     if (!split) {
         switch (n_mt) {
         case 1: k_conv3x3_f16s<1, 0, false><<<grid, 256, 0, st>>>(a); break;
@@ -479,4 +517,16 @@ extern "C" int snk_conv3x3_bn_f16s_head(const float *d_x, const void *d_wS, cons
     SNK_REQUIRE(d_x && d_wS && d_scale && d_shift && d_w1x1 && d_h1, "snk_conv3x3_bn_f16s_head: NULL argument");
     return conv_f16s_launch(d_x, d_wS, d_scale, d_shift, d_residual, d_out, d_w1x1, bn_scale, bn_shift, d_h1, n_images, height,
                             width, 1, true, stream);
+}
+
+// reduced precision with f16 activations in HBM (BASELINE configs[4]): d_x16 / d_residual16 are f16 [n][H][W][128]; the output
+// is f16 (out_f16 != 0: every tower layer but the last) or float32 (the layer the head reads).  Weights: the image
+// snk_conv3x3_prepare_weights_f16s makes with x_scale = 1.
+extern "C" int snk_conv3x3_bn_f16_act16(const void *d_x16, const void *d_wS, const float *d_scale, const float *d_shift,
+                                        const void *d_residual16, void *d_out, int out_f16, int n_images, int height, int width,
+                                        int relu, void *stream)
+{
+    SNK_REQUIRE(d_x16 && d_wS && d_scale && d_shift && d_out, "snk_conv3x3_bn_f16_act16: NULL argument");
+    return conv_f16s_launch((const float *)d_x16, d_wS, d_scale, d_shift, (const float *)d_residual16, (float *)d_out, nullptr, 0.f,
+                            0.f, nullptr, n_images, height, width, relu, false, stream, out_f16 ? 3 : 1);
 }

@@ -652,6 +652,7 @@ __global__ __launch_bounds__(256) void k_stem_conv(StemArgs p)
 // (the gather of k_stem_conv costs as many instructions as its FMAs: 2.3 TB/s of output, round 1).  Thread
 // (pg = tid / 32, cq = tid % 32) computes outputs 4 cq .. 4 cq + 3 of pixels pg, pg + 8, ...; its 27 x 4 weights stay in
 // registers; the 32 lanes of a pixel write its 512-byte row.  Same tap order as k_stem_conv: identical sums.
+template <bool OUT16>          // OUT16: the output activations are written as f16 (the reduced-precision tower with f16 activations)
 __global__ __launch_bounds__(256) void k_stem_conv_img(StemArgs p)
 {
     extern __shared__ __align__(16) float st_img[];
@@ -672,6 +673,7 @@ __global__ __launch_bounds__(256) void k_stem_conv_img(StemArgs p)
     }
     const float4 sc = *(const float4 *)(p.scale + 4 * cq), sh = *(const float4 *)(p.shift + 4 * cq);
     float *out = p.out + (long)blockIdx.x * HW * CV_C + 4 * cq;
+    _Float16 *out16 = (_Float16 *)p.out + (long)blockIdx.x * HW * CV_C + 4 * cq;
     __syncthreads();
     int y = pg / Wd, x = pg - y * Wd;
     for (int px = pg; px < HW; px += 8) {
@@ -688,7 +690,12 @@ __global__ __launch_bounds__(256) void k_stem_conv_img(StemArgs p)
         float4 v;
         v.x = fmaxf(alo.x * sc.x + sh.x, 0.f); v.y = fmaxf(alo.y * sc.y + sh.y, 0.f);
         v.z = fmaxf(ahi.x * sc.z + sh.z, 0.f); v.w = fmaxf(ahi.y * sc.w + sh.w, 0.f);
-        *(float4 *)(out + (long)px * CV_C) = v;
+        if (OUT16) {
+            typedef _Float16 st_f16x4 __attribute__((ext_vector_type(4)));
+            st_f16x4 o_;
+            o_[0] = (_Float16)v.x; o_[1] = (_Float16)v.y; o_[2] = (_Float16)v.z; o_[3] = (_Float16)v.w;
+            *(st_f16x4 *)(out16 + (long)px * CV_C) = o_;
+        } else *(float4 *)(out + (long)px * CV_C) = v;
         x += 8;
         while (x >= Wd) { x -= Wd; ++y; }
     }
@@ -900,8 +907,24 @@ extern "C" int snk_stem_conv_bn_relu_f32(const float *d_x, const float *d_w, con
     SNK_REQUIRE(M < (1l << 31), "snk_stem_conv_bn_relu_f32: batch too large");
     StemArgs a = {d_x, d_w, d_scale, d_shift, d_out, (int)M, height, width};
     const size_t lds = (size_t)(height + 2) * (width + 2) * 3 * sizeof(float);
-    if (lds <= 64 * 1024) k_stem_conv_img<<<n_images, 256, lds, (hipStream_t)stream>>>(a);
+    if (lds <= 64 * 1024) k_stem_conv_img<false><<<n_images, 256, lds, (hipStream_t)stream>>>(a);
     else k_stem_conv<<<(int)((M + ST_PX - 1) / ST_PX), 256, 0, (hipStream_t)stream>>>(a);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// the same with the output written as f16 [n][H][W][128] (input of snk_conv3x3_bn_f16_act16)
+extern "C" int snk_stem_conv_bn_relu_f16out(const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,
+                                            void *d_out16, int n_images, int height, int width, void *stream)
+{
+    SNK_REQUIRE(d_x && d_w && d_scale && d_shift && d_out16, "snk_stem_conv_bn_relu_f16out: NULL argument");
+    if (n_images <= 0) return 0;
+    const long M = (long)n_images * height * width;
+    SNK_REQUIRE(M < (1l << 31), "snk_stem_conv_bn_relu_f16out: batch too large");
+    const size_t lds = (size_t)(height + 2) * (width + 2) * 3 * sizeof(float);
+    SNK_REQUIRE(lds <= 64 * 1024, "snk_stem_conv_bn_relu_f16out: observation %d x %d too large", height, width);
+    StemArgs a = {d_x, d_w, d_scale, d_shift, (float *)d_out16, (int)M, height, width};
+    k_stem_conv_img<true><<<n_images, 256, lds, (hipStream_t)stream>>>(a);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -61,6 +61,8 @@ PROTOTYPES = {
     "snk_conv3x3_bn_f16s": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "snk_conv3x3_bn_f16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "snk_conv3x3_bn_f16s_head": (i32, [vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, i32, i32, i32, vp]),
+    "snk_conv3x3_bn_f16_act16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "snk_stem_conv_bn_relu_f16out": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "snk_head_dense_f32": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "snk_stem_conv_bn_relu_f32": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "snk_tt_create": (i32, [C.POINTER(vp), u64, i32]),

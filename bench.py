@@ -68,7 +68,7 @@ def cpu_baseline(weights, breadth, n_games=16, n_turns=2):
         e = CpuSelfPlay(seeded_games(64 * thr, seed=2), net=None, threads=thr, base=2, training=True, max_depth=8,
                         max_breadth=breadth, seed=2)
         t1 = time.time()
-        es = e.run(max_turns=2)
+        es = e.run(max_turns=2 if thr == 1 else 6)       # about a second of work either way
         eng[thr] = es["env_steps"] / (time.time() - t1)
         e.close()
     return {"value": st["env_steps"] / dt, "unit": "env-steps/s", "cores": cpus, "kind": "port",
@@ -78,7 +78,7 @@ def cpu_baseline(weights, breadth, n_games=16, n_turns=2):
                       f"(os.cpu_count() = {os.cpu_count()}, usable = {cpus})",
             "net_evals_per_s": st["net_evals"] / dt,
             "engine_only_env_steps_per_s": {f"{k}_threads": v for k, v in eng.items()},
-            "engine_only_note": "stub net inside the C code (zero net cost), 64 games per thread x 2 root turns: what the "
+            "engine_only_note": "stub net inside the C code (zero net cost), 64 games per thread x 2 (1 thread) / 6 (all threads) root turns: what the "
                                 "reference's Python loop does at 6.5 env-steps/s per core with a stub net (BASELINE.md)"}
 
 

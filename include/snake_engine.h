@@ -208,6 +208,15 @@ int snk_conv3x3_bn_f16(const float *d_x, const void *d_wS, const float *d_scale,
 int snk_conv3x3_bn_f16s_head(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
                              const float *d_residual, float *d_out, const float *d_w1x1, float bn_scale,
                              float bn_shift, float *d_h1, int n_images, int height, int width, void *stream);
+/* Reduced precision with f16 ACTIVATIONS in HBM (BASELINE configs[4], "bf16-class MFMA conv"; outside the 1e-5
+ * tolerance, never the default): d_x16 / d_residual16 are f16 [n][H][W][128] arrays, the output is f16 (out_f16 != 0:
+ * every tower layer but the last) or float32 (the layer the head reads); weights = snk_conv3x3_prepare_weights_f16s
+ * with x_scale 1.  snk_stem_conv_bn_relu_f16out is the stem that feeds it.                                       */
+int snk_conv3x3_bn_f16_act16(const void *d_x16, const void *d_wS, const float *d_scale, const float *d_shift,
+                             const void *d_residual16, void *d_out, int out_f16, int n_images, int height, int width,
+                             int relu, void *stream);
+int snk_stem_conv_bn_relu_f16out(const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,
+                                 void *d_out16, int n_images, int height, int width, void *stream);
 int snk_head_dense_f32(const float *d_h1, const float *d_fc1_w, const float *d_fc1_b, const float *d_fc2_w,
                        const float *d_fc2_b, const uint8_t *d_mask, float *d_q, int n_images, int height, int width,
                        void *stream);

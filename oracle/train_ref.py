@@ -147,3 +147,26 @@ def train_steps(weights, X, Y, lrs):
             ws[k + 4] = ws[k + 4] * BN_MOMENTUM + v * (n / max(n - 1.0, 1.0)) * (1 - BN_MOMENTUM)
         opt.step(ws, grads, lr)
     return ws, losses
+
+
+def forward_eval(weights, X):
+    """AlphaNNet.v_net.predict in float64 NumPy (inference-mode batch norm, alpha_nnet.py:19-56): a second,
+    code-independent statement of what oracle/net_ref.py (PyTorch) computes; tests/test_net_host_cpu.py compares the two.
+    Returns the unmasked (N, 3) outputs."""
+    ws = [np.asarray(w, np.float64) for w in weights]
+    blocks = (len(ws) - 14) // 10
+
+    def cbn(x, i):
+        y = _conv_fwd(x, ws[i])
+        return ws[i + 1] * (y - ws[i + 3]) / np.sqrt(ws[i + 4] + BN_EPS) + ws[i + 2]
+    h = np.maximum(cbn(np.asarray(X, np.float64), 0), 0.0)
+    i = 5
+    for _ in range(blocks):
+        sc = h
+        h = np.maximum(cbn(h, i), 0.0)
+        h = np.maximum(cbn(h, i + 5) + sc, 0.0)
+        i += 10
+    h = np.maximum(cbn(h, i), 0.0)
+    flat = h.reshape(h.shape[0], -1)
+    a1 = np.maximum(flat @ ws[i + 5] + ws[i + 6], 0.0)
+    return np.tanh(a1 @ ws[i + 7] + ws[i + 8])

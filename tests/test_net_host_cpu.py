@@ -41,3 +41,31 @@ def test_activation_scales_are_powers_of_two_with_headroom():
     assert sc2[0] * 850.0 <= 2 ** 9 < sc2[0] * 850.0 * 2
     assert sc2[1] == sc[1]                     # the second layer's input is bounded by the first block's own batch-norm
     assert sc2[2] < sc[2]                      # ... but the block output adds the shortcut's bound
+
+
+def test_torch_net_oracle_agrees_with_the_numpy_restatement():
+    """oracle/net_ref.py (PyTorch fp32, the checker of "Q within 1e-5") against oracle/train_ref.py::forward_eval (explicit
+    float64 NumPy loops): two statements of the Keras graph that share no code agree to float32 rounding, on the gen-0 net
+    and on a net with randomised batch-norm statistics, 11x11 observations from the reference's goldens"""
+    import numpy as np
+    from conftest import load_golden
+    from oracle import net_ref, train_ref
+    from snake_engine.net import glorot_uniform_weights
+    X = load_golden("states_11x11x4.npz")["raw"][:24]
+    rng = np.random.RandomState(3)
+    ws = glorot_uniform_weights((21, 21, 3), blocks=4, seed=0)
+    for randomise in (False, True):
+        if randomise:
+            k = 0
+            while k < len(ws):
+                if ws[k].ndim == 4:
+                    n = ws[k].shape[3]
+                    ws[k + 1] = (1.0 + 0.2 * rng.randn(n)).astype(np.float32); ws[k + 2] = (0.1 * rng.randn(n)).astype(np.float32)
+                    ws[k + 3] = (0.05 * rng.randn(n)).astype(np.float32); ws[k + 4] = (0.5 + rng.rand(n)).astype(np.float32)
+                    k += 5
+                else:
+                    k += 1
+        a = net_ref.forward(ws, X, apply_mask=False)
+        b = train_ref.forward_eval(ws, X)
+        assert np.abs(a - b).max() <= 2e-6, np.abs(a - b).max()
+        assert len(np.unique(np.round(b, 4))) > 20
