@@ -211,7 +211,7 @@ def main():
     ap.add_argument("--games", type=int, default=4096, help="parallel root games per GPU")
     ap.add_argument("--breadth", type=int, default=50)
     ap.add_argument("--chunk", type=int, default=8192, help="states per net forward chunk")
-    ap.add_argument("--conv-algo", choices=["winograd", "direct", "bf16", "f16s", "f16"], default=None,
+    ap.add_argument("--conv-algo", choices=["winograd", "direct", "bf16", "f16s", "f16", "f16a"], default=None,
                     help="default: f16s (float32-accurate split-f16 MFMA, the judged configuration); winograd, direct: f32 MFMA; bf16 = configs[4]-style bf16 MFMA, outside the 1e-5 tolerance")
     ap.add_argument("--board", type=int, default=11, choices=[7, 11, 19], help="board side; 19 with --snakes 8 --blocks 10 = BASELINE configs[4]")
     ap.add_argument("--snakes", type=int, default=4)
@@ -315,9 +315,9 @@ def main():
         conv_flops = sum(f for _, _, f in tm)
         achieved = conv_flops / conv_s / 1e12 if conv_s > 0 else None      # None: --no-conv-timing
         algo = nnet._qnet.conv_algo
-        peak = 2500.0 if algo in ("bf16", "f16s", "f16") else 157.3      # dense MFMA peaks (bf16 / f16, f32), MI355X_MICROARCH.md
+        peak = 2500.0 if algo in ("bf16", "f16s", "f16", "f16a") else 157.3      # dense MFMA peaks (bf16 / f16, f32), MI355X_MICROARCH.md
         # MFMA flops the kernel executes per algorithmic (direct-convolution) flop
-        executed = {"f16s": 3.0 * 448 / 441, "f16": 448 / 441.0, "winograd": 16 * 121 / (441 * 9.0)}.get(algo, 1.0)
+        executed = {"f16s": 3.0 * 448 / 441, "f16": 448 / 441.0, "f16a": 448 / 441.0, "winograd": 16 * 121 / (441 * 9.0)}.get(algo, 1.0)
         traffic = None      # HBM bytes per average launch, from the committed rocprofv3 --pmc passes (profiles/)
         tfile = os.path.join(REPO, "profiles", {"f16s": "r2_conv_f16s_traffic.json", "winograd": "r1_conv_traffic.json"}.get(algo, "none"))
         if os.path.exists(tfile) and tm:
@@ -329,6 +329,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"bf16": "bf16 operands, f32 accumulate (outside the 1e-5 parity tolerance)",
                       "f16": "f16 operands, f32 accumulate (outside the 1e-5 parity tolerance)",
+                      "f16a": "f16 operands and f16 activations in HBM, f32 accumulate (outside the 1e-5 parity tolerance)",
                       "f16s": "f32 (tower convolutions: each f32 operand split into f16 hi + lo, 3 f16 MFMAs per product, f32 accumulate)"}.get(algo, "f32"),
             "data": "synthetic",
             "config": {"workload": f"{workload_label(B, args.snakes, args.blocks, args.games, args.breadth, world)}: "
@@ -341,7 +342,8 @@ def main():
                        "graph_replays": m.stats.get("graph_replays", 0)},
             "roofline": {"bound": "mfma",
                          "kernel": {"winograd": "k_conv3x3_wino_f32", "bf16": "k_conv3x3_bf16", "f16s": "k_conv3x3_f16s",
-                                    "f16": "k_conv3x3_f16s<SPLIT = false>"}.get(algo, "k_conv3x3_f32"),
+                                    "f16": "k_conv3x3_f16s<SPLIT = false>",
+                                    "f16a": "k_conv3x3_f16s<SPLIT = false, IO16>"}.get(algo, "k_conv3x3_f32"),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak if achieved else None, "traffic": traffic, "launches": len(tm),
                          "flops_convention": "algorithmic = direct 3x3 convolution, 2*441*1152*128 per state and layer (SURVEY 8d)",
@@ -350,6 +352,7 @@ def main():
                                                    "algorithmic flops, fp32 throughout",
                                        "bf16": "implicit GEMM on v_mfma_f32_32x32x16_bf16",
                                        "f16": "implicit GEMM on v_mfma_f32_32x32x16_f16, f16-rounded operands (reduced precision)",
+                                       "f16a": "implicit GEMM on v_mfma_f32_32x32x16_f16, f16 operands, f16 activations in HBM (reduced precision)",
                                        "f16s": "implicit GEMM on v_mfma_f32_32x32x16_f16 with split operands: executes 3 (hi*hi, hi*lo, lo*hi) "
                                                "x 448/441 (M-tile padding) = 3.05 MFMA flops per algorithmic flop; peak = dense f16 MFMA "
                                                "at 2.4 GHz, the chip holds ~1.55 GHz in this loop on random data (DESIGN.md section 4)"}.get(

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 BN_EPS = 1e-3
 
 
-def forward(weights, states, legacy_mask=False, apply_mask=True, bf16_conv=False):
+def forward(weights, states, legacy_mask=False, apply_mask=True, bf16_conv=False, f16_act=False):
     """weights: list in Keras get_weights() order (snake_engine/net.py docstring); states (N,h,w,3) float32.
     Returns (N,3) float32 numpy: AlphaNNet.v(states)."""
     x_np = np.ascontiguousarray(states, np.float32)
@@ -29,13 +29,23 @@ def forward(weights, states, legacy_mask=False, apply_mask=True, bf16_conv=False
 
     def bn(x, g, b, m, v):
         return F.batch_norm(x, m, v, g, b, training=False, eps=BN_EPS)
+    def r16(v):      # f16_act: the tower's activations live in HBM as f16 (round to nearest even), the last layer's output stays float32
+        return v.to(torch.float16).to(torch.float32) if f16_act else v
+
+    def conv16(x, k):   # ... and the tower convolutions take f16-rounded weights (scaled by the power of two that brings max|w| to [256, 512))
+        if not f16_act:
+            return conv(x, k, bf16_conv)
+        sc_ = 2.0 ** (8 - int(np.floor(np.log2(float(k.abs().max())))))
+        return conv(x, (k * sc_).to(torch.float16).to(torch.float32) / sc_)
     with torch.no_grad():
-        h = F.relu(bn(conv(x, t[0]), *t[1:5]))
+        h = r16(F.relu(bn(conv(x, t[0]), *t[1:5])))
         for blk in range(blocks):
             b0 = 5 + 10 * blk
             sc = h
-            h = F.relu(bn(conv(h, t[b0], bf16_conv), *t[b0 + 1:b0 + 5]))
-            h = F.relu(bn(conv(h, t[b0 + 5], bf16_conv), *t[b0 + 6:b0 + 10]) + sc)
+            h = r16(F.relu(bn(conv16(h, t[b0]), *t[b0 + 1:b0 + 5])))
+            h = F.relu(bn(conv16(h, t[b0 + 5]), *t[b0 + 6:b0 + 10]) + sc)
+            if blk + 1 < blocks:
+                h = r16(h)
         b0 = 5 + 10 * blocks
         h = F.relu(bn(conv(h, t[b0]), *t[b0 + 1:b0 + 5]))              # (N,1,h,w)
         h = h.permute(0, 2, 3, 1).reshape(h.shape[0], -1)              # Flatten in HWC order

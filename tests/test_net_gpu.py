@@ -445,3 +445,57 @@ def test_agent_calibrates_new_weights_and_checks_the_range_every_turn(env, monke
     gr = MPGameRunner(11, 11, 4, 1, 8, seed=5)
     gr.run(alice, max_turns=2)
     assert nn_._qnet.calibrated and nn_._qnet.range_flags() == [0] * 8 and gr.env_steps == 16
+
+
+def test_f16_activation_tower_layer_and_net(env, monkeypatch):
+    """configs[4]'s fastest reduced-precision option (`SNK_CONV_ALGO=f16a`): f16 operands AND f16 activations in HBM.
+    One layer against a float64 convolution of the same f16 inputs (f16 output: within half an f16 ulp + float32 rounding;
+    float32 output: float32 rounding); the whole net against the CPU restatement with the same rounding points
+    (oracle/net_ref.py f16_act=True) to 1e-4, and within 5e-3 of the float32 net."""
+    torch, se, net = env
+    from snake_engine._lib import lib, check
+    from snake_engine.net import F16S_WEIGHT_BYTES
+    from oracle import net_ref
+    L = lib()
+    g = torch.Generator().manual_seed(33)
+    for n, hw in ((3, 21), (2, 37)):
+        x = (torch.randn(n, hw, hw, 128, generator=g)).to(torch.float16)
+        r = (torch.randn(n, hw, hw, 128, generator=g)).to(torch.float16)
+        w = torch.randn(3, 3, 128, 128, generator=g) * 0.05
+        sc, sh = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.1
+        ws_ = 2.0 ** (8 - int(torch.floor(torch.log2(w.abs().max())).item()))
+        wh = (w * ws_).to(torch.float16).double() / ws_
+        ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), wh.permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1)
+        ref = (ref * sc.double() + sh.double() + r.double()).clamp_min(0)
+        xd, rd, wd, scd, shd = x.cuda(), r.cuda(), w.cuda().contiguous(), sc.cuda(), sh.cuda()
+        wS = torch.empty(F16S_WEIGHT_BYTES, dtype=torch.uint8, device="cuda")
+        check(L.snk_conv3x3_prepare_weights_f16s(wd.data_ptr(), wS.data_ptr(), C.c_float(1.0), _st()))
+        o32 = torch.full((n, hw, hw, 128), float("nan"), device="cuda")
+        check(L.snk_conv3x3_bn_f16_act16(xd.data_ptr(), wS.data_ptr(), scd.data_ptr(), shd.data_ptr(), rd.data_ptr(),
+                                         o32.data_ptr(), 0, n, hw, hw, 1, _st()))
+        scale = ref.abs().max().item()
+        assert (o32.cpu().double() - ref).abs().max().item() <= 2e-5 * scale
+        o16 = torch.full((n, hw, hw, 128), float("nan"), dtype=torch.float16, device="cuda")
+        check(L.snk_conv3x3_bn_f16_act16(xd.data_ptr(), wS.data_ptr(), scd.data_ptr(), shd.data_ptr(), rd.data_ptr(),
+                                         o16.data_ptr(), 1, n, hw, hw, 1, _st()))
+        got = o16.cpu()
+        assert torch.isfinite(got).all()
+        # the f16 output is the float32 result rounded once: equal to rounding the float64 reference except where the two
+        # straddle a rounding boundary (then one f16 ulp apart)
+        want = ref.to(torch.float16)
+        ulp = (got.double() - want.double()).abs() / torch.clamp(want.double().abs(), min=2.0 ** -14) 
+        assert (ulp <= 2.0 ** -10).all() and (got == want).float().mean().item() > 0.99
+    monkeypatch.setenv("SNK_CONV_ALGO", "f16a")
+    s = load_golden("states_11x11x4.npz")
+    states = s["raw"][:64]
+    wsn = _randomised_bn(net.glorot_uniform_weights((21, 21, 3), blocks=4, seed=0), 5)
+    qn = net.QNet(wsn, (21, 21, 3), max_chunk=40)
+    got = qn.forward(torch.as_tensor(states, device="cuda")).cpu().numpy()
+    same = net_ref.forward(wsn, states, apply_mask=False, f16_act=True)
+    full = net_ref.forward(wsn, states, apply_mask=False)
+    assert np.abs(got - same).max() <= 1e-4, np.abs(got - same).max()
+    assert np.abs(got - full).max() <= 5e-3, np.abs(got - full).max()
+    s19 = load_golden("states_19x19x8.npz")
+    ws19 = _randomised_bn(net.glorot_uniform_weights((37, 37, 3), blocks=10, seed=1), 4)
+    got19 = net.QNet(ws19, (37, 37, 3)).forward(torch.as_tensor(s19["raw"][:6], device="cuda")).cpu().numpy()
+    assert np.abs(got19 - net_ref.forward(ws19, s19["raw"][:6], apply_mask=False, f16_act=True)).max() <= 2e-4
