@@ -14,6 +14,22 @@ prep, conv, wbytes = {"winograd": (L.snk_conv3x3_prepare_weights_winograd, L.snk
                       "bf16": (L.snk_conv3x3_prepare_weights_bf16, L.snk_conv3x3_bn_bf16, 9 * 128 * 128 * 2),
                       "f16s": (L.snk_conv3x3_prepare_weights_f16s, L.snk_conv3x3_bn_f16s, 9 * 128 * 128 * 4 + 32),
                       "f16": (L.snk_conv3x3_prepare_weights_f16s, L.snk_conv3x3_bn_f16, 9 * 128 * 128 * 4 + 32)}[algo]
+if algo == "f16a":      # f16 activations in HBM: time only (tests/test_net_gpu.py checks the values)
+    for n in sizes:
+        x = torch.randn(n, H, H, 128, device="cuda").to(torch.float16); o = torch.empty_like(x)
+        w = torch.randn(3, 3, 128, 128, device="cuda") * 0.05; U = torch.empty(9 * 128 * 128 * 4 + 32, dtype=torch.uint8, device="cuda")
+        sc = torch.rand(128, device="cuda") + 0.5; sh = torch.randn(128, device="cuda")
+        check(L.snk_conv3x3_prepare_weights_f16s(w.data_ptr(), U.data_ptr(), 1.0, st))
+        f = lambda: check(L.snk_conv3x3_bn_f16_act16(x.data_ptr(), U.data_ptr(), sc.data_ptr(), sh.data_ptr(), x.data_ptr(), o.data_ptr(), 1, n, H, H, 1, st))
+        for _ in range(3): f()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20): f()
+        b.record(); torch.cuda.synchronize()
+        t = a.elapsed_time(b) / 20 * 1e-3
+        print(f"f16a {H}x{H} n={n}: {t*1e3:.3f} ms  {2*n*H*H*1152*128/t/1e12:.1f} TF-equiv", flush=True)
+    sys.exit(0)
 torch.manual_seed(0)
 for n in sizes:
     for mag in (1.0, 1e-3) if n <= 64 else (1.0,):
