@@ -9,11 +9,6 @@ L = lib(); st = torch.cuda.current_stream().cuda_stream
 algo = sys.argv[1] if len(sys.argv) > 1 else "winograd"
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 21
 sizes = [int(v) for v in sys.argv[3:]] or [64, 512, 4096]
-prep, conv, wbytes = {"winograd": (L.snk_conv3x3_prepare_weights_winograd, L.snk_conv3x3_bn_f32_winograd, 16 * 128 * 128 * 4),
-                      "direct": (L.snk_conv3x3_prepare_weights, L.snk_conv3x3_bn_f32, 9 * 128 * 128 * 4),
-                      "bf16": (L.snk_conv3x3_prepare_weights_bf16, L.snk_conv3x3_bn_bf16, 9 * 128 * 128 * 2),
-                      "f16s": (L.snk_conv3x3_prepare_weights_f16s, L.snk_conv3x3_bn_f16s, 9 * 128 * 128 * 4 + 32),
-                      "f16": (L.snk_conv3x3_prepare_weights_f16s, L.snk_conv3x3_bn_f16, 9 * 128 * 128 * 4 + 32)}[algo]
 if algo == "f16a":      # f16 activations in HBM: time only (tests/test_net_gpu.py checks the values)
     for n in sizes:
         x = torch.randn(n, H, H, 128, device="cuda").to(torch.float16); o = torch.empty_like(x)
@@ -30,6 +25,11 @@ if algo == "f16a":      # f16 activations in HBM: time only (tests/test_net_gpu.
         t = a.elapsed_time(b) / 20 * 1e-3
         print(f"f16a {H}x{H} n={n}: {t*1e3:.3f} ms  {2*n*H*H*1152*128/t/1e12:.1f} TF-equiv", flush=True)
     sys.exit(0)
+prep, conv, wbytes = {"winograd": (L.snk_conv3x3_prepare_weights_winograd, L.snk_conv3x3_bn_f32_winograd, 16 * 128 * 128 * 4),
+                      "direct": (L.snk_conv3x3_prepare_weights, L.snk_conv3x3_bn_f32, 9 * 128 * 128 * 4),
+                      "bf16": (L.snk_conv3x3_prepare_weights_bf16, L.snk_conv3x3_bn_bf16, 9 * 128 * 128 * 2),
+                      "f16s": (L.snk_conv3x3_prepare_weights_f16s, L.snk_conv3x3_bn_f16s, 9 * 128 * 128 * 4 + 32),
+                      "f16": (L.snk_conv3x3_prepare_weights_f16s, L.snk_conv3x3_bn_f16, 9 * 128 * 128 * 4 + 32)}[algo]
 torch.manual_seed(0)
 for n in sizes:
     for mag in (1.0, 1e-3) if n <= 64 else (1.0,):
