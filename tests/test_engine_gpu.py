@@ -423,7 +423,8 @@ def test_error_codes_and_empty_inputs(se):
     assert L.snk_engine_create(C.byref(h), 4, 11, 11, 9, 1, 0.15, 1, 0) < 0 and b"snake count" in L.snk_last_error()
     assert L.snk_engine_create(C.byref(h), 0, 11, 11, 4, 1, 0.15, 1, 0) < 0
     with pytest.raises(EngineError):
-        se.Engine(4, 13, 13, 4)
+        se.Engine(4, 13, 12, 4)
+    assert se.Engine(4, 13, 13, 4).slot_bytes > 0            # any square board from 5x5 to 19x19 exists
     eng = se.Engine(8, 11, 11, 4)
     eng.reset()
     mv = eng.new((16, 4), torch.uint8, 1)
