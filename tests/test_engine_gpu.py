@@ -312,6 +312,55 @@ def test_clone_fanout(se):
         assert_state_equal(compact_from_state(out[i]), dict(golden_state(z, idx[i]), counters=np.zeros(6, np.int32)), f"clone-to {i}")
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_geometries_track_the_oracle(se, oracle, seed):
+    """differential run over board sizes and snake counts nobody picked by hand: device reset (Philox start boards), random
+    moves, device food spawns; the C oracle replays every tick from the device's spawn decisions -- whole states equal
+    after every tick, observations / masks / keys equal at the end (the run-time-geometry kernels included)"""
+    import torch
+    from snake_engine.engine import compact_from_state
+    from oracle.obs_key import obs_key, obstacle_mask
+    rng = np.random.RandomState(100 + seed)
+    for _ in range(4):
+        hw = int(rng.randint(5, 20))
+        S = int(rng.randint(2, 9))
+        hd = int(rng.choice([1, 3, 9]))
+        n, T = 48, 25
+        eng = se.Engine(n, hw, hw, S, hd, 0.15, seed=int(rng.randint(1 << 30)))
+        eng.reset()
+        start = eng.export()
+        games = [oracle.Game.from_compact(hw, hw, S, hd, 0.15, compact_from_state(start[g])) for g in range(n)]
+        for g in range(n):                                   # a legal start: S distinct standard cells, centre food
+            st = compact_from_state(start[g])
+            assert st["alive"].sum() == S and len({int(st["nodes"][s, 0]) for s in range(S)}) == S
+            assert st["food"][(hw // 2) * hw + hw // 2] == 1
+        spawned = eng.new((n,), torch.int16, 0)
+        for t in range(T):
+            mv = rng.randint(0, 3, size=(n, S)).astype(np.uint8)
+            mv[rng.rand(n, S) < 0.5] = 1
+            eng.step(torch.as_tensor(mv, device="cuda"), spawned=spawned)
+            sp = spawned.cpu().numpy()
+            out = eng.export()
+            for g in range(n):
+                if sum(games[g].g.alive[:S]) > 1:
+                    games[g].tic(mv[g], spawn_cell=int(sp[g]))
+                a, b = compact_from_state(out[g]), games[g].compact()
+                for k in a:
+                    assert np.array_equal(a[k], b[k]), (hw, S, t, g, k)
+        alive = eng.alive().cpu().numpy()
+        pairs = np.argwhere(alive).astype(np.int32)
+        if len(pairs) == 0:
+            continue
+        planes, mask, key = eng.observe_all(pairs)
+        ph, mh, kh = planes.cpu().numpy(), mask.cpu().numpy(), key.cpu().numpy().view(np.uint64)
+        for i, (g, s_) in enumerate(pairs):
+            ref = games[g].make_state(int(s_))
+            assert ph[i].tobytes() == ref.tobytes(), (hw, S, g, s_)
+            assert np.array_equal(mh[i].astype(bool), obstacle_mask(ref)[0]) and np.array_equal(kh[i], obs_key(ref)[0])
+        _, mask2, key2 = eng.observe_all(pairs, want_planes=False)           # the four-per-wavefront form
+        assert torch.equal(mask2, mask) and torch.equal(key2, key)
+
+
 def test_device_rng_spawn_replays_on_the_oracle(se, oracle):
     """device-RNG food spawn: legal (inside the oracle's empty set), ~15 % rate, and the whole run replays
     bit-exactly on the CPU oracle when the oracle is fed the device's spawn decisions as a tape"""
