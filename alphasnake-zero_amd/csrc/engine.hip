@@ -24,15 +24,6 @@ extern "C" int snk_version(void) { return 100; }
 
 #define WAVES_PER_BLOCK 4
 #define BLOCK_THREADS (WAVES_PER_BLOCK * 64)
-// Every game / observation lives in LDS that only its own wavefront touches, and a wavefront's LDS instructions execute in
-// program order: what the phases of a kernel need between them is that order (a compiler fence), not a workgroup barrier
-// that makes four unrelated wavefronts wait for each other.
-#define WAVE_SYNC()                                                     \
-    do {                                                                \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          \
-        __builtin_amdgcn_wave_barrier();                                \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");          \
-    } while (0)
 
 // Kernels are templated on the board side: 11x11, 7x7 and 19x19 (the BASELINE configs) get compile-time geometry; any
 // other square board runs the same code with the geometry read from the Layout: <0, 0> for boards of at most 255 cells
@@ -101,7 +92,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
     if (valid)
         for (int i = sl; i < L.stride / 16; i += GL) ((uint4 *)g)[i] = ((const uint4 *)gsrc)[i];
     for (int i = sl * 4; i < 2 * L.nc_pad; i += GL * 4) *(uint32_t *)(occ + i) = 0u;
-    WAVE_SYNC();
+    __syncthreads();
 
     SnakeMeta *meta = (SnakeMeta *)(g + L.meta_off);
     uint64_t *food = (uint64_t *)(g + L.food_off);
@@ -155,7 +146,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
         const int co = GSHFL(head_cell, o);
         if (eo && sl == 0) food[co >> 6] &= ~(1ull << (co & 63));
     }
-    WAVE_SYNC();
+    __syncthreads();
 
     // ---- Game.bodies / Game.heads as LDS byte planes, rebuilt from the rings by all lanes of the game
     for (int s = 0; s < S; ++s) {
@@ -168,7 +159,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
         }
     }
     if (go && !oob) hd[head_cell] = 1;
-    WAVE_SYNC();
+    __syncthreads();
 
     // ---- spawn food (game.py:130-138).  The game's empty-cell mask is assembled 64 cells per word from GL-cell ballots.
     int spawn = -1;
@@ -262,7 +253,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
             cnt[4] += n_eat; cnt[5] += 1;              // game_length (game.py:197)
         }
     }
-    WAVE_SYNC();
+    __syncthreads();
     if (!ended)
         for (int i = sl; i < L.stride / 16; i += GL) ((uint4 *)gsrc)[i] = ((const uint4 *)g)[i];
     if (done_out && valid && sl == 0) done_out[gi] = (uint8_t)(ended || n_alive <= 1);
@@ -289,7 +280,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_reset(uint8_t *__restrict__ s
     const int S = L.S;
     uint8_t *g = smem + wv * lds_per_wave(L);
     for (int i = lane; i < L.stride / 16; i += 64) ((uint4 *)g)[i] = make_uint4(0, 0, 0, 0);
-    WAVE_SYNC();
+    __syncthreads();
     if (valid && lane == 0) {
         const int sy[8] = {1, HH - 2, HH - 2, 1, 1, HH / 2, HH - 2, HH / 2};
         const int sx[8] = {1, WW - 2, 1, WW - 2, WW / 2, WW - 2, WW / 2, 1};
@@ -328,7 +319,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_reset(uint8_t *__restrict__ s
         }
         *(uint32_t *)(g + L.uid_off) = uid;
     }
-    WAVE_SYNC();
+    __syncthreads();
     if (valid) {
         const int slot = slots ? slots[gi] : gi;
         uint8_t *gdst = state + (size_t)slot * L.stride;
@@ -434,7 +425,7 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
     if (valid)
         for (int i = sl; i < L.stride / 16; i += GL) ((uint4 *)g)[i] = ((const uint4 *)gsrc)[i];
     for (int i = sl * 4; i < 4 * L.nc_pad; i += GL * 4) *(uint32_t *)((uint8_t *)ttl + i) = 0u;
-    WAVE_SYNC();
+    __syncthreads();
 
     const SnakeMeta *meta = (const SnakeMeta *)(g + L.meta_off);
     const uint64_t *food = (const uint64_t *)(g + L.food_off);
@@ -457,7 +448,7 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
         if (sl == 0)   // (snake.length - (you.length - 0.5)) * 0.04 in float64, then float32 (game.py:229-232,257)
             hval[s] = (float)(((double)ms.len - ((double)me.len - 0.5)) * 0.04);
     }
-    WAVE_SYNC();
+    __syncthreads();
 
     const int my_head = (int)((const cell_t *)(g + you * L.ring_bytes))[(me.tail + me.len - 1) & mask];
     const int hy = my_head / WW, hx = my_head - hy * WW;
@@ -496,7 +487,7 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
                 }
                 *(float4 *)(canvas + 4 * q) = v;
             }
-        WAVE_SYNC();
+        __syncthreads();
         if (live)
             for (int c = sl; c < NC; c += GL) {
                 const int y = c / WW, x = c - y * WW;
@@ -511,7 +502,7 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
                 for (int ch = 0; ch < 3; ++ch)
                     cv[(layout == SNK_NHWC_F32) ? 3 * pp + ch : ch * NPIX + pp] = cell_val(c, ch);
             }
-        WAVE_SYNC();
+        __syncthreads();
         if (valid && layout == SNK_NCHW_BF16) {            // same values, channel-major, rounded to bf16 (nearest even)
             unsigned short *o16 = (unsigned short *)planes + (size_t)pi * NEL;
             for (int e = sl; e < NEL; e += GL) {
