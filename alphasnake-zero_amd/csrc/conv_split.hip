@@ -326,8 +326,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
             v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
             if (has_out && off[pass & 1][j] >= 0) {
                 if (OUT16) {
-                    f16x4 o16_;
-                    o16_[0] = (_Float16)v.x; o16_[1] = (_Float16)v.y; o16_[2] = (_Float16)v.z; o16_[3] = (_Float16)v.w;
+                    f16x4 o16_;                                    // saturating: an f16 infinity would turn the next layer into NaNs
+                    o16_[0] = (_Float16)__builtin_amdgcn_fmed3f(v.x, -65504.f, 65504.f); o16_[1] = (_Float16)__builtin_amdgcn_fmed3f(v.y, -65504.f, 65504.f);
+                    o16_[2] = (_Float16)__builtin_amdgcn_fmed3f(v.z, -65504.f, 65504.f); o16_[3] = (_Float16)__builtin_amdgcn_fmed3f(v.w, -65504.f, 65504.f);
                     *(f16x4 *)((_Float16 *)p.out + obase + off[pass & 1][j]) = o16_;
                 } else *(float4 *)(p.out + obase + off[pass & 1][j]) = v;
             }

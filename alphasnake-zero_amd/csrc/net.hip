@@ -693,7 +693,8 @@ __global__ __launch_bounds__(256) void k_stem_conv_img(StemArgs p)
         if (OUT16) {
             typedef _Float16 st_f16x4 __attribute__((ext_vector_type(4)));
             st_f16x4 o_;
-            o_[0] = (_Float16)v.x; o_[1] = (_Float16)v.y; o_[2] = (_Float16)v.z; o_[3] = (_Float16)v.w;
+            o_[0] = (_Float16)fminf(v.x, 65504.f); o_[1] = (_Float16)fminf(v.y, 65504.f);      // post-ReLU: saturate upwards only
+            o_[2] = (_Float16)fminf(v.z, 65504.f); o_[3] = (_Float16)fminf(v.w, 65504.f);
             *(st_f16x4 *)(out16 + (long)px * CV_C) = o_;
         } else *(float4 *)(out + (long)px * CV_C) = v;
         x += 8;
