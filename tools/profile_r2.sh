@@ -17,3 +17,7 @@ find $O -name "*kernel_stats.csv" | head -3
 # 3. BASELINE configs[0] (8 games, 25 sims; eager compacted tick) under the kernel trace: GPU-busy time per rollout tick
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/small -- python3 $R/bench.py --games 8 --breadth 25 --steps 30 --warmup 5 --no-cpu-baseline --no-kernel-rooflines --no-conv-timing > $O/small_under_rocprof.json 2> /dev/null
 find $O -name "*kernel_stats.csv"
+# 4. HBM traffic of the engine kernels (262 144 games): FETCH_SIZE / WRITE_SIZE passes of tools/engine_only.py
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/eng_fetch -- python3 $R/tools/engine_only.py 262144 > $O/engine_only.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/eng_write -- python3 $R/tools/engine_only.py 262144 > /dev/null 2>&1
+for k in k_step k_clone k_observe; do python3 $R/tools/pmc_summary.py $O/eng_fetch FETCH_SIZE $k; python3 $R/tools/pmc_summary.py $O/eng_write WRITE_SIZE $k; done
