@@ -99,7 +99,7 @@ class DeviceMCTS:
         # (AlphaNNet.v_device is; a net that goes through the host is not).  None = decide per call from `graph_safe`.
         self.graph_ticks = graph_ticks
         self.graph_safe = False           # set by the owner (utils.agent.Agent) when evaluate() never touches the host
-        self._graph = None                # (graph, B, table handle value) of the captured tick
+        self._graph = None                # (graph, key): the captured tick and everything its launches have baked in
         self._side = None
         self.stats = dict(net_evals=0, rollout_ticks=0, sim_steps=0, lookups=0, graph_replays=0, graph_captures=0)
         self._sim_steps_pending = []      # device counters of the sub-game tics, folded into stats at the turn's end
@@ -242,7 +242,7 @@ class DeviceMCTS:
             self.now_dev.fill_(self.now)
             self._planes(m)
             n_replayed = 0
-            key = (B, id(self.tt), self.tt.generation, self.planes.data_ptr(), id(self.roll))
+            key = (B, id(self.tt), self.tt.generation, self.planes.data_ptr(), id(self.roll), root.health_dec, self.base)
             graph = self._graph[0] if self._graph is not None and self._graph[1] == key else None
             if graph is None:
                 self._graph = None
@@ -322,7 +322,7 @@ class DeviceMCTS:
                     self.tt.rebuild(cap * 2, self.now, 1 << 30)
                     tt = self.tt.h
                     graph, self._graph = None, None              # the captured launches point into the old table
-                    key = (B, id(self.tt), self.tt.generation, self.planes.data_ptr(), id(self.roll))
+                    key = (B, id(self.tt), self.tt.generation, self.planes.data_ptr(), id(self.roll), root.health_dec, self.base)
         if fixed:
             self.draw_ctr += n_replayed                          # the draws the ticks consumed
             self._sim_steps_pending.append(self.sims_dev.clone())
