@@ -658,12 +658,6 @@ __global__ __launch_bounds__(256) void k_stem_conv_img(StemArgs p)
     extern __shared__ __align__(16) float st_img[];
     const int tid = threadIdx.x, cq = tid & 31, pg = tid >> 5;
     const int Hd = p.Hd, Wd = p.Wd, HW = Hd * Wd, row3 = Wd * 3, P3 = (Wd + 2) * 3;
-    const float *src = p.x + (long)blockIdx.x * HW * 3;
-    for (int j = tid; j < (Hd + 2) * P3; j += 256) {
-        const int yy = j / P3, rr = j - yy * P3;
-        const bool inside = yy >= 1 && yy <= Hd && rr >= 3 && rr < 3 + row3;
-        st_img[j] = inside ? src[(yy - 1) * row3 + rr - 3] : 0.f;
-    }
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x2 wlo[27], whi[27];
 #pragma unroll
@@ -672,8 +666,18 @@ __global__ __launch_bounds__(256) void k_stem_conv_img(StemArgs p)
         wlo[q] = (f32x2){w_.x, w_.y}; whi[q] = (f32x2){w_.z, w_.w};
     }
     const float4 sc = *(const float4 *)(p.scale + 4 * cq), sh = *(const float4 *)(p.shift + 4 * cq);
-    float *out = p.out + (long)blockIdx.x * HW * CV_C + 4 * cq;
-    _Float16 *out16 = (_Float16 *)p.out + (long)blockIdx.x * HW * CV_C + 4 * cq;
+    const int n_img = p.M / HW;
+    // persistent blocks: the weights are loaded once per block, the images of the batch are taken round-robin
+    for (int img = blockIdx.x; img < n_img; img += gridDim.x) {
+    const float *src = p.x + (long)img * HW * 3;
+    __syncthreads();                                           // the previous image's readers are done with the LDS image
+    for (int j = tid; j < (Hd + 2) * P3; j += 256) {
+        const int yy = j / P3, rr = j - yy * P3;
+        const bool inside = yy >= 1 && yy <= Hd && rr >= 3 && rr < 3 + row3;
+        st_img[j] = inside ? src[(yy - 1) * row3 + rr - 3] : 0.f;
+    }
+    float *out = p.out + (long)img * HW * CV_C + 4 * cq;
+    _Float16 *out16 = (_Float16 *)p.out + (long)img * HW * CV_C + 4 * cq;
     __syncthreads();
     int y = pg / Wd, x = pg - y * Wd;
     for (int px = pg; px < HW; px += 8) {
@@ -699,6 +703,130 @@ __global__ __launch_bounds__(256) void k_stem_conv_img(StemArgs p)
         } else *(float4 *)(out + (long)px * CV_C) = v;
         x += 8;
         while (x >= Wd) { x -= Wd; ++y; }
+    }
+    }
+}
+
+// The stem on the matrix pipe.  k_stem_conv_img is VALU-bound at the clock the chip holds under packed-FMA load (measured:
+// 480-550 us for 7 483-8 192 images, 3.2-3.9 TB/s of output, against 244 us for a plain fill of the same bytes); the same
+// 3 MFLOP per image cost the matrix pipe next to nothing, so the kernel becomes a store stream.  GEMM: rows = the image's
+// pixels (32 per M tile), K = 27 patch values padded to 32 (two k steps of v_mfma_f32_32x32x16_f16), N = 128 outputs (4 N
+// tiles).  Float32 accuracy the same way as the tower (conv_split.hip): operands carried as f16 hi + lo after power-of-two
+// scales (inputs x 2^10: observation values are at most ~2.5; weights by the power of two that brings max |w| to [256, 512)),
+// hi*hi + hi*lo + lo*hi with float32 accumulation, the scales undone in the batch-norm scale.  One block = persistent loop
+// over images; the padded image sits in LDS as float32 ([(H+2)][(W+2)][3]); wave w takes M tiles w, w + 4, ...: per tile
+// each lane gathers its 16 patch values (k = 16 s + 8 h + j -> tap row k / 9, column k % 9: constant LDS offsets from the
+// pixel's address), splits them, and runs 24 MFMAs against the split weights it keeps in 64 VGPRs.  Output straight from
+// the accumulators: for each accumulator register the two 32-lane halves write 128 contiguous bytes of two pixel rows.
+typedef _Float16 sm_f16x8 __attribute__((ext_vector_type(8)));
+typedef float sm_f32x16 __attribute__((ext_vector_type(16)));
+template <bool OUT16>
+__global__ __launch_bounds__(256) void k_stem_conv_mfma(StemArgs p)
+{
+    extern __shared__ __align__(16) float st_img[];
+    __shared__ float s_wmax[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int Hd = p.Hd, Wd = p.Wd, HW = Hd * Wd, row3 = Wd * 3, P3 = (Wd + 2) * 3;
+    const int n_img = p.M / HW, T = (HW + 31) / 32;
+    // weight scale: max |w| over the 27 x 128 kernel -> 2^k with 256 <= max * 2^k < 512
+    float wm = 0.f;
+    for (int i = tid; i < 27 * CV_C; i += 256) wm = fmaxf(wm, fabsf(p.w[i]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o, 64));
+    if (lane == 0) s_wmax[wv] = wm;
+    __syncthreads();
+    wm = fmaxf(fmaxf(s_wmax[0], s_wmax[1]), fmaxf(s_wmax[2], s_wmax[3]));
+    int wk = 0;
+    if (wm > 0.f && wm < 3.0e38f) wk = 8 - ilogbf(wm);
+    wk = max(-100, min(100, wk));
+    const float wmul = ldexpf(1.0f, wk);
+    constexpr int AX = 10;                                     // input scale 2^10
+    const float amul = 1024.0f, undo = ldexpf(1.0f, -wk - AX);
+    // B fragments: lane (column 32 nt + l31, k half h) holds k = 16 s + 8 h + j, j = 0..7, as hi and lo
+    sm_f16x8 Bh[4][2], Bl[4][2];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * s_ + 8 * h + j;
+                const float v = k < 27 ? p.w[k * CV_C + 32 * nt + l31] * wmul : 0.f;
+                const _Float16 hi_ = (_Float16)v;
+                Bh[nt][s_][j] = hi_;
+                Bl[nt][s_][j] = (_Float16)(v - (float)hi_);
+            }
+    // LDS offsets (in floats, relative to the pixel's top-left tap) of this lane's 16 patch values; k >= 27 reads offset 0, masked
+    int koff[2][8];
+    unsigned kvalid = 0;
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * s_ + 8 * h + j;
+            koff[s_][j] = k < 27 ? (k / 9) * P3 + (k % 9) : 0;
+            if (k < 27) kvalid |= 1u << (8 * s_ + j);
+        }
+    float scl[4], shf[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { scl[nt] = p.scale[32 * nt + l31] * undo; shf[nt] = p.shift[32 * nt + l31]; }
+
+    const int n_lds = (Hd + 2) * P3;
+    for (int img = blockIdx.x; img < n_img; img += gridDim.x) {
+        const float *src = p.x + (long)img * HW * 3;
+        __syncthreads();                                       // the previous image's readers are done with the LDS image
+        for (int j = tid; j < n_lds; j += 256) {
+            const int yy = j / P3, rr = j - yy * P3;
+            const bool inside = yy >= 1 && yy <= Hd && rr >= 3 && rr < 3 + row3;
+            st_img[j] = inside ? src[(yy - 1) * row3 + rr - 3] * amul : 0.f;
+        }
+        __syncthreads();                                       // (prefetching the next image through registers into a second
+        //                                                        buffer was measured: no change, the loads are not what it waits for)
+        float *out = p.out + (long)img * HW * CV_C;
+        _Float16 *out16 = (_Float16 *)p.out + (long)img * HW * CV_C;
+        for (int t = wv; t < T; t += 4) {
+            const int pix = min(32 * t + l31, HW - 1);         // rows past the image repeat its last pixel (computed, never stored)
+            const int y = pix / Wd, x = pix - y * Wd;
+            const float *b = st_img + y * P3 + x * 3;
+            sm_f16x8 Ah[2], Al[2];
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float v = b[koff[s_][j]];
+                    if (!((kvalid >> (8 * s_ + j)) & 1u)) v = 0.f;
+                    const _Float16 hi_ = (_Float16)v;
+                    Ah[s_][j] = hi_;
+                    Al[s_][j] = (_Float16)(v - (float)hi_);
+                }
+            sm_f32x16 acc[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) {
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s_], Bh[nt][s_], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s_], Bl[nt][s_], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[s_], Bh[nt][s_], acc[nt], 0, 0, 0);
+                }
+            }
+            // output straight from the accumulators: register r holds rows (r & 3) + 8 (r >> 2) + 4 h of the tile (C layout of
+            // the 32x32 MFMA), so one store instruction writes 128 contiguous bytes of two pixel rows.  Measured alternatives:
+            // float4 stores through an LDS patch, one N tile at a time (same time) or whole 512-byte rows (slower: 476 vs 372 us)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < HW) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const float v = fmaxf(__builtin_fmaf(acc[nt][r], scl[nt], shf[nt]), 0.f);
+                        if (OUT16) out16[(long)row * CV_C + 32 * nt + l31] = (_Float16)fminf(v, 65504.f);
+                        else out[(long)row * CV_C + 32 * nt + l31] = v;
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -908,7 +1036,11 @@ extern "C" int snk_stem_conv_bn_relu_f32(const float *d_x, const float *d_w, con
     SNK_REQUIRE(M < (1l << 31), "snk_stem_conv_bn_relu_f32: batch too large");
     StemArgs a = {d_x, d_w, d_scale, d_shift, d_out, (int)M, height, width};
     const size_t lds = (size_t)(height + 2) * (width + 2) * 3 * sizeof(float);
-    if (lds <= 64 * 1024) k_stem_conv_img<false><<<n_images, 256, lds, (hipStream_t)stream>>>(a);
+    // default: the MFMA form on 512 persistent blocks (2 resident per CU); SNK_STEM=valu selects the packed-FMA form
+    static const int stem_grid = getenv("SNK_STEM_GRID") ? atoi(getenv("SNK_STEM_GRID")) : 512;
+    static const int stem_valu = getenv("SNK_STEM") ? !strcmp(getenv("SNK_STEM"), "valu") : 0;
+    if (lds <= 64 * 1024 && !stem_valu) k_stem_conv_mfma<false><<<min(n_images, stem_grid), 256, lds, (hipStream_t)stream>>>(a);
+    else if (lds <= 64 * 1024) k_stem_conv_img<false><<<min(n_images, 768), 256, lds, (hipStream_t)stream>>>(a);
     else k_stem_conv<<<(int)((M + ST_PX - 1) / ST_PX), 256, 0, (hipStream_t)stream>>>(a);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
@@ -925,7 +1057,7 @@ extern "C" int snk_stem_conv_bn_relu_f16out(const float *d_x, const float *d_w, 
     const size_t lds = (size_t)(height + 2) * (width + 2) * 3 * sizeof(float);
     SNK_REQUIRE(lds <= 64 * 1024, "snk_stem_conv_bn_relu_f16out: observation %d x %d too large", height, width);
     StemArgs a = {d_x, d_w, d_scale, d_shift, (float *)d_out16, (int)M, height, width};
-    k_stem_conv_img<true><<<n_images, 256, lds, (hipStream_t)stream>>>(a);
+    k_stem_conv_mfma<true><<<min(n_images, 512), 256, lds, (hipStream_t)stream>>>(a);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
