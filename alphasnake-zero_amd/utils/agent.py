@@ -113,12 +113,17 @@ class _Records(Sequence):
     def __len__(self):
         return self._a._n_records
 
-    def fetch(self, indices):
+    def fetch_device(self, indices):
+        """the observations of the given records as one device tensor [k, 2H-1, 2W-1, 3] (no host round trip: what the
+        iteration-end all-gather sends)"""
         a = self._a
         idx = np.asarray(indices, np.int64)
         pairs = a._rec_pairs_host()[idx]
         planes, _, _ = a._rec_engine.observe_all(pairs.astype(np.int32), want_mask=False, want_key=False)
-        return planes.cpu().numpy()
+        return planes
+
+    def fetch(self, indices):
+        return self.fetch_device(indices).cpu().numpy()
 
     def __getitem__(self, i):
         if isinstance(i, slice):

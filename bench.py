@@ -289,7 +289,7 @@ def main():
     # iteration-end exchange (trainer.py:63-75 across ranks): sampled rows all-gathered, counters all-reduced
     rng = np.random.RandomState(rank)
     idx, share = sdist.sample_share(len(alice.records), 5 * 2048, world, rng)
-    X = torch.as_tensor(alice.records.fetch(idx) if len(idx) else np.zeros((share, OBS, OBS, 3), np.float32), device="cuda")
+    X = alice.records.fetch_device(idx) if len(idx) else torch.zeros((share, OBS, OBS, 3), dtype=torch.float32, device="cuda")
     if X.shape[0] < share:
         X = torch.cat([X, X.new_zeros((share - X.shape[0], OBS, OBS, 3))])
     Vs = torch.as_tensor(alice._values_host()[idx] if len(idx) else np.zeros((share, 3), np.float32), device="cuda")
