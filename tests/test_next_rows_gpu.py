@@ -153,3 +153,36 @@ def test_trainer_flow_train_copy_save_load(tmp_path, monkeypatch):
     assert len(re.v_net.get_weights()) == 54
     with pytest.raises(OSError):
         AlphaNNet(model_name="models/t2.h5")
+
+
+def test_alpha_snake_zero_trainer_two_generations(tmp_path, monkeypatch):
+    """utils.alpha_snake_zero_trainer.AlphaSnakeZeroTrainer driven exactly as train.py drives it (train.py:32-40), for two
+    generations: log.csv gets the reference's header and one row of six per-game averages per generation, the learning rate
+    decays, models/<name><n>.h5 appear and load back"""
+    import random
+    from utils.alpha_nnet import AlphaNNet
+    from utils.alpha_snake_zero_trainer import AlphaSnakeZeroTrainer
+    from utils.mp_game_runner import MPGameRunner
+    random.seed(2); np.random.seed(2)
+    monkeypatch.chdir(tmp_path)
+    os.mkdir("models")
+    MPGameRunner.verbose = False
+    ANNet = AlphaNNet(input_shape=(21, 21, 3))
+    ANNet.save("gen0")
+    trainer = AlphaSnakeZeroTrainer(6, 4, 8, 1e-3, 0.98, 11, 11, 4, None)
+    last = trainer.train(ANNet, name="gen", iteration=0, max_iterations=2)
+    lines = open("log.csv").read().splitlines()
+    assert lines[0] == "new model gen"
+    assert lines[1] == "iteration, wall_collision, body_collision, head_collision, starvation, food_eaten, game_length"
+    rows = [l.split(", ") for l in lines[2:]]
+    assert [r[0] for r in rows] == ["0", "1"] and all(len(r) == 7 for r in rows)
+    for r in rows:
+        vals = [float(v) for v in r[1:]]
+        assert vals[5] > 1 and abs(sum(vals[:4]) - round(sum(vals[:4]) * 6) / 6) < 1e-9       # averages over 6 games
+    assert abs(trainer.lr - 1e-3 * 0.98 ** 2) < 1e-12
+    assert os.path.exists("models/gen1.h5") and os.path.exists("models/gen2.h5")
+    re = AlphaNNet(model_name="models/gen2.h5")
+    X = np.zeros((2, 21, 21, 3), np.float32); X[..., 1] = 1.0
+    assert np.array_equal(re.v(list(X)), last.v(list(X)))
+    w0, w2 = ANNet.v_net.get_weights(), re.v_net.get_weights()
+    assert max(float(np.abs(a - b).max()) for a, b in zip(w0, w2)) > 1e-4          # it trained

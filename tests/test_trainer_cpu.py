@@ -126,3 +126,18 @@ def test_two_rank_fit_equals_one_rank_full_batch(tmp_path):
         else:                     # float32: an Adam step is +-lr_t per element whatever the gradient's size, so an element whose
             #                       gradient is at rounding level moves differently; all others agree to 1e-6
             assert np.mean(d <= 1e-6) > 0.99 and d.max() <= 1e-3, (np.mean(d <= 1e-6), d.max())
+
+
+def test_trainer_curriculum_and_mirror_helpers():
+    """alpha_snake_zero_trainer.py:42-47 (health curriculum) and :93-100 (mirror augmentation)"""
+    from utils.alpha_snake_zero_trainer import AlphaSnakeZeroTrainer
+    t = AlphaSnakeZeroTrainer(256, 8, 128, 1e-4, 0.98)
+    assert [t.health_dec_for(i) for i in (0, 8, 9, 32, 33, 100)] == [9, 9, 3, 3, 1, 1]
+    assert (t.height, t.width, t.snake_cnt, t.self_play_games, t.max_MCTS_depth, t.max_MCTS_breadth) == (11, 11, 4, 256, 8, 128)
+    rng = np.random.RandomState(0)
+    X = [rng.rand(5, 7, 3).astype(np.float32) for _ in range(3)]
+    V = [rng.rand(3).astype(np.float32) for _ in range(3)]
+    mx, mv = t.mirror_states(X), t.mirror_values(V)
+    assert isinstance(mx, list) and isinstance(mv, list) and len(mx) == 3
+    assert np.array_equal(mx[1], X[1][:, ::-1, :]) and np.array_equal(mv[2], V[2][::-1])
+    assert t.mirror_states([]) == [] and t.mirror_values([]) == []
