@@ -186,3 +186,31 @@ def test_alpha_snake_zero_trainer_two_generations(tmp_path, monkeypatch):
     assert np.array_equal(re.v(list(X)), last.v(list(X)))
     w0, w2 = ANNet.v_net.get_weights(), re.v_net.get_weights()
     assert max(float(np.abs(a - b).max()) for a, b in zip(w0, w2)) > 1e-4          # it trained
+
+
+def test_trainer_generation_on_two_ranks(tmp_path):
+    """the generation loop under torch.distributed (two ranks sharing the box's GPU over gloo): the 10 games are cut 5 + 5,
+    the sampled rows are all-gathered, the fit runs data-parallel; both ranks end with bit-identical weights, rank 0 alone
+    writes log.csv (one row: averages over all 10 games) and the model file"""
+    import socket
+    import subprocess
+    import sys
+    from conftest import REPO
+    os.mkdir(tmp_path / "models")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "helpers", "trainer_rank.py"), str(tmp_path)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[0][-2000:] + outs[1][-2000:]
+    w0, w1 = np.load(tmp_path / "weights_r0.npz"), np.load(tmp_path / "weights_r1.npz")
+    assert len(w0.files) == 54
+    for k in w0.files:
+        assert np.array_equal(w0[k], w1[k]), k
+    lines = open(tmp_path / "log.csv").read().splitlines()
+    assert lines[0] == "new model dp" and len(lines) == 3 and lines[2].startswith("0, ")
+    vals = [float(v) for v in lines[2].split(", ")[1:]]
+    assert abs(vals[5] * 10 - round(vals[5] * 10)) < 1e-9            # game_length averaged over all 10 games
+    assert os.path.exists(tmp_path / "models" / "dp1.h5") and not os.path.exists(tmp_path / "models" / "dp2.h5")
