@@ -214,3 +214,29 @@ def test_trainer_generation_on_two_ranks(tmp_path):
     vals = [float(v) for v in lines[2].split(", ")[1:]]
     assert abs(vals[5] * 10 - round(vals[5] * 10)) < 1e-9            # game_length averaged over all 10 games
     assert os.path.exists(tmp_path / "models" / "dp1.h5") and not os.path.exists(tmp_path / "models" / "dp2.h5")
+
+
+def test_pit_scripts_call_sequence_with_real_nets(tmp_path, monkeypatch):
+    """the bodies of pit.py (2 snakes, models loaded from .h5, :15-46) and test_pit.py (1v3 both ways, then 2v2, :13-65) with
+    two real nets on the device path (observation tensor + obstacle mask straight into the MFMA net)"""
+    from utils.pit_agent import Agent
+    from utils.alpha_nnet import AlphaNNet
+    from utils.pit_mp_game_runner import MPGameRunner
+    import random
+    random.seed(7); np.random.seed(7)
+    monkeypatch.chdir(tmp_path)
+    os.mkdir("models")
+    AlphaNNet(input_shape=(21, 21, 3)).save("m1")
+    AlphaNNet(input_shape=(21, 21, 3)).save("m2")
+    nnet1, nnet2 = AlphaNNet(model_name="models/m1.h5"), AlphaNNet(model_name="models/m2.h5")
+    Alice, Bob = Agent(nnet1), Agent(nnet2)
+    n = 40
+    for snake_cnt, a_cnt, first, second in ((4, 1, Alice, Bob), (4, 1, Bob, Alice), (2, 1, Alice, Bob)):
+        gr = MPGameRunner(11, 11, snake_cnt, 1, n)
+        winner_ids = gr.run(first, second, a_cnt)
+        assert len(winner_ids) == n and all(w is None or 0 <= w < snake_cnt for w in winner_ids)
+        win = sum(1 for w in winner_ids if w is not None and w < a_cnt)
+        draw = sum(1 for w in winner_ids if w is None)
+        assert 0 <= win + draw <= n and len(gr.games) == 0
+    with pytest.raises(OSError):                                   # pit.py:58 polls for the next generation this way
+        AlphaNNet(model_name="models/m3.h5")
