@@ -778,7 +778,9 @@ __global__ __launch_bounds__(256) void k_stem_conv_mfma(StemArgs p)
         for (int j = tid; j < n_lds; j += 256) {
             const int yy = j / P3, rr = j - yy * P3;
             const bool inside = yy >= 1 && yy <= Hd && rr >= 3 && rr < 3 + row3;
-            st_img[j] = inside ? src[(yy - 1) * row3 + rr - 3] * amul : 0.f;
+            // observation values are bounded by construction (game.py:229-248: at most (H W + 2.5) * 0.04 = 14.6 on 19x19), so
+            // 2^10 leaves 4x headroom to the f16 range; anything a caller passes beyond +-63.97 saturates instead of becoming inf
+            st_img[j] = inside ? __builtin_amdgcn_fmed3f(src[(yy - 1) * row3 + rr - 3] * amul, -65504.f, 65504.f) : 0.f;
         }
         __syncthreads();                                       // (prefetching the next image through registers into a second
         //                                                        buffer was measured: no change, the loads are not what it waits for)
