@@ -74,3 +74,23 @@ def test_shard_range_partitions_everything():
     assert share == 32 and len(idx) == 32 and set(idx.tolist()) == set(range(5))
     idx, share = sample_share(0, 64, 2, np.random.RandomState(0))
     assert share == 32 and len(idx) == 0
+
+
+def test_bench_launcher_reports_a_failed_rank_and_does_not_hang():
+    """`python bench.py --gpus 2` on a box without a GPU: the parent starts two rank processes without touching the GPU
+    itself; they fail ("needs an MI355X"), the parent kills what is left, prints the exit codes and returns non-zero"""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: tests/test_bench_gpu.py covers the working path")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--games", "8"], capture_output=True,
+                         text=True, env=env, timeout=300)
+    assert out.returncode != 0
+    assert "rank exit codes" in out.stderr and "needs an MI355X" in out.stderr
+    assert out.stdout.strip() == ""                      # no JSON line from a failed run
+    # and a WORLD_SIZE that contradicts --gpus is refused before anything else happens
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                         env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE" in out.stderr
