@@ -71,12 +71,29 @@ def cpu_baseline(weights, breadth, n_games=16, n_turns=2):
         es = e.run(max_turns=2 if thr == 1 else 6)       # about a second of work either way
         eng[thr] = es["env_steps"] / (time.time() - t1)
         e.close()
+    # bridge to the reference itself: the Python restatement (oracle/mcts_oracle.py: the
+    # reference's loop statement for statement over the C game primitives) on the workload BASELINE.md timed the unmodified
+    # reference on -- 8 games, breadth 50, stub net, one process.  In the survey container the reference does 6.46 and this
+    # restatement 29.4 env-steps/s (ratio 0.22); the same ratio applied to this box's figure estimates the reference here.
+    from oracle.mcts_oracle import SelfPlayOracle, Draws
+    from oracle.obs_key import StubNet
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        spo = SelfPlayOracle(StubNet(), 2, True, 8, 50, Draws(seed=1))
+        t2 = time.time()
+        _, py_steps = spo.run(seeded_games(8, seed=1), max_turns=6, rng=np.random.RandomState(0))
+        py_rate = py_steps / (time.time() - t2)
     return {"value": st["env_steps"] / dt, "unit": "env-steps/s", "cores": cpus, "kind": "port",
             "sample": f"fixed work: {n_games} seeded games x {n_turns} root turns, breadth {breadth} = {st['env_steps']} env-steps, "
                       f"{st['net_evals']} net evals, {st['sim_steps']} rollout tics in {dt:.1f} s; oracle/mcts_cpu.c on "
                       f"{min(cpus, n_games)} threads + PyTorch-CPU fp32 net on {cpus} threads "
                       f"(os.cpu_count() = {os.cpu_count()}, usable = {cpus})",
             "net_evals_per_s": st["net_evals"] / dt,
+            "python_restatement_stub_net_1_process": py_rate,
+            "reference_estimate_stub_net_1_process": 6.46 / 29.4 * py_rate,
+            "reference_estimate_note": "the unmodified reference cannot run on this box; BASELINE.md measured it at 6.46 env-steps/s "
+                                       "(8 games, breadth 50, stub net, 1 core) where this Python restatement does 29.4",
             "engine_only_env_steps_per_s": {f"{k}_threads": v for k, v in eng.items()},
             "engine_only_note": "stub net inside the C code (zero net cost), 64 games per thread x 2 (1 thread) / 6 (all threads) root turns: what the "
                                 "reference's Python loop does at 6.5 env-steps/s per core with a stub net (BASELINE.md)"}
