@@ -4,6 +4,8 @@ plain PyTorch reference of the same op, and the whole AlphaNNet.v against the fp
 activation scale (fp32 accumulation order differs between a k-ordered MFMA chain and the reference)."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -501,3 +503,40 @@ def test_f16_activation_tower_layer_and_net(env, monkeypatch):
     ws19 = _randomised_bn(net.glorot_uniform_weights((37, 37, 3), blocks=10, seed=1), 4)
     got19 = net.QNet(ws19, (37, 37, 3)).forward(torch.as_tensor(s19["raw"][:6], device="cuda")).cpu().numpy()
     assert np.abs(got19 - net_ref.forward(ws19, s19["raw"][:6], apply_mask=False, f16_act=True)).max() <= 5e-3
+
+
+@pytest.mark.parametrize("form", ["mfma", "valu"])
+def test_stem_shapes_and_forms(env, form):
+    """the stem (3 -> 128, 3x3, BN, ReLU; alpha_nnet.py:21-22) against a float64 convolution on every observation size a
+    square board gives (9x9 ... 37x37), rectangular and ragged pixel counts, batches around the persistent grid size --
+    for the MFMA form (default) and the packed-FMA form; the f16-output variant against the rounded float32 result.
+    The form is chosen when the library first launches a stem, so each form runs in its own process."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    code = r'''
+import ctypes as C, sys, os
+sys.path[:0] = [%r, os.path.join(%r, "alphasnake-zero_amd")]
+import torch
+from snake_engine._lib import lib, check
+L = lib(); st = torch.cuda.current_stream().cuda_stream
+g = torch.Generator().manual_seed(5)
+for n, H, W in ((3, 9, 9), (2, 13, 13), (5, 21, 21), (1, 29, 29), (2, 37, 37), (4, 7, 30), (1, 3, 3), (600, 21, 21), (1030, 9, 9)):
+    x = torch.rand(n, H, W, 3, generator=g) * 6 - 1          # the range observations live in: [-1, 5]
+    w = torch.randn(3, 3, 3, 128, generator=g) * 0.2
+    sc, sh = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.1
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1)
+    ref = (ref * sc.double() + sh.double()).clamp_min(0)
+    d = [t.cuda() for t in (x, w, sc, sh)]
+    out = torch.full((n, H, W, 128), float("nan"), device="cuda")
+    check(L.snk_stem_conv_bn_relu_f32(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), out.data_ptr(), n, H, W, st))
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err <= 3e-6 * ref.abs().max().item(), (n, H, W, err)
+    o16 = torch.full((n, H, W, 128), float("nan"), dtype=torch.float16, device="cuda")
+    check(L.snk_stem_conv_bn_relu_f16out(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), o16.data_ptr(), n, H, W, st))
+    e16 = (o16.cpu().double() - ref).abs()
+    assert (e16 <= 2.0 ** -10 * ref.abs() + 1e-5).all(), (n, H, W, e16.max().item())
+print("ok")
+''' % (REPO, REPO)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, SNK_STEM=form), timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-3000:]
