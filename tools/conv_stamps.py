@@ -14,7 +14,7 @@ H = 21
 st = torch.cuda.current_stream().cuda_stream
 zeros = len(sys.argv) > 2 and sys.argv[2] == "zeros"
 x = torch.randn(n, H, H, 128, device="cuda") * (0.0 if zeros else 1.0); o = torch.empty_like(x)
-w = torch.randn(3, 3, 128, 128, device="cuda") * (0.0 if zeros else 0.05); U = torch.empty(9 * 128 * 128 * 4 + 16, dtype=torch.uint8, device="cuda")
+w = torch.randn(3, 3, 128, 128, device="cuda") * (0.0 if zeros else 0.05); U = torch.empty(9 * 128 * 128 * 4 + 32, dtype=torch.uint8, device="cuda")
 sc = torch.ones(128, device="cuda"); sh = torch.zeros(128, device="cuda")
 assert L.snk_conv3x3_prepare_weights_f16s(w.data_ptr(), U.data_ptr(), 256.0, st) == 0
 f = lambda: L.snk_conv3x3_bn_f16s(x.data_ptr(), U.data_ptr(), sc.data_ptr(), sh.data_ptr(), x.data_ptr(), o.data_ptr(), n, H, H, 1, st)
