@@ -8,6 +8,7 @@
 // Game.__init__ game.py:13-61, Game.subgame game.py:266-276 (see the per-kernel comments).
 #include "common.h"
 #include <stdarg.h>
+#include <stdlib.h>
 #include <vector>
 
 // ------------------------------------------------------------------------------------------ errors
@@ -40,6 +41,22 @@ template <> struct CellT<0> { using type = uint8_t; };
 
 __device__ static inline bool food_bit(const uint64_t *food, int c) { return (food[c >> 6] >> (c & 63)) & 1ull; }
 
+// DPP row_share:o (gfx90a+): every lane of a 16-lane row reads lane o of its row
+__device__ static inline int row_share16(int v, int o)
+{
+    switch (o & 15) {
+    case 0: return __builtin_amdgcn_update_dpp(0, v, 0x150, 0xF, 0xF, true);
+    case 1: return __builtin_amdgcn_update_dpp(0, v, 0x151, 0xF, 0xF, true);
+    case 2: return __builtin_amdgcn_update_dpp(0, v, 0x152, 0xF, 0xF, true);
+    case 3: return __builtin_amdgcn_update_dpp(0, v, 0x153, 0xF, 0xF, true);
+    case 4: return __builtin_amdgcn_update_dpp(0, v, 0x154, 0xF, 0xF, true);
+    case 5: return __builtin_amdgcn_update_dpp(0, v, 0x155, 0xF, 0xF, true);
+    case 6: return __builtin_amdgcn_update_dpp(0, v, 0x156, 0xF, 0xF, true);
+    case 7: return __builtin_amdgcn_update_dpp(0, v, 0x157, 0xF, 0xF, true);
+    default: return v;
+    }
+}
+
 // per-wave LDS carve-up used by step / observe
 __host__ __device__ static inline int lds_per_wave(const Layout &L) { return L.stride + 4 * L.nc_pad + 64; }
 // k_observe adds an output canvas of (2H-1)(2W-1)3 floats (+ alignment slack)
@@ -55,7 +72,7 @@ __host__ __device__ static inline int lds_per_wave_obs(const Layout &L)
 // bound, not HBM bound: four games per wave cut the wave-instructions per game about three times.
 // Sub-lane sl = lane % GL plays the role the lane index had; shuffles and ballots are confined to the game's lane group.
 // ------------------------------------------------------------------------------------------
-template <int H, int W, int GL>
+template <int H, int W, int GL, int SS = 0>      // SS: compile-time snake count (0 = read it from the layout): the per-snake loops unroll
 __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ state, Layout L,
                                                        const int32_t *__restrict__ slots, int n,
                                                        const uint8_t *__restrict__ moves,
@@ -77,8 +94,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
     // neither loaded nor stored; the flag load is independent of the record load (no slot indirection, one round trip)
     const bool frozen = gi < n && active && !active[gi];
     const bool valid = gi < n && !frozen;
-    const int S = L.S, mask = L.cap_mask;
-#define GSHFL(v, o) __shfl((v), gbase + (o), 64)
+    const int S = SS > 0 ? SS : L.S, mask = L.cap_mask;
+// value of sub-lane o of the game's lane group: with 16-lane groups (= one DPP row) a row_share move, one VALU instruction,
+// instead of a ds_bpermute through the LDS crossbar (o is a constant after the per-snake loops unroll)
+#define GSHFL(v, o) (GL == 16 ? row_share16((v), (o)) : __shfl((v), gbase + (o), 64))
 #define GBALLOT(pr) (GL == 64 ? __ballot(pr) : ((__ballot(pr) >> gbase) & ((1ull << (GL & 63)) - 1ull)))
     uint8_t *g = smem + (wv * GPW + gq) * lds_per_wave(L);
     uint8_t *occ = g + L.stride;       // 1 = some snake's non-head node sits here (Game.bodies)
@@ -128,7 +147,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
     // ---- food (game.py:121-127): list order, the first snake on a cell eats; Snake.grow (360-365)
     const bool hasfood = go && !oob && food_bit(food, head_cell);
     bool eats = hasfood;
-    for (int o = 0; o < S; ++o) {
+#pragma unroll
+    for (int o = 0; o < (SS > 0 ? SS : SNK_MAX_SNAKES); ++o) {
+        if (o >= S) break;
         const int ho = GSHFL(head_cell, o);
         const int fo = GSHFL((int)hasfood, o);
         if (o < sl && fo && ho == head_cell) eats = false;
@@ -141,7 +162,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
         m.len = (uint16_t)(m.len + 1);
     }
     const int n_eat = __popcll(GBALLOT(eats));
-    for (int o = 0; o < S; ++o) {
+#pragma unroll
+    for (int o = 0; o < (SS > 0 ? SS : SNK_MAX_SNAKES); ++o) {
+        if (o >= S) break;
         const int eo = GSHFL((int)eats, o);
         const int co = GSHFL(head_cell, o);
         if (eo && sl == 0) food[co >> 6] &= ~(1ull << (co & 63));
@@ -149,7 +172,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
     __syncthreads();
 
     // ---- Game.bodies / Game.heads as LDS byte planes, rebuilt from the rings by all lanes of the game
-    for (int s = 0; s < S; ++s) {
+#pragma unroll
+    for (int s = 0; s < (SS > 0 ? SS : SNK_MAX_SNAKES); ++s) {
+        if (s >= S) break;
         const int len_s = GSHFL((int)m.len, s);
         const int tail_s = GSHFL((int)m.tail, s);
         const int go_s = GSHFL((int)go, s);
@@ -220,7 +245,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
     // ---- deaths (game.py:144-165, an if/elif chain) and removal (167-192)
     const bool body_hit = go && !oob && occ[head_cell];
     bool shared = false, lose = false;
-    for (int o = 0; o < S; ++o) {
+#pragma unroll
+    for (int o = 0; o < (SS > 0 ? SS : SNK_MAX_SNAKES); ++o) {
+        if (o >= S) break;
         const int ho = GSHFL(head_cell, o);
         const int lo = GSHFL((int)m.len, o);
         if (o != sl && ho >= 0 && ho == head_cell) {
@@ -750,7 +777,8 @@ static int step_launch(snk_engine *e, const int32_t *d_slots, int n, const uint8
     if (L.H <= 11) {
         const size_t lds = (size_t)WAVES_PER_BLOCK * 4 * lds_per_wave(L);
         const int grid = (n + WAVES_PER_BLOCK * 4 - 1) / (WAVES_PER_BLOCK * 4);
-        if (L.H == 11) k_step<11, 11, 16><<<grid, BLOCK_THREADS, lds, (hipStream_t)stream>>>(STEP_ARGS);
+        if (L.H == 11 && L.S == 4) k_step<11, 11, 16, 4><<<grid, BLOCK_THREADS, lds, (hipStream_t)stream>>>(STEP_ARGS);
+        else if (L.H == 11) k_step<11, 11, 16><<<grid, BLOCK_THREADS, lds, (hipStream_t)stream>>>(STEP_ARGS);
         else if (L.H == 7) k_step<7, 7, 16><<<grid, BLOCK_THREADS, lds, (hipStream_t)stream>>>(STEP_ARGS);
         else k_step<0, 0, 16><<<grid, BLOCK_THREADS, lds, (hipStream_t)stream>>>(STEP_ARGS);
     } else {

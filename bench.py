@@ -142,6 +142,17 @@ def engine_kernel_rooflines(se, n=32768):
     out["step"] = {"bound": "hbm", "achieved": step_bytes / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": step_bytes / t / 8e12,
                    "bytes_per_unit": 2 * G, "units": n, "us": t * 1e6, "unfinished_games": live_games,
                    "bytes_counted": "G read per game + G written per unfinished game after 32 warm-up ticks of uniform legal moves"}
+    eng.set_params(food_spawn_chance=0.0)         # the form the rollout loop launches (sub-games never spawn food, game.py:268)
+    ts = []
+    for _ in range(20):
+        snap.clone_to(eng)
+        torch.cuda.synchronize()
+        ts.append(timed(lambda: eng.step(mv), 1))
+    t = float(np.median(ts))
+    eng.set_params(food_spawn_chance=0.15)
+    out["step_rollout_form"] = {"bound": "hbm", "achieved": step_bytes / t / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                "frac": step_bytes / t / 8e12, "bytes_per_unit": 2 * G, "units": n, "us": t * 1e6,
+                                "form": "food_spawn_chance 0: no Philox draw, no empty-cell mask"}
     t = timed(lambda: snap.clone_to(eng), 20)
     out["clone"] = {"bound": "hbm", "achieved": n * 2 * G / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": n * 2 * G / t / 8e12,
                     "bytes_per_unit": 2 * G, "units": n, "us": t * 1e6}
@@ -166,6 +177,7 @@ def engine_kernel_rooflines(se, n=32768):
         del eng, snap, planes, mask, key
         big = engine_kernel_rooflines(se, 262144)
         out["step_262144_games"] = big["step"]
+        out["step_rollout_form_262144_games"] = big["step_rollout_form"]
         out["clone_262144_games"] = big["clone"]
     return out
 
