@@ -25,9 +25,11 @@ def sample_share(n_local_records, total_samples, world, rng):
     return np.resize(rng.permutation(n_local_records), share), share
 
 
-def all_gather_samples(X, V, group=None):
-    """X [k, h, w, 3] float32, V [k, 3] float32 with the same k on every rank -> concatenation over ranks"""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+def all_gather_samples(X, V, group=None, single_rank_collective=False):
+    """X [k, h, w, 3] float32, V [k, 3] float32 with the same k on every rank -> concatenation over ranks.
+    With one rank there is nothing to exchange; `single_rank_collective` runs the collectives anyway (the RCCL calls
+    themselves can then be exercised on a one-GPU box, tests/test_bench_gpu.py)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not single_rank_collective):
         return X, V
     world = dist.get_world_size(group)
     dev = X.device
@@ -40,12 +42,13 @@ def all_gather_samples(X, V, group=None):
     return Xo.to(dev), Vo.to(dev)
 
 
-def all_reduce_counters(counters, game_cnt, device, group=None):
+def all_reduce_counters(counters, game_cnt, device, group=None, single_rank_collective=False):
     """sum of the six per-rank counter totals and of the game counts -> per-game averages (mp_game_runner.py:71-76)"""
     t = torch.tensor(list(counters) + [game_cnt], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 and dist.get_backend(group) == "gloo":
+    active = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or single_rank_collective)
+    if active and dist.get_backend(group) == "gloo":
         t = t.cpu()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if active:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     t = t.cpu().numpy()
     return (t[:6] / t[6]).tolist(), int(t[6])

@@ -60,3 +60,14 @@ def test_bench_refuses_a_world_size_mismatch_before_touching_the_gpu():
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--games", "16"],
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode != 0 and "WORLD_SIZE" in out.stderr
+
+
+def test_rccl_calls_of_the_exchange_run_on_one_rank():
+    """the collectives of the iteration-end exchange, of bench.py's timing reduction and of the trainer's gradient bucket,
+    issued to RCCL itself through a one-rank "nccl" process group (what a one-GPU box allows)"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tests", "helpers", "rccl_single_rank.py")], capture_output=True,
+                         text=True, env=env, timeout=600)
+    assert out.returncode == 0 and "rccl ok" in out.stdout, out.stderr[-3000:]
