@@ -110,7 +110,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
     const int tape_in = (valid && spawn_tape) ? spawn_tape[gi] : -1;
     if (valid)
         for (int i = sl; i < L.stride / 16; i += GL) ((uint4 *)g)[i] = ((const uint4 *)gsrc)[i];
-    for (int i = sl * 4; i < 2 * L.nc_pad; i += GL * 4) *(uint32_t *)(occ + i) = 0u;
+    for (int i = sl * 16; i < 2 * L.nc_pad; i += GL * 16) *(uint4 *)(occ + i) = make_uint4(0u, 0u, 0u, 0u);   // both byte planes
     __syncthreads();
 
     SnakeMeta *meta = (SnakeMeta *)(g + L.meta_off);
