@@ -240,3 +240,56 @@ def test_pit_scripts_call_sequence_with_real_nets(tmp_path, monkeypatch):
         assert 0 <= win + draw <= n and len(gr.games) == 0
     with pytest.raises(OSError):                                   # pit.py:58 polls for the next generation this way
         AlphaNNet(model_name="models/m3.h5")
+
+
+def test_entry_scripts_train_then_ladder_then_matches(tmp_path, monkeypatch, capsys):
+    """the package's own train.py / pit.py / test_pit.py / test_model.py / test_weights.py (counterparts of the reference's
+    entry scripts) on a tiny setting: train.py writes models/<name>0..2.h5 and log.csv, pit.py's ladder plays generations 1
+    and 2 against the champion and writes pit.txt in the reference's line formats with the score of the games it played,
+    then polls once for generation 3 and gives up; test_pit.py's three matches, test_model.py's replay, test_weights.py"""
+    import importlib.util
+    import random
+    import re
+    from conftest import PKG
+    from utils.mp_game_runner import MPGameRunner
+
+    def load_script(name):
+        spec = importlib.util.spec_from_file_location("entry_" + name, os.path.join(PKG, name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    random.seed(11); np.random.seed(11)
+    monkeypatch.chdir(tmp_path)
+    MPGameRunner.verbose = False
+    train, pit = load_script("train"), load_script("pit")
+    train.start("lad", 0, max_iterations=2, self_play_games=6, max_MCTS_depth=4, max_MCTS_breadth=8,
+                initial_learning_rate=1e-3)
+    assert all(os.path.exists(f"models/lad{g}.h5") for g in (0, 1, 2)) and not os.path.exists("models/lad3.h5")
+    assert open("log.csv").read().splitlines()[0] == "new model lad"
+    resumed = train.start("lad", 2, max_iterations=0)                     # a later start loads the file (train.py:34-36)
+    assert resumed.input_shape == (21, 21, 3)
+
+    played = pit.ladder("lad", 0, pit_games=24, poll_seconds=0, max_polls=1)
+    assert [g for g, _, _ in played] == [1, 2]
+    lines = open("pit.txt").read().splitlines()
+    assert lines[0] == "lad0 is set to be the baseline champion." and len(lines) == 3
+    for (g, score, took), line in zip(played, lines[1:]):
+        assert 0.0 <= score <= 1.0 and abs(score * 48 - round(score * 48)) < 1e-9     # half points over 24 games
+        assert took == (score > 0.51)
+        assert line + "\n" == pit.verdict_line(f"lad{g}", score)
+        assert re.fullmatch(r"lad\d (beats|failed to beat) the previouse champion\. score = [0-9.e-]+\.( It is the new champion!)?", line)
+    assert "A new challenger, lad1" in capsys.readouterr().out
+
+    load_script("test_pit").main(["lad1", "lad2"], games=12)
+    out = capsys.readouterr().out
+    assert out.count("Running games...") == 3 and out.count("Competing time") == 3
+    assert re.search(r"1v3 Win Rate of lad1 [0-9.]+ Draw Rate = [0-9.]+", out) and "2v2 Win Rate of lad2" in out
+
+    rewards, runner = load_script("test_model").play_one("lad2")
+    assert len(rewards) == 1 and sorted(set(rewards[0])) in ([-1.0], [-1.0, 1.0])
+    boards = open("replay.rep").read().split("\n\n")
+    assert len(boards) >= 2 * runner.game_length and boards[0].startswith("[")
+
+    load_script("test_weights").main(["lad2"])
+    out = capsys.readouterr().out
+    assert out.count("Min weight:") == 54 and "(3, 3, 128, 128)" in out
