@@ -16,7 +16,8 @@ What is recorded:
                    blake2b for all), obstacle masks (alpha_nnet.py:63-76)
   tables.npz       Agent.softermax / Agent.argmaxs tables (agent.py:114-137)
   mcts_tiny.npz    2-game MCTS self-play with a deterministic stub net and taped
-                   uniforms (Agent.make_moves / MCTSAgent.make_moves)
+                   uniforms (Agent.make_moves / MCTSAgent.make_moves); mcts_tiny_greedybase,
+                   mcts_7x7x2, mcts_9x9x3, mcts_19x19x8: the same at other settings / geometries
   runner.npz       MPGameRunner.run with a taped-move agent: rewards + counters
   pit.npz          pit_mp_game_runner.MPGameRunner.run with two stub nets (1v3, 2v2, 3v1):
                    start boards, spawn tape, moves, winner indices
@@ -738,7 +739,7 @@ def record_replay(seed=31, H=11, W=11, S=4, hd=9):
 
 if __name__ == "__main__":
     os.chdir("/tmp")
-    which = set(sys.argv[1:]) or {"tic", "tic_more", "corner", "tables", "mcts", "runner", "pit", "replay"}
+    which = set(sys.argv[1:]) or {"tic", "tic_more", "corner", "tables", "mcts", "mcts_more", "runner", "pit", "replay"}
     if "tic" in which:
         record_trajectories("11x11x4", 11, 11, 4, 1, 40, seed=1, p_legal=0.92, max_ticks=400, raw_every=23)
         record_trajectories("11x11x4_dec9", 11, 11, 4, 9, 10, seed=2, p_legal=0.97, max_ticks=400, raw_every=29)
@@ -756,6 +757,10 @@ if __name__ == "__main__":
     if "mcts" in which:
         record_mcts_tiny("tiny", n_games=2, breadth=16, depth=8, base=2, seed=11, max_turns=12)
         record_mcts_tiny("tiny_greedybase", n_games=3, breadth=8, depth=4, base=10, seed=12, max_turns=8)
+    if "mcts_more" in which:     # the same recording at other geometries (2 snakes: the deepest rollouts; 8 snakes: depth cap <= 0)
+        record_mcts_tiny("7x7x2", n_games=3, breadth=16, depth=8, base=2, seed=13, max_turns=10, H=7, W=7, S=2, hd=3)
+        record_mcts_tiny("19x19x8", n_games=1, breadth=8, depth=8, base=3, seed=14, max_turns=5, H=19, W=19, S=8, hd=1)
+        record_mcts_tiny("9x9x3", n_games=2, breadth=24, depth=6, base=5, seed=15, max_turns=8, H=9, W=9, S=3, hd=9)
     if "runner" in which:
         record_runner()
     if "pit" in which:

@@ -12,7 +12,7 @@ from conftest import load_golden
 KEYS = ("alive", "health", "length", "dir", "nodes", "food", "rewards", "counters")
 
 
-@pytest.mark.parametrize("tag", ["tiny", "tiny_greedybase"])
+@pytest.mark.parametrize("tag", ["tiny", "tiny_greedybase", "7x7x2", "19x19x8", "9x9x3"])
 @pytest.mark.parametrize("callback_net", [False, True])
 def test_c_mcts_replays_the_reference_run(oracle, tag, callback_net):
     from oracle.mcts_cpu import CpuSelfPlay

@@ -49,7 +49,7 @@ def _golden_engine(se, z, chance=0.15):
     return eng, (H, W, S, hd, n)
 
 
-@pytest.mark.parametrize("tag", ["tiny", "tiny_greedybase"])
+@pytest.mark.parametrize("tag", ["tiny", "tiny_greedybase", "7x7x2", "19x19x8", "9x9x3"])
 def test_sequential_mode_replays_the_reference_run(env, tag):
     torch, se = env
     from snake_engine.mcts import DeviceMCTS

@@ -8,7 +8,7 @@ import pytest
 from conftest import load_golden
 
 
-@pytest.mark.parametrize("tag", ["tiny", "tiny_greedybase"])
+@pytest.mark.parametrize("tag", ["tiny", "tiny_greedybase", "7x7x2", "19x19x8", "9x9x3"])
 def test_mcts_self_play_matches_reference_bitwise(oracle, tag):
     from oracle.mcts_oracle import SelfPlayOracle, Draws
     from oracle.obs_key import StubNet
