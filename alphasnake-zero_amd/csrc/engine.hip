@@ -57,6 +57,16 @@ __device__ static inline int row_share16(int v, int o)
     }
 }
 
+// A game's lanes all sit in ONE wavefront and its LDS region is touched by no other wave, so the phases of a kernel need
+// no workgroup barrier: LDS instructions of one wave execute in issue order; what is needed is that the compiler keeps
+// them in program order across the phase boundary (a wavefront-scope fence + the wave barrier, which emit no s_barrier).
+#define GAME_SYNC()                                                                                     \
+    do {                                                                                                \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                          \
+        __builtin_amdgcn_wave_barrier();                                                                \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                          \
+    } while (0)
+
 // per-wave LDS carve-up used by step / observe
 __host__ __device__ static inline int lds_per_wave(const Layout &L) { return L.stride + 4 * L.nc_pad + 64; }
 // k_observe adds an output canvas of (2H-1)(2W-1)3 floats (+ alignment slack)
@@ -111,7 +121,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
     if (valid)
         for (int i = sl; i < L.stride / 16; i += GL) ((uint4 *)g)[i] = ((const uint4 *)gsrc)[i];
     for (int i = sl * 16; i < 2 * L.nc_pad; i += GL * 16) *(uint4 *)(occ + i) = make_uint4(0u, 0u, 0u, 0u);   // both byte planes
-    __syncthreads();
+    GAME_SYNC();
 
     SnakeMeta *meta = (SnakeMeta *)(g + L.meta_off);
     uint64_t *food = (uint64_t *)(g + L.food_off);
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
         const int co = GSHFL(head_cell, o);
         if (eo && sl == 0) food[co >> 6] &= ~(1ull << (co & 63));
     }
-    __syncthreads();
+    GAME_SYNC();
 
     // ---- Game.bodies / Game.heads as LDS byte planes, rebuilt from the rings by all lanes of the game
 #pragma unroll
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
         }
     }
     if (go && !oob) hd[head_cell] = 1;
-    __syncthreads();
+    GAME_SYNC();
 
     // ---- spawn food (game.py:130-138).  The game's empty-cell mask is assembled 64 cells per word from GL-cell ballots.
     int spawn = -1;
@@ -280,13 +290,258 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
             cnt[4] += n_eat; cnt[5] += 1;              // game_length (game.py:197)
         }
     }
-    __syncthreads();
+    GAME_SYNC();
     if (!ended)
         for (int i = sl; i < L.stride / 16; i += GL) ((uint4 *)gsrc)[i] = ((const uint4 *)g)[i];
     if (done_out && valid && sl == 0) done_out[gi] = (uint8_t)(ended || n_alive <= 1);
     if (done_out && frozen && sl == 0) done_out[gi] = 0;
 #undef GSHFL
 #undef GBALLOT
+}
+
+// ------------------------------------------------------------------------------------------
+// Game.tic again, for games of at most 4 snakes on boards of at most 255 cells: ONE LANE PER SNAKE, a quad per game,
+// sixteen games per wavefront.  k_step above is VALU-issue bound (SQ counters at 262 144 games: 455 VALU instructions
+// per wave of four games, three quarters of its lanes idle in the per-snake steps); here every lane of the per-snake steps
+// works, cross-snake questions are DPP quad_perm moves (one VALU instruction, no LDS crossbar), the body and head
+// occupancy are LDS BIT planes filled with ds_or_b32 by each snake's own lane (its ring walk is sequential), the
+// empty-cell mask of the food spawn is three 64-bit logic operations per word, and the death / eat counts of a game
+// travel as one packed quad sum.  Same record, same arguments, same results as k_step.
+// ------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int q_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+__host__ __device__ constexpr int q_stride(int nc, int s)          // make_layout's stride for 8-bit rings
+{
+    return (s * q_pow2(nc + 2) + s * 8 + (nc + 63) / 64 * 8 + 24 + (s + 3) / 4 * 4 + 4 + 15) / 16 * 16;
+}
+__device__ static inline int quad_bcast(int v, int o)              // lane o of the quad
+{
+    switch (o & 3) {
+    case 0: return __builtin_amdgcn_update_dpp(0, v, 0x00, 0xF, 0xF, true);
+    case 1: return __builtin_amdgcn_update_dpp(0, v, 0x55, 0xF, 0xF, true);
+    case 2: return __builtin_amdgcn_update_dpp(0, v, 0xAA, 0xF, 0xF, true);
+    default: return __builtin_amdgcn_update_dpp(0, v, 0xFF, 0xF, 0xF, true);
+    }
+}
+__device__ static inline int quad_sum(int v)                       // all four lanes get the sum
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+    return v;
+}
+// LDS per game of the quad form: the record + two bit planes (bodies, heads) of QFW 64-bit words each
+__host__ __device__ static inline int lds_per_game_quad(const Layout &L) { return L.stride + 16 * ((L.FW + 1) / 2) * 2; }
+
+template <int H, int W, int SS>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_step_quad(uint8_t *__restrict__ state, Layout L,
+                                                            const int32_t *__restrict__ slots, int n,
+                                                            const uint8_t *__restrict__ moves,
+                                                            const int16_t *__restrict__ spawn_tape,
+                                                            uint8_t *__restrict__ done_out,
+                                                            int16_t *__restrict__ spawned_out,
+                                                            uint64_t *__restrict__ empty_out, int health_dec,
+                                                            double chance, uint32_t seed_lo, uint32_t seed_hi,
+                                                            const uint8_t *__restrict__ active)
+{
+    using cell_t = uint8_t;
+    const int HH = H > 0 ? H : L.H, WW = W > 0 ? W : L.W;
+    const int NC = HH * WW;
+    constexpr int QFW = H > 0 ? (H * W + 63) / 64 : 4;             // 64-bit words of a bit plane (255 cells at most)
+    constexpr int CHUNKS = (H > 0 && SS > 0) ? q_stride(H * W, SS) / 16 : 0;
+    constexpr int GPWQ = 16;
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sl = lane & 3, gq = lane >> 2;
+    const int gi = (blockIdx.x * WAVES_PER_BLOCK + wv) * GPWQ + gq;
+    const bool frozen = gi < n && active && !active[gi];
+    const bool valid = gi < n && !frozen;
+    const int S = SS > 0 ? SS : L.S, mask = L.cap_mask;
+    const int FW = H > 0 ? QFW : L.FW;
+    const int plane_bytes = 8 * ((L.FW + 1) / 2) * 2;
+    uint8_t *g = smem + (size_t)(wv * GPWQ + gq) * L.stride;                       // records first: 16-byte chunks stay aligned
+    uint32_t *bodies = (uint32_t *)(smem + (size_t)WAVES_PER_BLOCK * GPWQ * L.stride
+                                    + (size_t)(wv * GPWQ + gq) * 2 * plane_bytes);
+    uint32_t *heads = bodies + plane_bytes / 4;
+    const int slot = valid ? (slots ? slots[gi] : gi) : 0;
+    uint8_t *gsrc = state + (size_t)slot * L.stride;
+
+    const int mv_in = (valid && sl < S) ? moves[(size_t)gi * S + sl] : 1;
+    const int tape_in = (valid && spawn_tape) ? spawn_tape[gi] : -1;
+    if (CHUNKS > 0) {                                              // all loads of the record in flight at once
+        uint4 t[(CHUNKS + 3) / 4 > 0 ? (CHUNKS + 3) / 4 : 1];         // unconditional loads (an idle quad re-reads slot 0's
+#pragma unroll                                                       // first chunk), so that the array stays in registers
+        for (int j = 0; j < (CHUNKS + 3) / 4; ++j)
+            t[j] = ((const uint4 *)gsrc)[valid ? min(sl + 4 * j, CHUNKS - 1) : 0];
+#pragma unroll
+        for (int j = 0; j < (CHUNKS + 3) / 4; ++j)
+            if (valid && sl + 4 * j < CHUNKS) ((uint4 *)g)[sl + 4 * j] = t[j];
+    } else if (valid) {
+        for (int i = sl; i < L.stride / 16; i += 4) ((uint4 *)g)[i] = ((const uint4 *)gsrc)[i];
+    }
+    for (int i = sl; i < plane_bytes / 2; i += 4) bodies[i] = 0u;                 // both planes
+    GAME_SYNC();
+
+    SnakeMeta *meta = (SnakeMeta *)(g + L.meta_off);
+    uint64_t *food = (uint64_t *)(g + L.food_off);
+    uint32_t *food32 = (uint32_t *)(g + L.food_off);
+    uint32_t *cnt = (uint32_t *)(g + L.cnt_off);
+    int8_t *rew = (int8_t *)(g + L.rew_off);
+
+    const bool act = valid && sl < S;
+    SnakeMeta m = {0, 0, 0, 0, 0};
+    if (act) m = meta[sl];
+    const bool alive0 = act && m.alive;
+    const int n_alive0 = quad_sum((int)alive0);
+    const bool ended = !valid || n_alive0 <= 1;
+    const bool go = alive0 && !ended;
+    cell_t *ring = (cell_t *)(g + (sl < S ? sl : 0) * L.ring_bytes);
+
+    // ---- execute moves (game.py:90-114) + health (117-118)
+    int head_cell = -1;
+    bool oob = false;
+    if (go) {
+        const int d = (mv_in + m.dir + 3) & 3;
+        m.dir = (uint8_t)d;
+        const int hi = (m.tail + m.len - 1) & mask;
+        const int hc = ring[hi];
+        int y = hc / WW, x = hc - y * WW;
+        y += (d == 2) - (d == 0);
+        x += (d == 1) - (d == 3);
+        oob = (y < 0) | (y >= HH) | (x < 0) | (x >= WW);
+        head_cell = oob ? -1 : y * WW + x;
+        m.tail = (uint16_t)((m.tail + 1) & mask);
+        if (!oob) ring[(hi + 1) & mask] = (cell_t)head_cell;
+        m.health = (int16_t)(m.health - health_dec);
+    }
+    // ---- food (game.py:121-127): the first snake in list order on a cell eats
+    const bool hasfood = go && !oob && ((food32[head_cell >> 5] >> (head_cell & 31)) & 1u);
+    bool eats = hasfood;
+    const int fcell = hasfood ? head_cell : -1;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const int fo = quad_bcast(fcell, o);
+        if (o < sl && fo >= 0 && fo == head_cell) eats = false;
+    }
+    if (eats) {
+        m.health = 100;
+        const int t = (m.tail - 1) & mask;
+        ring[t] = ring[m.tail];                        // duplicate the tail node (Snake.grow game.py:360-365)
+        m.tail = (uint16_t)t;
+        m.len = (uint16_t)(m.len + 1);
+        atomicAnd(&food32[head_cell >> 5], ~(1u << (head_cell & 31)));
+    }
+    // ---- Game.bodies / Game.heads as bit planes: every snake's own lane walks its ring
+    if (go) {
+        for (int k = 0; k < (int)m.len - 1; ++k) {
+            const int c = ring[(m.tail + k) & mask];
+            atomicOr(&bodies[c >> 5], 1u << (c & 31));
+        }
+        if (!oob) atomicOr(&heads[head_cell >> 5], 1u << (head_cell & 31));
+    }
+    GAME_SYNC();
+
+    // ---- spawn food (game.py:130-138): empty = not body, not head, not food
+    int spawn = -1;
+    if (chance > 0.0 && !ended) {
+        int n_food = 0, n_empty = 0;
+        uint64_t emk[QFW];
+#pragma unroll
+        for (int w = 0; w < QFW; ++w) {
+            emk[w] = 0ull;
+            if (w < FW) {
+                const uint64_t fw = food[w];
+                const uint64_t used = fw | ((const uint64_t *)bodies)[w] | ((const uint64_t *)heads)[w];
+                const int left = NC - 64 * w;                                       // cells of this word
+                const uint64_t cells = left >= 64 ? ~0ull : ((1ull << (left > 0 ? left : 0)) - 1ull);
+                emk[w] = ~used & cells;
+                n_food += __popcll(fw);
+                n_empty += __popcll(emk[w]);
+                if (empty_out && sl == 0) empty_out[(size_t)gi * L.FW + w] = emk[w];
+            }
+        }
+        if (spawn_tape) {
+            spawn = tape_in;
+        } else {
+            const uint32_t uid = *(const uint32_t *)(g + L.uid_off);
+            uint32_t r[4];
+            philox4x32(uid, cnt[5], 0x5350574Eu /* 'SPWN' */, 0u, seed_lo, seed_hi, r);
+            const double u1 = ((double)r[0] + 0.5) * (1.0 / 4294967296.0);
+            if ((n_food == 0 || u1 <= chance) && n_empty > 0) {
+                int k = (int)(((uint64_t)r[1] * (uint64_t)n_empty) >> 32);
+#pragma unroll
+                for (int w = 0; w < QFW; ++w) {
+                    const uint64_t mk = emk[w];
+                    const int pc = __popcll(mk);
+                    if (spawn < 0) {
+                        if (k < pc) {
+                            uint64_t t = mk;
+                            int pos = 0;
+#pragma unroll
+                            for (int sh = 32; sh >= 1; sh >>= 1) {
+                                const int cl = __popcll(t & ((1ull << sh) - 1ull));
+                                if (k >= cl) { k -= cl; t >>= sh; pos += sh; }
+                            }
+                            spawn = w * 64 + pos;
+                        } else {
+                            k -= pc;
+                        }
+                    }
+                }
+            }
+        }
+    } else if (empty_out && valid && sl == 0) {
+        for (int w = 0; w < L.FW; ++w) empty_out[(size_t)gi * L.FW + w] = 0ull;
+    }
+    if (spawned_out && valid && sl == 0) spawned_out[gi] = (int16_t)spawn;
+
+    // ---- deaths (game.py:144-165) and removal (167-192)
+    const bool body_hit = go && !oob && ((bodies[head_cell >> 5] >> (head_cell & 31)) & 1u);
+    bool shared = false, lose = false;
+    const int hl = (head_cell + 1) | ((int)m.len << 9);            // head_cell + 1 <= 255, length in the bits above
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const int q = quad_bcast(hl, o);
+        const int ho = (q & 511) - 1, lo = q >> 9;
+        if (o != sl && ho >= 0 && ho == head_cell) {
+            shared = true;
+            if ((int)m.len <= lo) lose = true;
+        }
+    }
+    int cause = -1;
+    if (go) {
+        if (oob) cause = 0;
+        else if (body_hit) cause = 1;
+        else if (shared) { if (lose) cause = 2; }
+        else if (m.health <= 0) cause = 3;
+    }
+    const bool dead = cause >= 0;
+    const int tally = quad_sum((cause >= 0 ? 1 << (3 * cause) : 0) | ((go && !dead) ? 1 << 12 : 0) | (eats ? 1 << 15 : 0));
+    const int n_alive = (tally >> 12) & 7;
+    if (!ended) {
+        if (dead) {
+            m.alive = 0; m.len = 0; m.health = 0; m.dir = 0; m.tail = 0;
+            rew[sl] = -1;
+        } else if (go && n_alive == 1) {
+            rew[sl] = 1;
+        }
+        if (act) meta[sl] = m;
+        if (sl == 0) {
+            if (spawn >= 0) food[spawn >> 6] |= 1ull << (spawn & 63);
+            cnt[0] += tally & 7; cnt[1] += (tally >> 3) & 7; cnt[2] += (tally >> 6) & 7; cnt[3] += (tally >> 9) & 7;
+            cnt[4] += (tally >> 15) & 7; cnt[5] += 1;
+        }
+    }
+    GAME_SYNC();
+    if (!ended) {
+        if (CHUNKS > 0) {
+#pragma unroll
+            for (int j = 0; j < (CHUNKS + 3) / 4; ++j)
+                if (sl + 4 * j < CHUNKS) ((uint4 *)gsrc)[sl + 4 * j] = ((const uint4 *)g)[sl + 4 * j];
+        } else {
+            for (int i = sl; i < L.stride / 16; i += 4) ((uint4 *)gsrc)[i] = ((const uint4 *)g)[i];
+        }
+    }
+    if (done_out && valid && sl == 0) done_out[gi] = (uint8_t)(ended || n_alive <= 1);
+    if (done_out && frozen && sl == 0) done_out[gi] = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -784,7 +1039,14 @@ static int step_launch(snk_engine *e, const int32_t *d_slots, int n, const uint8
     // four games per wavefront where the per-game LDS is small (11x11, 7x7), one per wavefront on 19x19
 #define STEP_ARGS e->d_state, L, d_slots, n, d_moves, d_spawn_tape, d_done, d_spawned, d_empty, e->health_dec, e->food_chance, \
                   (uint32_t)e->seed, (uint32_t)(e->seed >> 32), d_active
-    if (L.H <= 11) {
+    static const bool wide = getenv("SNK_STEP_FORM") && !strcmp(getenv("SNK_STEP_FORM"), "wide");   // A/B: the lane-group kernel
+    if (L.S <= 4 && L.NC <= 255 && !wide) {               // a quad per game, sixteen games per wavefront
+        const size_t lds = (size_t)WAVES_PER_BLOCK * 16 * lds_per_game_quad(L);
+        const int grid = (n + WAVES_PER_BLOCK * 16 - 1) / (WAVES_PER_BLOCK * 16);
+        if (L.H == 11 && L.W == 11 && L.S == 4) k_step_quad<11, 11, 4><<<grid, BLOCK_THREADS, lds, (hipStream_t)stream>>>(STEP_ARGS);
+        else if (L.H == 7 && L.W == 7 && L.S == 2) k_step_quad<7, 7, 2><<<grid, BLOCK_THREADS, lds, (hipStream_t)stream>>>(STEP_ARGS);
+        else k_step_quad<0, 0, 0><<<grid, BLOCK_THREADS, lds, (hipStream_t)stream>>>(STEP_ARGS);
+    } else if (L.H <= 11) {
         const size_t lds = (size_t)WAVES_PER_BLOCK * 4 * lds_per_wave(L);
         const int grid = (n + WAVES_PER_BLOCK * 4 - 1) / (WAVES_PER_BLOCK * 4);
         if (L.H == 11 && L.S == 4) k_step<11, 11, 16, 4><<<grid, BLOCK_THREADS, lds, (hipStream_t)stream>>>(STEP_ARGS);
