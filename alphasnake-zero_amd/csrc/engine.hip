@@ -69,7 +69,12 @@ __device__ static inline int row_share16(int v, int o)
 
 // per-wave LDS carve-up used by step / observe
 __host__ __device__ static inline int lds_per_wave(const Layout &L) { return L.stride + 4 * L.nc_pad + 64; }
-// k_observe adds an output canvas of (2H-1)(2W-1)3 floats (+ alignment slack)
+// k_observe, NHWC planes: a canvas of the H window rows, 3 (2W-1) H floats (+ two pieces of slack at the ends)
+__host__ __device__ static inline int lds_per_wave_win(const Layout &L)
+{
+    return lds_per_wave(L) + ((3 * (2 * L.W - 1) * L.H + 8) * 4 + 15) / 16 * 16;
+}
+// k_observe, channel-major planes: an output canvas of (2H-1)(2W-1)3 floats (+ alignment slack)
 __host__ __device__ static inline int lds_per_wave_obs(const Layout &L)
 {
     return lds_per_wave(L) + (((2 * L.H - 1) * (2 * L.W - 1) * 3 + 8) * 4 + 15) / 16 * 16;
@@ -691,12 +696,14 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
     static_assert(H == W, "only square boards batch (rot90 transposes odd-k shapes)");
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr int GPW = 64 / GL;                       // observations per wavefront
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // wave-uniform values are made scalar (readfirstlane): with a whole wavefront per observation everything derived from
+    // the pair, the observing snake's meta word and its head then runs on the scalar unit instead of costing VALU issue
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sl = lane % GL, gq = lane / GL;
     const int pi = (blockIdx.x * WPB + wv) * GPW + gq;
     const bool valid = pi < m;
     const int S = L.S, mask = L.cap_mask;
-    uint8_t *g = smem + (wv * GPW + gq) * (planes ? lds_per_wave_obs(L) : lds_per_wave(L));
+    uint8_t *g = smem + (wv * GPW + gq) * (!planes ? lds_per_wave(L) : layout == SNK_NHWC_F32 ? lds_per_wave_win(L) : lds_per_wave_obs(L));
     uint16_t *ttl = (uint16_t *)(g + L.stride);             // max tail-distance of any node on the cell
     uint8_t *hidx = (uint8_t *)(g + L.stride + 2 * L.nc_pad);  // 1 + id of the snake whose head is here
     float *hval = (float *)(g + L.stride + 4 * L.nc_pad);   // channel-0 value per snake id (8 floats)
@@ -707,32 +714,45 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
     if (valid)
         for (int i = sl; i < L.stride / 16; i += GL) ((uint4 *)g)[i] = ((const uint4 *)gsrc)[i];
     for (int i = sl * 4; i < 4 * L.nc_pad; i += GL * 4) *(uint32_t *)((uint8_t *)ttl + i) = 0u;
-    __syncthreads();
+    GAME_SYNC();
 
     const SnakeMeta *meta = (const SnakeMeta *)(g + L.meta_off);
     const uint64_t *food = (const uint64_t *)(g + L.food_off);
-    const SnakeMeta me = meta[you];
+    SnakeMeta me = meta[you];
+    if (GL == 64) {
+        uint2 w = *(const uint2 *)&me;
+        w.x = __builtin_amdgcn_readfirstlane(w.x); w.y = __builtin_amdgcn_readfirstlane(w.y);
+        me = *(const SnakeMeta *)&w;
+    }
     const bool live = valid && me.alive;
 
     // body plane: walking tail -> head with dist 1,2,... the last write wins (game.py:236-241);
     // only the node nearest the head of a run of stacked nodes writes, so there is no race.
-    for (int s = 0; s < S; ++s) {
+    // With a whole wavefront per observation and at most four snakes, sixteen lanes walk each snake at once (one pass for
+    // bodies of up to 16 nodes) instead of all lanes walking the snakes one after the other.  (Alive snakes never share a
+    // cell in a state a tick produced, so the order between snakes does not matter.)
+    constexpr int LPS = GL == 64 ? 16 : GL;              // lanes per snake
+    const bool by_snake = GL == 64 && S <= 4;
+    for (int s0 = 0; s0 < S; ++s0) {
         if (!valid) break;                               // an idle wave holds no record: touch nothing
+        const int s = by_snake ? sl / LPS : s0;
+        if (by_snake && (s0 > 0 || s >= S)) break;
         const SnakeMeta ms = meta[s];
         if (!ms.alive) continue;
         const cell_t *r = (const cell_t *)(g + s * L.ring_bytes);
-        for (int k = sl; k < ms.len; k += GL) {
+        for (int k = by_snake ? sl % LPS : sl; k < ms.len; k += LPS) {
             const int c = r[(ms.tail + k) & mask];
             const bool last = (k == ms.len - 1) || (r[(ms.tail + k + 1) & mask] != c);
             if (last) ttl[c] = (uint16_t)(k + 1);
             if (k == ms.len - 1) hidx[c] = (uint8_t)(s + 1);
         }
-        if (sl == 0)   // (snake.length - (you.length - 0.5)) * 0.04 in float64, then float32 (game.py:229-232,257)
+        if ((by_snake ? sl % LPS : sl) == 0)   // (snake.length - (you.length - 0.5)) * 0.04 in float64, then float32 (game.py:229-232,257)
             hval[s] = (float)(((double)ms.len - ((double)me.len - 0.5)) * 0.04);
     }
-    __syncthreads();
+    GAME_SYNC();
 
-    const int my_head = (int)((const cell_t *)(g + you * L.ring_bytes))[(me.tail + me.len - 1) & mask];
+    int my_head = (int)((const cell_t *)(g + you * L.ring_bytes))[(me.tail + me.len - 1) & mask];
+    if (GL == 64) my_head = __builtin_amdgcn_readfirstlane(my_head);
     const int hy = my_head / WW, hx = my_head - hy * WW;
     const int k = me.dir & 3;
     const float fval = (float)((double)(101 - (int)me.health) * 0.01);   // game.py:243-244
@@ -745,8 +765,67 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
         return food_bit(food, c) ? fval : 0.0f;
     };
 
-    if (planes) {
-        // The observation is the wall pattern almost everywhere (441 canvas pixels, 121 board cells): fill an LDS
+    if (planes && layout == SNK_NHWC_F32) {
+        // The reference's layout, the one the net reads: every output byte is written once, in aligned 16-byte pieces.
+        // The observation is the wall pattern (0, 1, 0 per pixel) except inside the H canvas rows the board window occupies
+        // -- one contiguous element range.  Pieces outside that range go out straight from registers (the pattern of a piece
+        // depends on the channel of its first element only, which advances by one from a lane's piece to its next: three
+        // float4 registers used in turn); pieces inside it are first laid into a small LDS canvas (window rows only), the
+        // board cells are scattered over them there, and the canvas is streamed out.  Measured on the way: the full-canvas
+        // form with per-element pattern arithmetic was VALU-issue bound (SQ counters: 715 VALU instructions per observation,
+        // 104 us of VALU issue against 67 us of HBM time at 78 229 observations); pattern everywhere + cells stored over it
+        // as 12-byte pixels cost 50 us for the cells alone (partial-line writes of lines that had left the L2).
+        float *out = planes + (size_t)pi * NEL;
+        const int lead = (int)(((size_t)pi * NEL) & 3);               // out + e is 16-byte aligned where (e + lead) % 4 == 0
+        const int nvec = (NEL + lead + 3) / 4;                          // piece q = elements 4 q - lead .. 4 q - lead + 3
+        float *cvs = (float *)(g + L.stride + 4 * L.nc_pad + 64);      // cvs[4 (q - qa) + t] <-> element 4 q - lead + t
+        int qa = 0, qb = 0;                                            // pieces of the window rows
+        if (live) {
+            const int i0 = k == 0 ? HH - 1 - hy : k == 1 ? hx : k == 2 ? hy : WW - 1 - hx;   // first canvas row of the window
+            qa = (3 * N * i0 + lead) >> 2;
+            qb = (3 * N * (i0 + HH) + lead + 3) >> 2;
+        }
+        auto store_piece = [&](int q, const float4 &v) {
+            const int e0 = 4 * q - lead;
+            if (e0 >= 0 && e0 + 3 < NEL) {
+                *(float4 *)(out + e0) = v;
+            } else {                                                   // the first / last piece of the observation
+                const float pv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (e0 + t >= 0 && e0 + t < NEL) out[e0 + t] = pv[t];
+            }
+        };
+        if (valid) {
+            static_assert((4 * GL) % 3 == 1, "the channel of a lane's next piece advances by one");
+            const int c0 = (4 * sl - lead + 3) % 3;                    // channel of the first element of piece q = sl
+            const float one = live ? 1.0f : 0.0f;                      // the observation of a dead snake is all zeros
+            const float a = c0 == 0 ? one : 0.0f, b = c0 == 1 ? one : 0.0f, c = c0 == 2 ? one : 0.0f;
+            float4 p0 = make_float4(b, a, c, b), p1 = make_float4(a, c, b, a), p2 = make_float4(c, b, a, c);
+            for (int q = sl; q < nvec; q += GL) {
+                if (q >= qa && q < qb) *(float4 *)(cvs + 4 * (q - qa)) = p0;
+                else store_piece(q, p0);
+                const float4 t4 = p0; p0 = p1; p1 = p2; p2 = t4;
+            }
+        }
+        GAME_SYNC();
+        if (live)
+            for (int c = sl; c < NC; c += GL) {
+                const int y = c / WW, x = c - y * WW;
+                const int si = y - hy + (HH - 1), sj = x - hx + (WW - 1);
+                int i, j;                              // numpy.rot90(grid, k): out[i][j] = grid[si][sj], inverted
+                if (k == 0) { i = si; j = sj; }
+                else if (k == 1) { i = N - 1 - sj; j = si; }
+                else if (k == 2) { i = N - 1 - si; j = N - 1 - sj; }
+                else { i = sj; j = N - 1 - si; }
+                float *px = cvs + (3 * (i * N + j) + lead - 4 * qa);
+                px[0] = cell_val(c, 0); px[1] = cell_val(c, 1); px[2] = cell_val(c, 2);
+            }
+        GAME_SYNC();
+        if (live)
+            for (int q = qa + sl; q < qb; q += GL) store_piece(q, *(const float4 *)(cvs + 4 * (q - qa)));
+    } else if (planes) {
+        // The channel-major layouts.  The observation is the wall pattern almost everywhere (441 canvas pixels, 121 board cells): fill an LDS
         // canvas with the pattern, scatter the board cells into their rotated positions, stream the canvas out
         // with 16-byte stores.  The canvas is shifted by `lead` floats so that LDS and HBM addresses are congruent
         // mod 16 bytes whatever the row's position in the output array.
@@ -779,7 +858,7 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
                 ch0 -= ch0 >= 3 ? 3 : 0;
             }
         }
-        __syncthreads();
+        GAME_SYNC();
         if (live)
             for (int c = sl; c < NC; c += GL) {
                 const int y = c / WW, x = c - y * WW;
@@ -794,7 +873,7 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
                 for (int ch = 0; ch < 3; ++ch)
                     cv[(layout == SNK_NHWC_F32) ? 3 * pp + ch : ch * NPIX + pp] = cell_val(c, ch);
             }
-        __syncthreads();
+        GAME_SYNC();
         if (valid && layout == SNK_NCHW_BF16) {            // same values, channel-major, rounded to bf16 (nearest even)
             unsigned short *o16 = (unsigned short *)planes + (size_t)pi * NEL;
             for (int e = sl; e < NEL; e += GL) {
@@ -1115,7 +1194,7 @@ extern "C" int snk_engine_observe(const snk_engine *e, const int32_t *d_pairs, i
         else if (L.H == 7) k_observe<7, 7, 16, WPB><<<grid, WPB * 64, lds, (hipStream_t)stream>>>(e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask);
         else k_observe<0, 0, 16, WPB><<<grid, WPB * 64, lds, (hipStream_t)stream>>>(e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask);
     } else {
-        const size_t lds = (size_t)WAVES_PER_BLOCK * (d_planes ? lds_per_wave_obs(L) : lds_per_wave(L));
+        const size_t lds = (size_t)WAVES_PER_BLOCK * (!d_planes ? lds_per_wave(L) : layout == SNK_NHWC_F32 ? lds_per_wave_win(L) : lds_per_wave_obs(L));
         DISPATCH_BOARD(L, (k_observe<BH, BW, 64, WAVES_PER_BLOCK><<<wave_grid(m), BLOCK_THREADS, lds, (hipStream_t)stream>>>(
             e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask)));
     }

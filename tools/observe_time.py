@@ -1,0 +1,41 @@
+"""k_observe on mid-game boards (32 warm-up ticks of uniform legal moves): planes form and mask + key form, time and HBM
+fraction.  Development tool: observe_time.py [games]"""
+import os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO, os.path.join(REPO, "alphasnake-zero_amd")]
+import numpy as np, torch
+import snake_engine as se
+import snake_engine._lib as _l
+_l.LIB_PATH = os.environ.get("OBS_LIB", _l.LIB_PATH)      # a development build of the library
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+eng = se.Engine(n, 11, 11, 4, 1, 0.15, seed=1234)
+eng.reset()
+g = torch.Generator(device="cuda").manual_seed(1234)
+sub = torch.arange(n, dtype=torch.int32, device="cuda").repeat_interleave(4)
+allp = torch.stack([sub, torch.arange(4, dtype=torch.int32, device="cuda").repeat(n)], dim=1).contiguous()
+blocked = torch.empty((4 * n, 3), dtype=torch.uint8, device="cuda")
+for _ in range(32):
+    eng.observe(allp, 4 * n, None, blocked, None)
+    r = torch.rand((4 * n, 3), device="cuda", generator=g) - 2.0 * blocked.float()
+    mv = torch.where(blocked.bool().all(dim=1), torch.ones((), dtype=torch.int64, device="cuda"), r.argmax(dim=1))
+    eng.step(mv.to(torch.uint8).reshape(n, 4).contiguous())
+pairs = torch.nonzero(eng.alive()).to(torch.int32).contiguous()
+m = pairs.shape[0]
+planes = torch.empty((m, 21, 21, 3), device="cuda")
+mask = torch.empty((m, 3), dtype=torch.uint8, device="cuda")
+key = torch.empty((m, 2), dtype=torch.int64, device="cuda")
+G = eng.slot_bytes
+def timed(fn, iters=10):
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e-3)
+    return float(np.median(ts))
+for name, fn, byts in (("planes", lambda: eng.observe(pairs, m, planes, None, None), m * (G + 5292)),
+                       ("mask+key", lambda: eng.observe(pairs, m, None, mask, key), m * (G + 19)),
+                       ("planes+mask+key", lambda: eng.observe(pairs, m, planes, mask, key), m * (G + 5292 + 19))):
+    t = timed(fn)
+    print(f"{m} observations, {name}: {t * 1e6:.1f} us, {byts / t / 1e12:.2f} TB/s = {byts / t / 8e12:.3f} of 8 TB/s")
+print("checksum", int(key.sum().item()) & 0xFFFFFFFF, float(planes.sum().item()), int(mask.sum().item()))
