@@ -69,15 +69,17 @@ __device__ static inline int row_share16(int v, int o)
 
 // per-wave LDS carve-up used by step / observe
 __host__ __device__ static inline int lds_per_wave(const Layout &L) { return L.stride + 4 * L.nc_pad + 64; }
-// k_observe, NHWC planes: a canvas of the H window rows, 3 (2W-1) H floats (+ two pieces of slack at the ends)
+// k_observe: the record + two float planes (channel 0 and channel 1 values per board cell)
+__host__ __device__ static inline int lds_per_obs(const Layout &L) { return L.stride + 8 * L.nc_pad; }
+// k_observe, NHWC planes: + a canvas of the H window rows, 3 (2W-1) H floats (+ two pieces of slack at the ends)
 __host__ __device__ static inline int lds_per_wave_win(const Layout &L)
 {
-    return lds_per_wave(L) + ((3 * (2 * L.W - 1) * L.H + 8) * 4 + 15) / 16 * 16;
+    return lds_per_obs(L) + ((3 * (2 * L.W - 1) * L.H + 8) * 4 + 15) / 16 * 16;
 }
-// k_observe, channel-major planes: an output canvas of (2H-1)(2W-1)3 floats (+ alignment slack)
+// k_observe, channel-major planes: + an output canvas of (2H-1)(2W-1)3 floats (+ alignment slack)
 __host__ __device__ static inline int lds_per_wave_obs(const Layout &L)
 {
-    return lds_per_wave(L) + (((2 * L.H - 1) * (2 * L.W - 1) * 3 + 8) * 4 + 15) / 16 * 16;
+    return lds_per_obs(L) + (((2 * L.H - 1) * (2 * L.W - 1) * 3 + 8) * 4 + 15) / 16 * 16;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -688,7 +690,7 @@ template <int H, int W, int GL, int WPB>
 __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict__ state, Layout L,
                                                           const int32_t *__restrict__ pairs, int m, int layout,
                                                           float *__restrict__ planes, uint8_t *__restrict__ mask_out,
-                                                          uint64_t *__restrict__ key_out, int legacy_mask)
+                                                          uint64_t *__restrict__ key_out, int legacy_mask, int reps)
 {
     using cell_t = typename CellT<H * W>::type;
     BOARD_DIMS(L)
@@ -700,20 +702,39 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
     // the pair, the observing snake's meta word and its head then runs on the scalar unit instead of costing VALU issue
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sl = lane % GL, gq = lane / GL;
-    const int pi = (blockIdx.x * WPB + wv) * GPW + gq;
-    const bool valid = pi < m;
+    // A lane group takes `reps` consecutive observations, one after the other, the next one's record already travelling
+    // while the current one is worked on: a wavefront's life is two dependent loads (pair, record), the work, and the wait
+    // for its stores to be acknowledged (s_endpgm waits for them); with one observation per wavefront that chain, not the
+    // instruction count or the HBM rate, set the time (measured: 8 192 wave slots x 5.3 KB per ~10 us lifetime).
+    const int pi0 = ((blockIdx.x * WPB + wv) * GPW + gq) * reps;
     const int S = L.S, mask = L.cap_mask;
-    uint8_t *g = smem + (wv * GPW + gq) * (!planes ? lds_per_wave(L) : layout == SNK_NHWC_F32 ? lds_per_wave_win(L) : lds_per_wave_obs(L));
-    uint16_t *ttl = (uint16_t *)(g + L.stride);             // max tail-distance of any node on the cell
-    uint8_t *hidx = (uint8_t *)(g + L.stride + 2 * L.nc_pad);  // 1 + id of the snake whose head is here
-    float *hval = (float *)(g + L.stride + 4 * L.nc_pad);   // channel-0 value per snake id (8 floats)
+    const int nch = L.stride / 16;
+    uint4 ahead = make_uint4(0u, 0u, 0u, 0u);             // chunk `sl` of the record of the next observation
+    int ahead_you = 0;
+    const uint8_t *ahead_src = state;
+    if (pi0 < m) {
+        ahead_src = state + (size_t)pairs[2 * pi0] * L.stride;
+        ahead_you = pairs[2 * pi0 + 1];
+        if (sl < nch) ahead = ((const uint4 *)ahead_src)[sl];
+    }
+    for (int rep = 0; rep < reps; ++rep) {
+    const int pi = pi0 + rep;
+    const bool valid = pi < m;
+    uint8_t *g = smem + (wv * GPW + gq) * (!planes ? lds_per_obs(L) : layout == SNK_NHWC_F32 ? lds_per_wave_win(L) : lds_per_wave_obs(L));
+    float *v1 = (float *)(g + L.stride);                    // channel 1 per board cell: 0.02 x the largest tail-distance of a node on it
+    float *v0 = v1 + L.nc_pad;                              // channel 0 per board cell: the head value of the snake whose head is here
 
-    const int slot = valid ? pairs[2 * pi] : 0;
-    const int you = valid ? pairs[2 * pi + 1] : 0;
-    const uint8_t *gsrc = state + (size_t)slot * L.stride;
+    const int you = ahead_you;
+    const uint8_t *gsrc = ahead_src;
+    if (valid && sl < nch) ((uint4 *)g)[sl] = ahead;
     if (valid)
-        for (int i = sl; i < L.stride / 16; i += GL) ((uint4 *)g)[i] = ((const uint4 *)gsrc)[i];
-    for (int i = sl * 4; i < 4 * L.nc_pad; i += GL * 4) *(uint32_t *)((uint8_t *)ttl + i) = 0u;
+        for (int i = sl + GL; i < nch; i += GL) ((uint4 *)g)[i] = ((const uint4 *)gsrc)[i];
+    if (rep + 1 < reps && pi + 1 < m) {                     // request the next record now
+        ahead_src = state + (size_t)pairs[2 * (pi + 1)] * L.stride;
+        ahead_you = pairs[2 * (pi + 1) + 1];
+        if (sl < nch) ahead = ((const uint4 *)ahead_src)[sl];
+    }
+    for (int i = sl * 16; i < 8 * L.nc_pad; i += GL * 16) *(uint4 *)((uint8_t *)v1 + i) = make_uint4(0u, 0u, 0u, 0u);   // both planes
     GAME_SYNC();
 
     const SnakeMeta *meta = (const SnakeMeta *)(g + L.meta_off);
@@ -743,11 +764,10 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
         for (int k = by_snake ? sl % LPS : sl; k < ms.len; k += LPS) {
             const int c = r[(ms.tail + k) & mask];
             const bool last = (k == ms.len - 1) || (r[(ms.tail + k + 1) & mask] != c);
-            if (last) ttl[c] = (uint16_t)(k + 1);
-            if (k == ms.len - 1) hidx[c] = (uint8_t)(s + 1);
+            if (last) v1[c] = (float)((double)(k + 1) * 0.02);          // float64 product, then float32 (game.py:236-241, 257)
+            if (k == ms.len - 1)   // (snake.length - (you.length - 0.5)) * 0.04 in float64, then float32 (game.py:229-232,257)
+                v0[c] = (float)(((double)ms.len - ((double)me.len - 0.5)) * 0.04);
         }
-        if ((by_snake ? sl % LPS : sl) == 0)   // (snake.length - (you.length - 0.5)) * 0.04 in float64, then float32 (game.py:229-232,257)
-            hval[s] = (float)(((double)ms.len - ((double)me.len - 0.5)) * 0.04);
     }
     GAME_SYNC();
 
@@ -760,8 +780,8 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
     // value of board cell c, channel ch, exactly as make_state writes it
     auto cell_val = [&](int c, int ch) -> float {
         if (c == my_head) return -1.0f;                                   // game.py:248
-        if (ch == 0) { const int h = hidx[c]; return h ? hval[h - 1] : 0.0f; }
-        if (ch == 1) { const int t = ttl[c]; return t ? (float)((double)t * 0.02) : 0.0f; }
+        if (ch == 0) return v0[c];
+        if (ch == 1) return v1[c];
         return food_bit(food, c) ? fval : 0.0f;
     };
 
@@ -778,38 +798,29 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
         float *out = planes + (size_t)pi * NEL;
         const int lead = (int)(((size_t)pi * NEL) & 3);               // out + e is 16-byte aligned where (e + lead) % 4 == 0
         const int nvec = (NEL + lead + 3) / 4;                          // piece q = elements 4 q - lead .. 4 q - lead + 3
-        float *cvs = (float *)(g + L.stride + 4 * L.nc_pad + 64);      // cvs[4 (q - qa) + t] <-> element 4 q - lead + t
+        float *cvs = (float *)(g + lds_per_obs(L));                    // cvs[4 (q - qa) + t] <-> element 4 q - lead + t
         int qa = 0, qb = 0;                                            // pieces of the window rows
         if (live) {
             const int i0 = k == 0 ? HH - 1 - hy : k == 1 ? hx : k == 2 ? hy : WW - 1 - hx;   // first canvas row of the window
             qa = (3 * N * i0 + lead) >> 2;
             qb = (3 * N * (i0 + HH) + lead + 3) >> 2;
         }
-        auto store_piece = [&](int q, const float4 &v) {
-            const int e0 = 4 * q - lead;
-            if (e0 >= 0 && e0 + 3 < NEL) {
-                *(float4 *)(out + e0) = v;
-            } else {                                                   // the first / last piece of the observation
-                const float pv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    if (e0 + t >= 0 && e0 + t < NEL) out[e0 + t] = pv[t];
-            }
-        };
+        const int q_lo = lead ? 1 : 0, q_hi = (NEL + lead) >> 2;       // pieces q_lo <= q < q_hi lie wholly inside the observation
+        const float one = live ? 1.0f : 0.0f;                          // the observation of a dead snake is all zeros
         if (valid) {
             static_assert((4 * GL) % 3 == 1, "the channel of a lane's next piece advances by one");
             const int c0 = (4 * sl - lead + 3) % 3;                    // channel of the first element of piece q = sl
-            const float one = live ? 1.0f : 0.0f;                      // the observation of a dead snake is all zeros
             const float a = c0 == 0 ? one : 0.0f, b = c0 == 1 ? one : 0.0f, c = c0 == 2 ? one : 0.0f;
             float4 p0 = make_float4(b, a, c, b), p1 = make_float4(a, c, b, a), p2 = make_float4(c, b, a, c);
             for (int q = sl; q < nvec; q += GL) {
-                if (q >= qa && q < qb) *(float4 *)(cvs + 4 * (q - qa)) = p0;
-                else store_piece(q, p0);
+                if ((unsigned)(q - qa) < (unsigned)(qb - qa)) *(float4 *)(cvs + 4 * (q - qa)) = p0;
+                else if ((unsigned)(q - q_lo) < (unsigned)(q_hi - q_lo)) *(float4 *)(out + (4 * q - lead)) = p0;
                 const float4 t4 = p0; p0 = p1; p1 = p2; p2 = t4;
             }
         }
         GAME_SYNC();
-        if (live)
+        if (live) {
+            const int base = lead - 4 * qa;
             for (int c = sl; c < NC; c += GL) {
                 const int y = c / WW, x = c - y * WW;
                 const int si = y - hy + (HH - 1), sj = x - hx + (WW - 1);
@@ -818,19 +829,35 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
                 else if (k == 1) { i = N - 1 - sj; j = si; }
                 else if (k == 2) { i = N - 1 - si; j = N - 1 - sj; }
                 else { i = sj; j = N - 1 - si; }
-                float *px = cvs + (3 * (i * N + j) + lead - 4 * qa);
-                px[0] = cell_val(c, 0); px[1] = cell_val(c, 1); px[2] = cell_val(c, 2);
+                float *px = cvs + (3 * (i * N + j) + base);
+                px[0] = v0[c]; px[1] = v1[c]; px[2] = food_bit(food, c) ? fval : 0.0f;
             }
+            // the observer's own head (game.py:248) is the centre pixel whatever the rotation: -1 in all three channels,
+            // written after the scatter (LDS instructions of a wave execute in order)
+            if (sl < 3) cvs[3 * ((HH - 1) * N + (WW - 1)) + base + sl] = -1.0f;
+        }
         GAME_SYNC();
         if (live)
-            for (int q = qa + sl; q < qb; q += GL) store_piece(q, *(const float4 *)(cvs + 4 * (q - qa)));
+            for (int q = max(qa, q_lo) + sl; q < min(qb, q_hi); q += GL)
+                *(float4 *)(out + (4 * q - lead)) = *(const float4 *)(cvs + 4 * (q - qa));
+        // the at most 3 + 3 elements of the partial pieces at both ends: lanes 0..3 the head, lanes 4..7 the tail
+        if (valid && sl < 8) {
+            const int e = sl < 4 ? sl : 4 * q_hi - lead + (sl - 4);
+            const bool mine = sl < 4 ? (sl < 4 * q_lo - lead) : (e < NEL);
+            if (mine) {
+                const int q = (e + lead) >> 2;
+                float v = (e % 3 == 1) ? one : 0.0f;
+                if ((unsigned)(q - qa) < (unsigned)(qb - qa)) v = cvs[e + lead - 4 * qa];
+                out[e] = v;
+            }
+        }
     } else if (planes) {
         // The channel-major layouts.  The observation is the wall pattern almost everywhere (441 canvas pixels, 121 board cells): fill an LDS
         // canvas with the pattern, scatter the board cells into their rotated positions, stream the canvas out
         // with 16-byte stores.  The canvas is shifted by `lead` floats so that LDS and HBM addresses are congruent
         // mod 16 bytes whatever the row's position in the output array.
         float *out = planes + (size_t)pi * NEL;
-        float *canvas = (float *)(g + L.stride + 4 * L.nc_pad + 64);
+        float *canvas = (float *)(g + lds_per_obs(L));
         const int lead = (layout == SNK_NCHW_BF16) ? 0 : (int)(((size_t)pi * NEL) & 3);
         float *cv = canvas + lead;                     // cv[e] <-> out[e]
         const int nvec = (NEL + lead + 3) / 4;
@@ -929,6 +956,8 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
         lo = group_sum_u64<GL>(lo);
         hi = group_sum_u64<GL>(hi);
         if (valid && sl == 0) { key_out[2 * (size_t)pi] = lo; key_out[2 * (size_t)pi + 1] = hi; }
+    }
+    GAME_SYNC();                                           // the LDS region is reused by the next observation
     }
 }
 
@@ -1188,15 +1217,18 @@ extern "C" int snk_engine_observe(const snk_engine *e, const int32_t *d_pairs, i
     // stream per observation and one wavefront per observation keeps more stores in flight (measured: 61 us against 105).
     if (L.H <= 11 && !d_planes) {
         constexpr int WPB = 4;
-        const size_t lds = (size_t)WPB * 4 * lds_per_wave(L);
+        const size_t lds = (size_t)WPB * 4 * lds_per_obs(L);
         const int grid = (m + WPB * 4 - 1) / (WPB * 4);
-        if (L.H == 11) k_observe<11, 11, 16, WPB><<<grid, WPB * 64, lds, (hipStream_t)stream>>>(e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask);
-        else if (L.H == 7) k_observe<7, 7, 16, WPB><<<grid, WPB * 64, lds, (hipStream_t)stream>>>(e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask);
-        else k_observe<0, 0, 16, WPB><<<grid, WPB * 64, lds, (hipStream_t)stream>>>(e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask);
+        if (L.H == 11) k_observe<11, 11, 16, WPB><<<grid, WPB * 64, lds, (hipStream_t)stream>>>(e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask, 1);
+        else if (L.H == 7) k_observe<7, 7, 16, WPB><<<grid, WPB * 64, lds, (hipStream_t)stream>>>(e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask, 1);
+        else k_observe<0, 0, 16, WPB><<<grid, WPB * 64, lds, (hipStream_t)stream>>>(e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask, 1);
     } else {
-        const size_t lds = (size_t)WAVES_PER_BLOCK * (!d_planes ? lds_per_wave(L) : layout == SNK_NHWC_F32 ? lds_per_wave_win(L) : lds_per_wave_obs(L));
-        DISPATCH_BOARD(L, (k_observe<BH, BW, 64, WAVES_PER_BLOCK><<<wave_grid(m), BLOCK_THREADS, lds, (hipStream_t)stream>>>(
-            e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask)));
+        const size_t lds = (size_t)WAVES_PER_BLOCK * (!d_planes ? lds_per_obs(L) : layout == SNK_NHWC_F32 ? lds_per_wave_win(L) : lds_per_wave_obs(L));
+        // several observations per wavefront once the request fills the chip's wave slots (256 CUs x 32) a few times over
+        static const int reps_env = getenv("SNK_OBS_REPS") ? atoi(getenv("SNK_OBS_REPS")) : 0;
+        const int reps = reps_env > 0 ? reps_env : (d_planes && m >= 4 * 8192) ? 2 : 1;
+        DISPATCH_BOARD(L, (k_observe<BH, BW, 64, WAVES_PER_BLOCK><<<wave_grid((m + reps - 1) / reps), BLOCK_THREADS, lds, (hipStream_t)stream>>>(
+            e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask, reps)));
     }
     SNK_CHECK_HIP(hipGetLastError());
     return 0;

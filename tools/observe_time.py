@@ -1,5 +1,5 @@
 """k_observe on mid-game boards (32 warm-up ticks of uniform legal moves): planes form and mask + key form, time and HBM
-fraction.  Development tool: observe_time.py [games]"""
+fraction.  Development tool: observe_time.py [games [planes|mask+key|planes+mask+key]]"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [REPO, os.path.join(REPO, "alphasnake-zero_amd")]
@@ -8,6 +8,7 @@ import snake_engine as se
 import snake_engine._lib as _l
 _l.LIB_PATH = os.environ.get("OBS_LIB", _l.LIB_PATH)      # a development build of the library
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+only = sys.argv[2] if len(sys.argv) > 2 else None      # time one form only (for counter passes)
 eng = se.Engine(n, 11, 11, 4, 1, 0.15, seed=1234)
 eng.reset()
 g = torch.Generator(device="cuda").manual_seed(1234)
@@ -36,6 +37,8 @@ def timed(fn, iters=10):
 for name, fn, byts in (("planes", lambda: eng.observe(pairs, m, planes, None, None), m * (G + 5292)),
                        ("mask+key", lambda: eng.observe(pairs, m, None, mask, key), m * (G + 19)),
                        ("planes+mask+key", lambda: eng.observe(pairs, m, planes, mask, key), m * (G + 5292 + 19))):
+    if only and name != only:
+        continue
     t = timed(fn)
     print(f"{m} observations, {name}: {t * 1e6:.1f} us, {byts / t / 1e12:.2f} TB/s = {byts / t / 8e12:.3f} of 8 TB/s")
 print("checksum", int(key.sum().item()) & 0xFFFFFFFF, float(planes.sum().item()), int(mask.sum().item()))
