@@ -2,6 +2,7 @@
 (include/snake_engine.h via ctypes), against golden vectors recorded from the reference and
 against the CPU oracle on the same seeded inputs.  Everything here is integer / byte /
 float-bit work, so the bar is bit-exact."""
+import os
 import hashlib
 
 import numpy as np
@@ -507,3 +508,18 @@ def test_engine_ids_order(se):
     exp = [(int(sl), int(s)) for sl in order for s in np.flatnonzero(golden_state(z, slot_state[int(sl)])["alive"])]
     c = int(cnt.item())
     assert c == len(exp) and [tuple(r) for r in pairs[:c].cpu().tolist()] == exp
+
+
+def test_lane_group_tick_kernel_still_replays_the_goldens():
+    """the 16-lanes-per-game form of the tick kernel (SNK_STEP_FORM=wide; since the quad-per-game form it only runs for more
+    than 4 snakes on small boards, which no golden covers) against the same recorded ticks, corner cases and random
+    geometries, in a child process (the switch is read once per process)"""
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, SNK_STEP_FORM="wide")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(REPO, "tests", "test_engine_gpu.py"), "-q", "-x", "-m", "gpu", "-k",
+                        "golden_tick or trajectories or corner_cases or step_active or no_empty_cell or device_rng or random_geometries"],
+                       env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
