@@ -1,9 +1,11 @@
 // engine.hip -- gfx950 kernels + C ABI for the batched Battlesnake engine.
 //
-// A lane group (16 lanes in k_step on 11x11 / 7x7 = four games per wavefront, 64 lanes elsewhere) owns one game for
-// the duration of a kernel: the game's HBM record (common.h) is streamed into LDS with 16-byte loads, the rules are
-// evaluated with sub-lanes 0..S-1 holding one snake each (cross-snake questions go through group-confined shuffles /
-// ballots), body occupancy is rebuilt as an LDS byte plane by all lanes of the group, and the record is streamed back.
+// A lane group owns one game (or one observation) for the duration of a kernel: the game's HBM record (common.h) is
+// streamed into LDS with 16-byte loads, the rules are evaluated with one lane per snake, body occupancy is rebuilt in LDS
+// from the rings, and the record is streamed back.  The tick: k_step_quad -- a quad per game, sixteen games per wavefront,
+// cross-snake questions as DPP quad_perm moves, occupancy as bit planes -- for up to 4 snakes on up to 255 cells; k_step --
+// 16 or 64 lanes per game, group-confined shuffles / ballots, byte planes -- for everything else.  All lanes of a group sit
+// in one wavefront, so the phases of a kernel are ordered by GAME_SYNC (no workgroup barrier).
 // Reference semantics: Game.tic game.py:87-205, Game.make_state game.py:215-257,
 // Game.__init__ game.py:13-61, Game.subgame game.py:266-276 (see the per-kernel comments).
 #include "common.h"
