@@ -523,3 +523,18 @@ def test_lane_group_tick_kernel_still_replays_the_goldens():
                        env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_observe_with_several_observations_per_wavefront():
+    """the plane-writing observe kernel takes two consecutive observations per wavefront from 32 768 observations on
+    (SNK_OBS_REPS overrides): the observation tests again with three per wavefront, in a child process (the switch is read
+    once per process) -- reference bytes, masks and keys must not depend on it"""
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, SNK_OBS_REPS="3")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(REPO, "tests", "test_engine_gpu.py"), "-q", "-x", "-m", "gpu", "-k",
+                        "observe_bytes or observe_dead or random_geometries or large_batch"],
+                       env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
