@@ -1,0 +1,180 @@
+// train.hip -- the memory-bound half of the training step (AlphaNNet.train, alpha_nnet.py:58-59):
+// training-mode batch normalisation of a 128-channel activation (the BatchNormalization layers of alpha_nnet.py:23-46 under
+// model.fit), fused with the ReLU and the residual add around it, forward and backward.  Activations are channels-last
+// float32 [rows = n * h * w][128]; a thread owns four channels (one float4 column) of every eighth row of its block's share.
+//
+//   forward   k_bn_sums           per-channel sum and sum of squares          (1 read)
+//             k_bn_apply          out = act(y * scale + shift (+ residual))    (1-2 reads, 1 write)
+//   backward  k_bn_grad_sums      per-channel sum(g), sum(g * xhat), g = dout masked by the ReLU   (2-3 reads)
+//             k_bn_grad_apply     dx = a (g - b - xhat c)  (+ g itself for the residual branch)    (2-3 reads, 1-2 writes)
+//
+// The reductions are two-stage and deterministic: every block writes its 256 partial sums, one block adds them in
+// float64 in a fixed order (a run repeats bit for bit; ranks all-reduce the 256 numbers between the two kernels of each
+// direction, utils/trainer_torch.py).  Everything here is HBM-bound: the PyTorch expressions these kernels replace made ten to
+// fifteen passes over the activation per layer and direction.
+#include "common.h"
+
+#define TR_C 128
+#define TR_THREADS 256
+#define TR_ROWLANES (TR_THREADS / 32)
+
+__device__ static inline void tr_block_reduce_store(float4 a, float4 b, float *__restrict__ part)
+{
+    __shared__ float4 sh[2][TR_ROWLANES][32];
+    const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    sh[0][rl][cq] = a;
+    sh[1][rl][cq] = b;
+    __syncthreads();
+    if (rl < 2) {                                   // row lane 0 finishes the first quantity, row lane 1 the second
+        float4 s = sh[rl][0][cq];
+#pragma unroll
+        for (int r = 1; r < TR_ROWLANES; ++r) {
+            const float4 v = sh[rl][r][cq];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *(float4 *)(part + (size_t)blockIdx.x * (2 * TR_C) + rl * TR_C + 4 * cq) = s;
+    }
+}
+
+__global__ __launch_bounds__(TR_THREADS) void k_bn_sums(const float *__restrict__ y, long rows, float *__restrict__ part)
+{
+    const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    for (long r = (long)blockIdx.x * TR_ROWLANES + rl; r < rows; r += (long)gridDim.x * TR_ROWLANES) {
+        const float4 v = *(const float4 *)(y + r * TR_C + 4 * cq);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+    }
+    tr_block_reduce_store(s, q, part);
+}
+
+// out[2 * 128] = column sums of part[n_blocks][2 * 128], added in float64 in block order
+__global__ __launch_bounds__(2 * TR_C) void k_bn_fold(const float *__restrict__ part, int n_blocks, float *__restrict__ out)
+{
+    double acc = 0.0;
+    for (int b = 0; b < n_blocks; ++b) acc += (double)part[(size_t)b * (2 * TR_C) + threadIdx.x];
+    out[threadIdx.x] = (float)acc;
+}
+
+__global__ __launch_bounds__(TR_THREADS) void k_bn_apply(const float *__restrict__ y, const float *__restrict__ scale,
+                                                        const float *__restrict__ shift, const float *__restrict__ res,
+                                                        float *__restrict__ out, long rows, int relu)
+{
+    const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const float4 sc = *(const float4 *)(scale + 4 * cq), sh = *(const float4 *)(shift + 4 * cq);
+    for (long r = (long)blockIdx.x * TR_ROWLANES + rl; r < rows; r += (long)gridDim.x * TR_ROWLANES) {
+        const long o = r * TR_C + 4 * cq;
+        const float4 v = *(const float4 *)(y + o);
+        float4 t = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+        if (res) {
+            const float4 a = *(const float4 *)(res + o);
+            t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+        }
+        if (relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+        *(float4 *)(out + o) = t;
+    }
+}
+
+// g = dout where the layer's output is positive (ReLU) or everywhere (no ReLU); xhat = (y - mean) * inv
+#define TR_G(dv, ov) (relu ? make_float4(ov.x > 0.f ? dv.x : 0.f, ov.y > 0.f ? dv.y : 0.f, ov.z > 0.f ? dv.z : 0.f, ov.w > 0.f ? dv.w : 0.f) : dv)
+
+__global__ __launch_bounds__(TR_THREADS) void k_bn_grad_sums(const float *__restrict__ dout, const float *__restrict__ out,
+                                                            const float *__restrict__ y, const float *__restrict__ mean,
+                                                            const float *__restrict__ inv, long rows, int relu,
+                                                            float *__restrict__ part)
+{
+    const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const float4 mu = *(const float4 *)(mean + 4 * cq), iv = *(const float4 *)(inv + 4 * cq);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    for (long r = (long)blockIdx.x * TR_ROWLANES + rl; r < rows; r += (long)gridDim.x * TR_ROWLANES) {
+        const long o = r * TR_C + 4 * cq;
+        const float4 dv = *(const float4 *)(dout + o);
+        float4 ov = dv;
+        if (relu) ov = *(const float4 *)(out + o);
+        const float4 g = TR_G(dv, ov);
+        const float4 v = *(const float4 *)(y + o);
+        s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+        q.x += g.x * ((v.x - mu.x) * iv.x); q.y += g.y * ((v.y - mu.y) * iv.y);
+        q.z += g.z * ((v.z - mu.z) * iv.z); q.w += g.w * ((v.w - mu.w) * iv.w);
+    }
+    tr_block_reduce_store(s, q, part);
+}
+
+// dx = a (g - b - xhat c) with a = gamma * inv, b = sum(g) / count, c = sum(g * xhat) / count; g_out (optional) = g
+__global__ __launch_bounds__(TR_THREADS) void k_bn_grad_apply(const float *__restrict__ dout, const float *__restrict__ out,
+                                                             const float *__restrict__ y, const float *__restrict__ mean,
+                                                             const float *__restrict__ inv, const float *__restrict__ a,
+                                                             const float *__restrict__ b, const float *__restrict__ c,
+                                                             float *__restrict__ dx, float *__restrict__ g_out, long rows,
+                                                             int relu)
+{
+    const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const float4 mu = *(const float4 *)(mean + 4 * cq), iv = *(const float4 *)(inv + 4 * cq);
+    const float4 a4 = *(const float4 *)(a + 4 * cq), b4 = *(const float4 *)(b + 4 * cq), c4 = *(const float4 *)(c + 4 * cq);
+    for (long r = (long)blockIdx.x * TR_ROWLANES + rl; r < rows; r += (long)gridDim.x * TR_ROWLANES) {
+        const long o = r * TR_C + 4 * cq;
+        const float4 dv = *(const float4 *)(dout + o);
+        float4 ov = dv;
+        if (relu) ov = *(const float4 *)(out + o);
+        const float4 g = TR_G(dv, ov);
+        const float4 v = *(const float4 *)(y + o);
+        float4 d;
+        d.x = a4.x * (g.x - b4.x - ((v.x - mu.x) * iv.x) * c4.x);
+        d.y = a4.y * (g.y - b4.y - ((v.y - mu.y) * iv.y) * c4.y);
+        d.z = a4.z * (g.z - b4.z - ((v.z - mu.z) * iv.z) * c4.z);
+        d.w = a4.w * (g.w - b4.w - ((v.w - mu.w) * iv.w) * c4.w);
+        *(float4 *)(dx + o) = d;
+        if (g_out) *(float4 *)(g_out + o) = g;
+    }
+}
+
+static int tr_grid(long rows)
+{
+    const long want = (rows + TR_ROWLANES - 1) / TR_ROWLANES;
+    return (int)(want < 2048 ? (want > 0 ? want : 1) : 2048);      // eight blocks per CU; every thread strides over its rows
+}
+
+extern "C" int snk_bn_train_sums(const float *d_y, long rows, float *d_partials, float *d_sums, void *stream)
+{
+    SNK_REQUIRE(d_y && d_partials && d_sums && rows > 0, "snk_bn_train_sums: bad argument");
+    const int grid = tr_grid(rows);
+    k_bn_sums<<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_y, rows, d_partials);
+    k_bn_fold<<<1, 2 * TR_C, 0, (hipStream_t)stream>>>(d_partials, grid, d_sums);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int snk_bn_train_apply(const float *d_y, const float *d_scale, const float *d_shift, const float *d_residual,
+                                  float *d_out, long rows, int relu, void *stream)
+{
+    SNK_REQUIRE(d_y && d_scale && d_shift && d_out && rows > 0, "snk_bn_train_apply: bad argument");
+    k_bn_apply<<<tr_grid(rows), TR_THREADS, 0, (hipStream_t)stream>>>(d_y, d_scale, d_shift, d_residual, d_out, rows, relu);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int snk_bn_train_grad_sums(const float *d_dout, const float *d_out, const float *d_y, const float *d_mean,
+                                      const float *d_inv, long rows, int relu, float *d_partials, float *d_sums, void *stream)
+{
+    SNK_REQUIRE(d_dout && d_y && d_mean && d_inv && d_partials && d_sums && rows > 0 && (!relu || d_out),
+                "snk_bn_train_grad_sums: bad argument");
+    const int grid = tr_grid(rows);
+    k_bn_grad_sums<<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_dout, d_out, d_y, d_mean, d_inv, rows, relu, d_partials);
+    k_bn_fold<<<1, 2 * TR_C, 0, (hipStream_t)stream>>>(d_partials, grid, d_sums);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int snk_bn_train_grad_apply(const float *d_dout, const float *d_out, const float *d_y, const float *d_mean,
+                                       const float *d_inv, const float *d_a, const float *d_b, const float *d_c, float *d_dx,
+                                       float *d_g, long rows, int relu, void *stream)
+{
+    SNK_REQUIRE(d_dout && d_y && d_mean && d_inv && d_a && d_b && d_c && d_dx && rows > 0 && (!relu || d_out),
+                "snk_bn_train_grad_apply: bad argument");
+    k_bn_grad_apply<<<tr_grid(rows), TR_THREADS, 0, (hipStream_t)stream>>>(d_dout, d_out, d_y, d_mean, d_inv, d_a, d_b, d_c, d_dx,
+                                                                          d_g, rows, relu);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int snk_bn_train_partials(void) { return 2048 * 2 * TR_C; }      // floats the caller provides for d_partials

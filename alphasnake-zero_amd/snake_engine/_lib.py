@@ -84,6 +84,11 @@ PROTOTYPES = {
     "snk_softermax_argmax": (i32, [vp, i32, C.c_float, vp, vp, vp]),
     "snk_engine_rewards": (i32, [vp, vp, i32, vp, vp]),
     "snk_head_f32": (i32, [vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "snk_bn_train_partials": (i32, []),
+    "snk_bn_train_sums": (i32, [vp, C.c_long, vp, vp, vp]),
+    "snk_bn_train_apply": (i32, [vp, vp, vp, vp, vp, C.c_long, i32, vp]),
+    "snk_bn_train_grad_sums": (i32, [vp, vp, vp, vp, vp, C.c_long, i32, vp, vp, vp]),
+    "snk_bn_train_grad_apply": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_long, i32, vp]),
 }
 
 

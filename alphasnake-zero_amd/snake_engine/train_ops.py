@@ -1,0 +1,142 @@
+"""Training-side operators on the hand-written kernels (`AlphaNNet.train`, alpha_nnet.py:58-59).
+
+`SplitConv3x3`: the tower's 128 -> 128 3x3 convolution as a `torch.autograd.Function` whose forward pass and input
+gradient run on `k_conv3x3_f16s` (csrc/conv_split.hip: float32 accuracy on the f16 matrix pipe, each operand split into
+f16 hi + lo) -- the input gradient of a stride-1 'same' convolution is the same convolution with the taps flipped and the
+channel axes swapped.  The weight gradient stays with the library convolution (MIOpen's NHWC float32 kernel).  Activations
+are channels-last in memory, which is the layout the kernel reads, so no tensor is permuted or copied.
+
+The kernel scales its input by a power of two before splitting it (the f16 range is +-65504 and values far below the
+largest one lose their low bits): the scale is taken from the tensor's largest magnitude on the device (2^11 <= max * scale
+< 2^12), without a host round trip -- gradients of 1e-6 and activations of 10 both keep ~22 significant bits.
+"""
+import torch
+
+from ._lib import check, lib
+from .net import F16S_TAIL_OFFSET, F16S_WEIGHT_BYTES
+
+
+def _conv_same(x_nhwc, k_hwio):
+    """x: contiguous float32 cuda [n, h, w, 128]; k: float32 [3, 3, 128, 128] (kh, kw, cin, cout) -> [n, h, w, 128]"""
+    L = lib()
+    st = torch.cuda.current_stream().cuda_stream
+    n, h, w, c = x_nhwc.shape
+    image = torch.empty(F16S_WEIGHT_BYTES, dtype=torch.uint8, device=x_nhwc.device)
+    check(L.snk_conv3x3_prepare_weights_f16s(k_hwio.contiguous().data_ptr(), image.data_ptr(), 1.0, st))
+    amax = x_nhwc.abs().amax().clamp_min(1e-30)
+    e = torch.floor(12.0 - torch.log2(amax)).clamp(-100.0, 100.0).to(torch.int32)
+    scale = torch.ldexp(torch.ones((), device=x_nhwc.device), e)          # an exact power of two
+    tail = image[F16S_TAIL_OFFSET:F16S_TAIL_OFFSET + 16].view(torch.float32)
+    tail[2:4] = torch.stack([scale, 1.0 / scale])
+    ones = torch.ones(c, device=x_nhwc.device)
+    zeros = torch.zeros(c, device=x_nhwc.device)
+    out = torch.empty_like(x_nhwc)
+    check(L.snk_conv3x3_bn_f16s(x_nhwc.data_ptr(), image.data_ptr(), ones.data_ptr(), zeros.data_ptr(), None, out.data_ptr(),
+                                n, h, w, 0, st))
+    return out
+
+
+def usable(x, k):
+    """the operator covers what the tower needs: float32 on the GPU, 3x3, 128 -> 128 channels"""
+    return x.is_cuda and x.dtype == torch.float32 and tuple(k.shape) == (3, 3, 128, 128) and k.dtype == torch.float32
+
+
+class SplitConv3x3(torch.autograd.Function):
+    """y = conv2d(x, k), stride 1, 'same' zero padding.  x: [n, 128, h, w] (any strides; channels-last costs nothing),
+    k: Keras layout [3, 3, cin, cout].  Returns a channels-last [n, 128, h, w] tensor."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        x_nhwc = x.permute(0, 2, 3, 1).contiguous()            # a view when x is channels-last
+        ctx.save_for_backward(x_nhwc, k)
+        return _conv_same(x_nhwc, k).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_nhwc, k = ctx.saved_tensors
+        dy_nhwc = dy.permute(0, 2, 3, 1).contiguous()
+        dx = dk = None
+        if ctx.needs_input_grad[0]:                            # the same convolution, taps flipped, channel axes swapped
+            dx = _conv_same(dy_nhwc, k.flip(0, 1).permute(0, 1, 3, 2)).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            g = torch.ops.aten.convolution_backward(dy_nhwc.permute(0, 3, 1, 2), x_nhwc.permute(0, 3, 1, 2),
+                                                    k.permute(3, 2, 0, 1), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                    [False, True, False])[1]
+            dk = g.permute(2, 3, 1, 0)                         # (cout, cin, kh, kw) -> (kh, kw, cin, cout)
+        return dx, dk
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+BN_EPS = 1e-3           # Keras BatchNormalization default epsilon (alpha_nnet.py:23-46)
+_scratch = {}
+
+
+def _partials(device):
+    """the block-partials scratch of the two-stage reductions (one per device; stream-ordered reuse)"""
+    key = (device.type, device.index)
+    if key not in _scratch:
+        _scratch[key] = torch.empty(lib().snk_bn_train_partials(), dtype=torch.float32, device=device)
+    return _scratch[key]
+
+
+def bn_usable(y):
+    return y.is_cuda and y.dtype == torch.float32 and y.dim() == 4 and y.shape[1] == 128
+
+
+class FusedBatchNormAct(torch.autograd.Function):
+    """out = act(gamma * (y - mean) / sqrt(var + eps) + beta (+ residual)), mean / biased variance over (N, H, W) of ALL
+    ranks, on the kernels of csrc/train.hip: two passes over the activation forward, two backward.
+    y, residual: [n, 128, h, w]; returns (out channels-last, mean, var, count) -- the last three for the moving averages.
+    `dist` is torch.distributed when the step runs data-parallel (the 256 sums are all-reduced), else None."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, residual, relu, dist):
+        L = lib()
+        st = torch.cuda.current_stream().cuda_stream
+        y_nhwc = y.permute(0, 2, 3, 1).contiguous()
+        rows = y_nhwc.shape[0] * y_nhwc.shape[1] * y_nhwc.shape[2]
+        c = 128
+        stat = torch.empty(2 * c + 1, dtype=torch.float32, device=y.device)
+        check(L.snk_bn_train_sums(y_nhwc.data_ptr(), rows, _partials(y.device).data_ptr(), stat.data_ptr(), st))
+        stat[2 * c] = float(rows)
+        if dist is not None:
+            dist.all_reduce(stat)
+        n = stat[2 * c]
+        mean = stat[:c] / n
+        var = (stat[c:2 * c] / n - mean * mean).clamp_min(0.0)
+        inv = torch.rsqrt(var + BN_EPS)
+        scale = (gamma * inv).contiguous()
+        shift = (beta - mean * scale).contiguous()
+        res_nhwc = residual.permute(0, 2, 3, 1).contiguous() if residual is not None else None
+        out = torch.empty_like(y_nhwc)
+        check(L.snk_bn_train_apply(y_nhwc.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                   res_nhwc.data_ptr() if res_nhwc is not None else None, out.data_ptr(), rows, int(relu), st))
+        ctx.save_for_backward(y_nhwc, out, gamma, mean.contiguous(), inv.contiguous(), n)
+        ctx.relu, ctx.has_res, ctx.dist = bool(relu), residual is not None, dist
+        res = out.permute(0, 3, 1, 2)
+        ctx.mark_non_differentiable(mean, var, n)
+        return res, mean, var, n
+
+    @staticmethod
+    def backward(ctx, dout, _dm, _dv, _dn):
+        y_nhwc, out, gamma, mean, inv, n = ctx.saved_tensors
+        L = lib()
+        st = torch.cuda.current_stream().cuda_stream
+        c = 128
+        rows = y_nhwc.shape[0] * y_nhwc.shape[1] * y_nhwc.shape[2]
+        d_nhwc = dout.permute(0, 2, 3, 1).contiguous()
+        red = torch.empty(2 * c, dtype=torch.float32, device=dout.device)
+        check(L.snk_bn_train_grad_sums(d_nhwc.data_ptr(), out.data_ptr(), y_nhwc.data_ptr(), mean.data_ptr(), inv.data_ptr(), rows,
+                                       int(ctx.relu), _partials(dout.device).data_ptr(), red.data_ptr(), st))
+        dbeta, dgamma = red[:c].clone(), red[c:].clone()                  # this rank's share of the parameter gradients
+        if ctx.dist is not None:
+            ctx.dist.all_reduce(red)                                      # the input gradient needs the global reductions
+        a = (gamma * inv).contiguous()
+        b = (red[:c] / n).contiguous()
+        cc = (red[c:] / n).contiguous()
+        dx = torch.empty_like(y_nhwc)
+        g = torch.empty_like(y_nhwc) if ctx.has_res else None
+        check(L.snk_bn_train_grad_apply(d_nhwc.data_ptr(), out.data_ptr(), y_nhwc.data_ptr(), mean.data_ptr(), inv.data_ptr(),
+                                        a.data_ptr(), b.data_ptr(), cc.data_ptr(), dx.data_ptr(),
+                                        g.data_ptr() if g is not None else None, rows, int(ctx.relu), st))
+        return dx.permute(0, 3, 1, 2), dgamma, dbeta, (g.permute(0, 3, 1, 2) if g is not None else None), None, None

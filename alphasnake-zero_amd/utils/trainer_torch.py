@@ -22,9 +22,13 @@ of the gradient), the gradients are summed in ONE flat bucket per step.  The res
 result up to float32 rounding, the ranks run the same number of steps by construction and end with identical weights
 and moving statistics.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
+
+_NATIVE_CONV = os.environ.get("SNK_TRAIN_CONV", "native") != "torch"      # `torch`: every convolution through the library (A/B runs)
 
 BN_EPS, BN_MOMENTUM, L2_C = 1e-3, 0.99, 1e-5
 ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-7
@@ -107,29 +111,48 @@ class _Net:
     def params(self):
         return [self.t[j] for j in self.param_idx]
 
-    def _conv_bn(self, x, i, train):
+    def _conv_bn(self, x, i, train, residual=None, relu=True):
+        """act(batch_norm(conv(x)) (+ residual)), act = ReLU (every layer of the graph has one after its batch norm)"""
         k = self.t[i]
-        y = F.conv2d(x, k.permute(3, 2, 0, 1), padding=k.shape[0] // 2)
+        if _NATIVE_CONV and x.is_cuda:                       # the tower layers: forward and input gradient on k_conv3x3_f16s
+            from snake_engine import train_ops
+            y = train_ops.SplitConv3x3.apply(x, k) if train_ops.usable(x, k) else None
+        else:
+            y = None
+        if y is None:
+            y = F.conv2d(x, k.permute(3, 2, 0, 1), padding=k.shape[0] // 2)
         g, b, mean, var = self.t[i + 1:i + 5]
         if train:
-            out, m, v, n = _SyncBatchNormTrain.apply(y, g, b)
+            fused = False
+            if _NATIVE_CONV and y.is_cuda:                   # batch norm + residual + ReLU on the kernels of csrc/train.hip
+                from snake_engine import train_ops
+                fused = train_ops.bn_usable(y)
+            if fused:
+                out, m, v, n = train_ops.FusedBatchNormAct.apply(y, g, b, residual, relu, _dist())
+            else:
+                out, m, v, n = _SyncBatchNormTrain.apply(y, g, b)
             with torch.no_grad():
                 unbiased = v * (n / (n - 1.0).clamp_min(1.0))
                 mean.mul_(BN_MOMENTUM).add_(m * (1 - BN_MOMENTUM))
                 var.mul_(BN_MOMENTUM).add_(unbiased * (1 - BN_MOMENTUM))
-            return out
-        return (y - mean[None, :, None, None]) * (g / torch.sqrt(var + BN_EPS))[None, :, None, None] + b[None, :, None, None]
+            if fused:
+                return out
+        else:
+            out = (y - mean[None, :, None, None]) * (g / torch.sqrt(var + BN_EPS))[None, :, None, None] + b[None, :, None, None]
+        if residual is not None:
+            out = out + residual
+        return F.relu(out) if relu else out
 
     def forward(self, x_nhwc, train):
         x = x_nhwc.permute(0, 3, 1, 2)
-        h = F.relu(self._conv_bn(x, 0, train))
+        h = self._conv_bn(x, 0, train)
         i = 5
         for _ in range(self.blocks):
             sc = h
-            h = F.relu(self._conv_bn(h, i, train))
-            h = F.relu(self._conv_bn(h, i + 5, train) + sc)
+            h = self._conv_bn(h, i, train)
+            h = self._conv_bn(h, i + 5, train, residual=sc)
             i += 10
-        h = F.relu(self._conv_bn(h, i, train))
+        h = self._conv_bn(h, i, train)
         h = h.permute(0, 2, 3, 1).reshape(h.shape[0], -1)
         h = F.relu(h @ self.t[i + 5] + self.t[i + 6])
         return torch.tanh(h @ self.t[i + 7] + self.t[i + 8])

@@ -304,6 +304,25 @@ int snk_softermax_argmax(const float *d_z, int m, float softmax_base, float *d_p
 /* Game.rewards of n games as int8[n][S]: 0 None, +1, -1 (mp_game_runner.py:110) */
 int snk_engine_rewards(const snk_engine *e, const int32_t *d_slots, int n, int8_t *d_rewards, void *stream);
 
+/* ---- training half: AlphaNNet.train = model.fit (alpha_nnet.py:58-59) -------------------------
+ * Training-mode batch normalisation of a 128-channel channels-last float32 activation [rows = n * h * w][128] (the
+ * BatchNormalization layers of alpha_nnet.py:23-46 as Keras runs them under fit), fused with the ReLU / residual add around
+ * it.  The caller (utils/trainer_torch.py) turns the sums into mean / variance / scales between the two kernels of each
+ * direction -- and all-reduces them over the ranks there.  d_partials: snk_bn_train_partials() floats of scratch.
+ *   snk_bn_train_sums        d_sums[0..127] = per-channel sum of y, d_sums[128..255] = sum of y * y (deterministic order)
+ *   snk_bn_train_apply       out = y * scale + shift (+ residual), then ReLU when relu != 0
+ *   snk_bn_train_grad_sums   with g = dout (masked by out > 0 when relu): d_sums = { sum g, sum g * xhat }, xhat = (y - mean) * inv
+ *   snk_bn_train_grad_apply  dx = a * (g - b - xhat * c); d_g (optional) = g, the gradient of the residual branch        */
+int snk_bn_train_partials(void);
+int snk_bn_train_sums(const float *d_y, long rows, float *d_partials, float *d_sums, void *stream);
+int snk_bn_train_apply(const float *d_y, const float *d_scale, const float *d_shift, const float *d_residual,
+                       float *d_out, long rows, int relu, void *stream);
+int snk_bn_train_grad_sums(const float *d_dout, const float *d_out, const float *d_y, const float *d_mean,
+                           const float *d_inv, long rows, int relu, float *d_partials, float *d_sums, void *stream);
+int snk_bn_train_grad_apply(const float *d_dout, const float *d_out, const float *d_y, const float *d_mean,
+                            const float *d_inv, const float *d_a, const float *d_b, const float *d_c, float *d_dx,
+                            float *d_g, long rows, int relu, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
