@@ -48,12 +48,65 @@ __global__ __launch_bounds__(TR_THREADS) void k_bn_sums(const float *__restrict_
     tr_block_reduce_store(s, q, part);
 }
 
-// out[2 * 128] = column sums of part[n_blocks][2 * 128], added in float64 in block order
-__global__ __launch_bounds__(2 * TR_C) void k_bn_fold(const float *__restrict__ part, int n_blocks, float *__restrict__ out)
+// out[2 * 128] = column sums of part[n_blocks][2 * 128] in float64, in a fixed order: four row groups per column, each
+// adding every fourth block with eight loads in flight, then the four group sums in order
+__global__ __launch_bounds__(8 * TR_C) void k_bn_fold(const float *__restrict__ part, int n_blocks, float *__restrict__ out)
 {
+    __shared__ double sh[4][2 * TR_C];
+    const int col = threadIdx.x & (2 * TR_C - 1), grp = threadIdx.x / (2 * TR_C);
     double acc = 0.0;
-    for (int b = 0; b < n_blocks; ++b) acc += (double)part[(size_t)b * (2 * TR_C) + threadIdx.x];
-    out[threadIdx.x] = (float)acc;
+    int b = grp;
+    for (; b + 28 < n_blocks; b += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + 4 * u) * (2 * TR_C) + col];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (double)v[u];
+    }
+    for (; b < n_blocks; b += 4) acc += (double)part[(size_t)b * (2 * TR_C) + col];
+    sh[grp][col] = acc;
+    __syncthreads();
+    if (grp == 0) out[col] = (float)(((sh[0][col] + sh[1][col]) + sh[2][col]) + sh[3][col]);
+}
+
+// largest magnitude of a float32 array -> the power-of-two input scale of the split-f16 convolution, written into the
+// tail of its weight image { 2^-k, 2^k, x_scale, 1 / x_scale, flag } (conv_split.hip): 2^11 <= max * x_scale < 2^12
+__global__ __launch_bounds__(TR_THREADS) void k_amax_part(const float *__restrict__ x, long n4, float *__restrict__ part)
+{
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * TR_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * TR_THREADS) {
+        const float4 v = ((const float4 *)x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    __shared__ float sh[TR_THREADS];
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = TR_THREADS / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
+__global__ __launch_bounds__(1024) void k_amax_scale(const float *__restrict__ part, int n_blocks, float *__restrict__ tail)
+{
+    __shared__ float sh[1024];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n_blocks; i += 1024) m = fmaxf(m, part[i]);
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float mx = sh[0];
+        int k = 0;
+        if (mx > 0.f && mx < 3.0e38f) k = 11 - ilogbf(mx);          // 2^11 <= mx * 2^k < 2^12
+        k = max(-100, min(100, k));
+        tail[2] = ldexpf(1.0f, k);
+        tail[3] = ldexpf(1.0f, -k);
+    }
 }
 
 __global__ __launch_bounds__(TR_THREADS) void k_bn_apply(const float *__restrict__ y, const float *__restrict__ scale,
@@ -139,7 +192,7 @@ extern "C" int snk_bn_train_sums(const float *d_y, long rows, float *d_partials,
     SNK_REQUIRE(d_y && d_partials && d_sums && rows > 0, "snk_bn_train_sums: bad argument");
     const int grid = tr_grid(rows);
     k_bn_sums<<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_y, rows, d_partials);
-    k_bn_fold<<<1, 2 * TR_C, 0, (hipStream_t)stream>>>(d_partials, grid, d_sums);
+    k_bn_fold<<<1, 8 * TR_C, 0, (hipStream_t)stream>>>(d_partials, grid, d_sums);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -160,7 +213,7 @@ extern "C" int snk_bn_train_grad_sums(const float *d_dout, const float *d_out, c
                 "snk_bn_train_grad_sums: bad argument");
     const int grid = tr_grid(rows);
     k_bn_grad_sums<<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_dout, d_out, d_y, d_mean, d_inv, rows, relu, d_partials);
-    k_bn_fold<<<1, 2 * TR_C, 0, (hipStream_t)stream>>>(d_partials, grid, d_sums);
+    k_bn_fold<<<1, 8 * TR_C, 0, (hipStream_t)stream>>>(d_partials, grid, d_sums);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -173,6 +226,19 @@ extern "C" int snk_bn_train_grad_apply(const float *d_dout, const float *d_out, 
                 "snk_bn_train_grad_apply: bad argument");
     k_bn_grad_apply<<<tr_grid(rows), TR_THREADS, 0, (hipStream_t)stream>>>(d_dout, d_out, d_y, d_mean, d_inv, d_a, d_b, d_c, d_dx,
                                                                           d_g, rows, relu);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int snk_conv3x3_f16s_input_scale(const float *d_x, long n_floats, void *d_wS, float *d_partials, void *stream)
+{
+    SNK_REQUIRE(d_x && d_wS && d_partials && n_floats > 0 && n_floats % 4 == 0, "snk_conv3x3_f16s_input_scale: bad argument");
+    const long n4 = n_floats / 4;
+    const long want = (n4 + TR_THREADS - 1) / TR_THREADS;
+    const int grid = (int)(want < 2048 ? want : 2048);
+    float *tail = (float *)((char *)d_wS + SNK_CONV_F16S_TAIL_OFFSET);
+    k_amax_part<<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_x, n4, d_partials);
+    k_amax_scale<<<1, 1024, 0, (hipStream_t)stream>>>(d_partials, grid, tail);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }

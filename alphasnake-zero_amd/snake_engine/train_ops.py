@@ -13,7 +13,26 @@ largest one lose their low bits): the scale is taken from the tensor's largest m
 import torch
 
 from ._lib import check, lib
-from .net import F16S_TAIL_OFFSET, F16S_WEIGHT_BYTES
+from .net import F16S_WEIGHT_BYTES
+
+
+_scratch = {}
+
+
+def _partials(device):
+    """the block-partials scratch of the two-stage reductions (one per device; stream-ordered reuse)"""
+    key = (device.type, device.index)
+    if key not in _scratch:
+        _scratch[key] = torch.empty(lib().snk_bn_train_partials(), dtype=torch.float32, device=device)
+    return _scratch[key]
+
+
+def _unit(device):
+    """identity batch-norm scale / shift for the convolution kernel's fused epilogue"""
+    key = ("unit", device.type, device.index)
+    if key not in _scratch:
+        _scratch[key] = (torch.ones(128, device=device), torch.zeros(128, device=device))
+    return _scratch[key]
 
 
 def _conv_same(x_nhwc, k_hwio):
@@ -23,13 +42,8 @@ def _conv_same(x_nhwc, k_hwio):
     n, h, w, c = x_nhwc.shape
     image = torch.empty(F16S_WEIGHT_BYTES, dtype=torch.uint8, device=x_nhwc.device)
     check(L.snk_conv3x3_prepare_weights_f16s(k_hwio.contiguous().data_ptr(), image.data_ptr(), 1.0, st))
-    amax = x_nhwc.abs().amax().clamp_min(1e-30)
-    e = torch.floor(12.0 - torch.log2(amax)).clamp(-100.0, 100.0).to(torch.int32)
-    scale = torch.ldexp(torch.ones((), device=x_nhwc.device), e)          # an exact power of two
-    tail = image[F16S_TAIL_OFFSET:F16S_TAIL_OFFSET + 16].view(torch.float32)
-    tail[2:4] = torch.stack([scale, 1.0 / scale])
-    ones = torch.ones(c, device=x_nhwc.device)
-    zeros = torch.zeros(c, device=x_nhwc.device)
+    check(L.snk_conv3x3_f16s_input_scale(x_nhwc.data_ptr(), x_nhwc.numel(), image.data_ptr(), _partials(x_nhwc.device).data_ptr(), st))
+    ones, zeros = _unit(x_nhwc.device)
     out = torch.empty_like(x_nhwc)
     check(L.snk_conv3x3_bn_f16s(x_nhwc.data_ptr(), image.data_ptr(), ones.data_ptr(), zeros.data_ptr(), None, out.data_ptr(),
                                 n, h, w, 0, st))
@@ -68,17 +82,6 @@ class SplitConv3x3(torch.autograd.Function):
 
 # ---------------------------------------------------------------------------------------------------------------------
 BN_EPS = 1e-3           # Keras BatchNormalization default epsilon (alpha_nnet.py:23-46)
-_scratch = {}
-
-
-def _partials(device):
-    """the block-partials scratch of the two-stage reductions (one per device; stream-ordered reuse)"""
-    key = (device.type, device.index)
-    if key not in _scratch:
-        _scratch[key] = torch.empty(lib().snk_bn_train_partials(), dtype=torch.float32, device=device)
-    return _scratch[key]
-
-
 def bn_usable(y):
     return y.is_cuda and y.dtype == torch.float32 and y.dim() == 4 and y.shape[1] == 128
 

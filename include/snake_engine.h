@@ -314,6 +314,10 @@ int snk_engine_rewards(const snk_engine *e, const int32_t *d_slots, int n, int8_
  *   snk_bn_train_grad_sums   with g = dout (masked by out > 0 when relu): d_sums = { sum g, sum g * xhat }, xhat = (y - mean) * inv
  *   snk_bn_train_grad_apply  dx = a * (g - b - xhat * c); d_g (optional) = g, the gradient of the residual branch        */
 int snk_bn_train_partials(void);
+/* The split-f16 convolution's power-of-two input scale from the data itself, for tensors whose range is not known ahead
+ * (gradients): x_scale with 2^11 <= max|x| * x_scale < 2^12 is written into the tail of the weight image d_wS
+ * (after snk_conv3x3_prepare_weights_f16s), on the device.  n_floats: a multiple of 4; d_partials as above. */
+int snk_conv3x3_f16s_input_scale(const float *d_x, long n_floats, void *d_wS, float *d_partials, void *stream);
 int snk_bn_train_sums(const float *d_y, long rows, float *d_partials, float *d_sums, void *stream);
 int snk_bn_train_apply(const float *d_y, const float *d_scale, const float *d_shift, const float *d_residual,
                        float *d_out, long rows, int relu, void *stream);
