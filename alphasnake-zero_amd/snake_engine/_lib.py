@@ -86,6 +86,8 @@ PROTOTYPES = {
     "snk_head_f32": (i32, [vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "snk_bn_train_partials": (i32, []),
     "snk_conv3x3_f16s_input_scale": (i32, [vp, C.c_long, vp, vp, vp]),
+    "snk_conv3x3_wgrad_partials": (C.c_long, [i32, i32]),
+    "snk_conv3x3_wgrad_f16s": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "snk_bn_train_sums": (i32, [vp, C.c_long, vp, vp, vp]),
     "snk_bn_train_apply": (i32, [vp, vp, vp, vp, vp, C.c_long, i32, vp]),
     "snk_bn_train_grad_sums": (i32, [vp, vp, vp, vp, vp, C.c_long, i32, vp, vp, vp]),

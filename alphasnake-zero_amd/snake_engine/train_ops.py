@@ -3,19 +3,23 @@
 `SplitConv3x3`: the tower's 128 -> 128 3x3 convolution as a `torch.autograd.Function` whose forward pass and input
 gradient run on `k_conv3x3_f16s` (csrc/conv_split.hip: float32 accuracy on the f16 matrix pipe, each operand split into
 f16 hi + lo) -- the input gradient of a stride-1 'same' convolution is the same convolution with the taps flipped and the
-channel axes swapped.  The weight gradient stays with the library convolution (MIOpen's NHWC float32 kernel).  Activations
-are channels-last in memory, which is the layout the kernel reads, so no tensor is permuted or copied.
+channel axes swapped -- and whose weight gradient runs on `k_wgrad_f16s` (csrc/train_wgrad.hip; shapes whose LDS planes
+do not fit fall back to the library's kernel).  Activations are channels-last in memory, which is the layout the kernels
+read, so no tensor is permuted or copied.
 
 The kernel scales its input by a power of two before splitting it (the f16 range is +-65504 and values far below the
 largest one lose their low bits): the scale is taken from the tensor's largest magnitude on the device (2^11 <= max * scale
 < 2^12), without a host round trip -- gradients of 1e-6 and activations of 10 both keep ~22 significant bits.
 """
+import os
+
 import torch
 
 from ._lib import check, lib
-from .net import F16S_WEIGHT_BYTES
+from .net import F16S_TAIL_OFFSET, F16S_WEIGHT_BYTES
 
 
+_NATIVE_WGRAD = os.environ.get("SNK_TRAIN_WGRAD", "native") != "torch"    # `torch`: the library's weight gradient (A/B runs)
 _scratch = {}
 
 
@@ -47,7 +51,31 @@ def _conv_same(x_nhwc, k_hwio):
     out = torch.empty_like(x_nhwc)
     check(L.snk_conv3x3_bn_f16s(x_nhwc.data_ptr(), image.data_ptr(), ones.data_ptr(), zeros.data_ptr(), None, out.data_ptr(),
                                 n, h, w, 0, st))
-    return out
+    return out, image[F16S_TAIL_OFFSET:F16S_TAIL_OFFSET + 16].view(torch.float32)      # the tail carries the input's scale
+
+
+def _input_scale(x_nhwc):
+    """{., ., scale, 1 / scale} of a tensor that no convolution call has scaled yet"""
+    image = torch.empty(F16S_WEIGHT_BYTES, dtype=torch.uint8, device=x_nhwc.device)
+    check(lib().snk_conv3x3_f16s_input_scale(x_nhwc.data_ptr(), x_nhwc.numel(), image.data_ptr(), _partials(x_nhwc.device).data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream))
+    return image[F16S_TAIL_OFFSET:F16S_TAIL_OFFSET + 16].view(torch.float32)
+
+
+def _wgrad(x_nhwc, dy_nhwc, x_tail, dy_tail):
+    """[3, 3, 128, 128] weight gradient on k_wgrad_f16s, or None when the shape does not fit its LDS planes"""
+    L = lib()
+    n, h, w, _ = x_nhwc.shape
+    need = L.snk_conv3x3_wgrad_partials(h, w)
+    if need <= 0:
+        return None
+    key = ("wgrad", x_nhwc.device.type, x_nhwc.device.index)
+    if key not in _scratch or _scratch[key].numel() < need:
+        _scratch[key] = torch.empty(need, dtype=torch.float32, device=x_nhwc.device)
+    dk = torch.empty(3, 3, 128, 128, dtype=torch.float32, device=x_nhwc.device)
+    check(L.snk_conv3x3_wgrad_f16s(x_nhwc.data_ptr(), dy_nhwc.data_ptr(), x_tail.data_ptr(), dy_tail.data_ptr(),
+                                   _scratch[key].data_ptr(), dk.data_ptr(), n, h, w, torch.cuda.current_stream().cuda_stream))
+    return dk
 
 
 def usable(x, k):
@@ -62,17 +90,21 @@ class SplitConv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, k):
         x_nhwc = x.permute(0, 2, 3, 1).contiguous()            # a view when x is channels-last
-        ctx.save_for_backward(x_nhwc, k)
-        return _conv_same(x_nhwc, k).permute(0, 3, 1, 2)
+        y, x_tail = _conv_same(x_nhwc, k)
+        ctx.save_for_backward(x_nhwc, k, x_tail)
+        return y.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, dy):
-        x_nhwc, k = ctx.saved_tensors
+        x_nhwc, k, x_tail = ctx.saved_tensors
         dy_nhwc = dy.permute(0, 2, 3, 1).contiguous()
-        dx = dk = None
+        dx = dk = dy_tail = None
         if ctx.needs_input_grad[0]:                            # the same convolution, taps flipped, channel axes swapped
-            dx = _conv_same(dy_nhwc, k.flip(0, 1).permute(0, 1, 3, 2)).permute(0, 3, 1, 2)
-        if ctx.needs_input_grad[1]:
+            dx, dy_tail = _conv_same(dy_nhwc, k.flip(0, 1).permute(0, 1, 3, 2))
+            dx = dx.permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1] and _NATIVE_WGRAD:          # the reduction over pixels on k_wgrad_f16s
+            dk = _wgrad(x_nhwc, dy_nhwc, x_tail, dy_tail if dy_tail is not None else _input_scale(dy_nhwc))
+        if ctx.needs_input_grad[1] and dk is None:             # shapes whose planes do not fit the LDS: the library's kernel
             g = torch.ops.aten.convolution_backward(dy_nhwc.permute(0, 3, 1, 2), x_nhwc.permute(0, 3, 1, 2),
                                                     k.permute(3, 2, 0, 1), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                     [False, True, False])[1]
@@ -82,6 +114,8 @@ class SplitConv3x3(torch.autograd.Function):
 
 # ---------------------------------------------------------------------------------------------------------------------
 BN_EPS = 1e-3           # Keras BatchNormalization default epsilon (alpha_nnet.py:23-46)
+
+
 def bn_usable(y):
     return y.is_cuda and y.dtype == torch.float32 and y.dim() == 4 and y.shape[1] == 128
 

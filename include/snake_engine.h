@@ -318,6 +318,14 @@ int snk_bn_train_partials(void);
  * (gradients): x_scale with 2^11 <= max|x| * x_scale < 2^12 is written into the tail of the weight image d_wS
  * (after snk_conv3x3_prepare_weights_f16s), on the device.  n_floats: a multiple of 4; d_partials as above. */
 int snk_conv3x3_f16s_input_scale(const float *d_x, long n_floats, void *d_wS, float *d_partials, void *stream);
+/* Weight gradient of the tower convolution (the third convolution pass of a training step), float32 accuracy on the f16
+ * matrix pipe: d_dw[3][3][128][128] (Keras layout) = sum over images and pixels of x[n][y + kh - 1][x + kw - 1][ci] *
+ * dy[n][y][x][co]; x, dy channels-last float32 [n][h][w][128]; d_x_tail / d_dy_tail: the 4 floats { ., ., scale, 1 / scale }
+ * at SNK_CONV_F16S_TAIL_OFFSET of a weight image on which snk_conv3x3_f16s_input_scale ran for that tensor.
+ * d_partials: snk_conv3x3_wgrad_partials(h, w) floats (-1: the shape does not fit, use another path). */
+long snk_conv3x3_wgrad_partials(int height, int width);
+int snk_conv3x3_wgrad_f16s(const float *d_x, const float *d_dy, const float *d_x_tail, const float *d_dy_tail,
+                           float *d_partials, float *d_dw, int n_images, int height, int width, void *stream);
 int snk_bn_train_sums(const float *d_y, long rows, float *d_partials, float *d_sums, void *stream);
 int snk_bn_train_apply(const float *d_y, const float *d_scale, const float *d_shift, const float *d_residual,
                        float *d_out, long rows, int relu, void *stream);
