@@ -109,12 +109,29 @@ __global__ __launch_bounds__(1024) void k_amax_scale(const float *__restrict__ p
     }
 }
 
+// optional by-product of the two element-wise kernels: the largest magnitude they WRITE (the next convolution's input), one
+// value per block into amax_part -- k_amax_scale turns them into that convolution's power-of-two input scale, so the tensor
+// is not read once more just for its maximum
+__device__ static inline void tr_block_amax(float m, float *__restrict__ amax_part)
+{
+    __shared__ float shm[TR_THREADS];
+    shm[threadIdx.x] = m;
+    __syncthreads();
+    for (int s_ = TR_THREADS / 2; s_ > 0; s_ >>= 1) {
+        if ((int)threadIdx.x < s_) shm[threadIdx.x] = fmaxf(shm[threadIdx.x], shm[threadIdx.x + s_]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) amax_part[blockIdx.x] = shm[0];
+}
+
 __global__ __launch_bounds__(TR_THREADS) void k_bn_apply(const float *__restrict__ y, const float *__restrict__ scale,
                                                         const float *__restrict__ shift, const float *__restrict__ res,
-                                                        float *__restrict__ out, long rows, int relu)
+                                                        float *__restrict__ out, long rows, int relu,
+                                                        float *__restrict__ amax_part)
 {
     const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const float4 sc = *(const float4 *)(scale + 4 * cq), sh = *(const float4 *)(shift + 4 * cq);
+    float am = 0.f;
     for (long r = (long)blockIdx.x * TR_ROWLANES + rl; r < rows; r += (long)gridDim.x * TR_ROWLANES) {
         const long o = r * TR_C + 4 * cq;
         const float4 v = *(const float4 *)(y + o);
@@ -125,7 +142,9 @@ __global__ __launch_bounds__(TR_THREADS) void k_bn_apply(const float *__restrict
         }
         if (relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
         *(float4 *)(out + o) = t;
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(t.x), fabsf(t.y))), fmaxf(fabsf(t.z), fabsf(t.w)));
     }
+    if (amax_part) tr_block_amax(am, amax_part);
 }
 
 // g = dout where the layer's output is positive (ReLU) or everywhere (no ReLU); xhat = (y - mean) * inv
@@ -159,9 +178,10 @@ __global__ __launch_bounds__(TR_THREADS) void k_bn_grad_apply(const float *__res
                                                              const float *__restrict__ inv, const float *__restrict__ a,
                                                              const float *__restrict__ b, const float *__restrict__ c,
                                                              float *__restrict__ dx, float *__restrict__ g_out, long rows,
-                                                             int relu)
+                                                             int relu, float *__restrict__ amax_part)
 {
     const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    float am = 0.f;
     const float4 mu = *(const float4 *)(mean + 4 * cq), iv = *(const float4 *)(inv + 4 * cq);
     const float4 a4 = *(const float4 *)(a + 4 * cq), b4 = *(const float4 *)(b + 4 * cq), c4 = *(const float4 *)(c + 4 * cq);
     for (long r = (long)blockIdx.x * TR_ROWLANES + rl; r < rows; r += (long)gridDim.x * TR_ROWLANES) {
@@ -178,7 +198,9 @@ __global__ __launch_bounds__(TR_THREADS) void k_bn_grad_apply(const float *__res
         d.w = a4.w * (g.w - b4.w - ((v.w - mu.w) * iv.w) * c4.w);
         *(float4 *)(dx + o) = d;
         if (g_out) *(float4 *)(g_out + o) = g;
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(d.x), fabsf(d.y))), fmaxf(fabsf(d.z), fabsf(d.w)));
     }
+    if (amax_part) tr_block_amax(am, amax_part);
 }
 
 static int tr_grid(long rows)
@@ -198,10 +220,13 @@ extern "C" int snk_bn_train_sums(const float *d_y, long rows, float *d_partials,
 }
 
 extern "C" int snk_bn_train_apply(const float *d_y, const float *d_scale, const float *d_shift, const float *d_residual,
-                                  float *d_out, long rows, int relu, void *stream)
+                                  float *d_out, long rows, int relu, float *d_partials, float *d_out_scale_tail, void *stream)
 {
-    SNK_REQUIRE(d_y && d_scale && d_shift && d_out && rows > 0, "snk_bn_train_apply: bad argument");
-    k_bn_apply<<<tr_grid(rows), TR_THREADS, 0, (hipStream_t)stream>>>(d_y, d_scale, d_shift, d_residual, d_out, rows, relu);
+    SNK_REQUIRE(d_y && d_scale && d_shift && d_out && rows > 0 && (!d_out_scale_tail || d_partials), "snk_bn_train_apply: bad argument");
+    const int grid = tr_grid(rows);
+    k_bn_apply<<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_y, d_scale, d_shift, d_residual, d_out, rows, relu,
+                                                              d_out_scale_tail ? d_partials : nullptr);
+    if (d_out_scale_tail) k_amax_scale<<<1, 1024, 0, (hipStream_t)stream>>>(d_partials, grid, d_out_scale_tail);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -220,12 +245,14 @@ extern "C" int snk_bn_train_grad_sums(const float *d_dout, const float *d_out, c
 
 extern "C" int snk_bn_train_grad_apply(const float *d_dout, const float *d_out, const float *d_y, const float *d_mean,
                                        const float *d_inv, const float *d_a, const float *d_b, const float *d_c, float *d_dx,
-                                       float *d_g, long rows, int relu, void *stream)
+                                       float *d_g, long rows, int relu, float *d_partials, float *d_dx_scale_tail, void *stream)
 {
-    SNK_REQUIRE(d_dout && d_y && d_mean && d_inv && d_a && d_b && d_c && d_dx && rows > 0 && (!relu || d_out),
-                "snk_bn_train_grad_apply: bad argument");
-    k_bn_grad_apply<<<tr_grid(rows), TR_THREADS, 0, (hipStream_t)stream>>>(d_dout, d_out, d_y, d_mean, d_inv, d_a, d_b, d_c, d_dx,
-                                                                          d_g, rows, relu);
+    SNK_REQUIRE(d_dout && d_y && d_mean && d_inv && d_a && d_b && d_c && d_dx && rows > 0 && (!relu || d_out) &&
+                (!d_dx_scale_tail || d_partials), "snk_bn_train_grad_apply: bad argument");
+    const int grid = tr_grid(rows);
+    k_bn_grad_apply<<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_dout, d_out, d_y, d_mean, d_inv, d_a, d_b, d_c, d_dx, d_g, rows,
+                                                                   relu, d_dx_scale_tail ? d_partials : nullptr);
+    if (d_dx_scale_tail) k_amax_scale<<<1, 1024, 0, (hipStream_t)stream>>>(d_partials, grid, d_dx_scale_tail);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }

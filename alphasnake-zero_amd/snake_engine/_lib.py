@@ -89,9 +89,9 @@ PROTOTYPES = {
     "snk_conv3x3_wgrad_partials": (C.c_long, [i32, i32]),
     "snk_conv3x3_wgrad_f16s": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "snk_bn_train_sums": (i32, [vp, C.c_long, vp, vp, vp]),
-    "snk_bn_train_apply": (i32, [vp, vp, vp, vp, vp, C.c_long, i32, vp]),
+    "snk_bn_train_apply": (i32, [vp, vp, vp, vp, vp, C.c_long, i32, vp, vp, vp]),
     "snk_bn_train_grad_sums": (i32, [vp, vp, vp, vp, vp, C.c_long, i32, vp, vp, vp]),
-    "snk_bn_train_grad_apply": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_long, i32, vp]),
+    "snk_bn_train_grad_apply": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_long, i32, vp, vp, vp]),
 }
 
 

@@ -21,6 +21,10 @@ from .net import F16S_TAIL_OFFSET, F16S_WEIGHT_BYTES
 
 _NATIVE_WGRAD = os.environ.get("SNK_TRAIN_WGRAD", "native") != "torch"    # `torch`: the library's weight gradient (A/B runs)
 _scratch = {}
+# (data_ptr, numel, {., ., scale, 1 / scale}) of the tensor the LAST batch-norm kernel wrote: the convolution that reads it next
+# (forward: the following layer; backward: this layer's own convolution) takes its input scale from there.  A live tensor's
+# address cannot belong to another tensor, so an address + size match with the most recent producer identifies it.
+_last_scale = None
 
 
 def _partials(device):
@@ -46,12 +50,18 @@ def _conv_same(x_nhwc, k_hwio):
     n, h, w, c = x_nhwc.shape
     image = torch.empty(F16S_WEIGHT_BYTES, dtype=torch.uint8, device=x_nhwc.device)
     check(L.snk_conv3x3_prepare_weights_f16s(k_hwio.contiguous().data_ptr(), image.data_ptr(), 1.0, st))
-    check(L.snk_conv3x3_f16s_input_scale(x_nhwc.data_ptr(), x_nhwc.numel(), image.data_ptr(), _partials(x_nhwc.device).data_ptr(), st))
+    global _last_scale
+    tail = image[F16S_TAIL_OFFSET:F16S_TAIL_OFFSET + 16].view(torch.float32)
+    if _last_scale is not None and _last_scale[0] == x_nhwc.data_ptr() and _last_scale[1] == x_nhwc.numel():
+        tail[2:4] = _last_scale[2][2:4]        # the kernel that wrote this tensor a moment ago also took its largest magnitude
+    else:
+        check(L.snk_conv3x3_f16s_input_scale(x_nhwc.data_ptr(), x_nhwc.numel(), image.data_ptr(), _partials(x_nhwc.device).data_ptr(), st))
+    _last_scale = None
     ones, zeros = _unit(x_nhwc.device)
     out = torch.empty_like(x_nhwc)
     check(L.snk_conv3x3_bn_f16s(x_nhwc.data_ptr(), image.data_ptr(), ones.data_ptr(), zeros.data_ptr(), None, out.data_ptr(),
                                 n, h, w, 0, st))
-    return out, image[F16S_TAIL_OFFSET:F16S_TAIL_OFFSET + 16].view(torch.float32)      # the tail carries the input's scale
+    return out, tail                                       # the tail carries the input's scale
 
 
 def _input_scale(x_nhwc):
@@ -145,9 +155,13 @@ class FusedBatchNormAct(torch.autograd.Function):
         scale = (gamma * inv).contiguous()
         shift = (beta - mean * scale).contiguous()
         res_nhwc = residual.permute(0, 2, 3, 1).contiguous() if residual is not None else None
+        global _last_scale
         out = torch.empty_like(y_nhwc)
+        tail = torch.empty(4, dtype=torch.float32, device=y.device)
         check(L.snk_bn_train_apply(y_nhwc.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                   res_nhwc.data_ptr() if res_nhwc is not None else None, out.data_ptr(), rows, int(relu), st))
+                                   res_nhwc.data_ptr() if res_nhwc is not None else None, out.data_ptr(), rows, int(relu),
+                                   _partials(y.device).data_ptr(), tail.data_ptr(), st))
+        _last_scale = (out.data_ptr(), out.numel(), tail)
         ctx.save_for_backward(y_nhwc, out, gamma, mean.contiguous(), inv.contiguous(), n)
         ctx.relu, ctx.has_res, ctx.dist = bool(relu), residual is not None, dist
         res = out.permute(0, 3, 1, 2)
@@ -173,7 +187,11 @@ class FusedBatchNormAct(torch.autograd.Function):
         cc = (red[c:] / n).contiguous()
         dx = torch.empty_like(y_nhwc)
         g = torch.empty_like(y_nhwc) if ctx.has_res else None
+        global _last_scale
+        tail = torch.empty(4, dtype=torch.float32, device=dout.device)
         check(L.snk_bn_train_grad_apply(d_nhwc.data_ptr(), out.data_ptr(), y_nhwc.data_ptr(), mean.data_ptr(), inv.data_ptr(),
                                         a.data_ptr(), b.data_ptr(), cc.data_ptr(), dx.data_ptr(),
-                                        g.data_ptr() if g is not None else None, rows, int(ctx.relu), st))
+                                        g.data_ptr() if g is not None else None, rows, int(ctx.relu),
+                                        _partials(dout.device).data_ptr(), tail.data_ptr(), st))
+        _last_scale = (dx.data_ptr(), dx.numel(), tail)
         return dx.permute(0, 3, 1, 2), dgamma, dbeta, (g.permute(0, 3, 1, 2) if g is not None else None), None, None

@@ -312,7 +312,10 @@ int snk_engine_rewards(const snk_engine *e, const int32_t *d_slots, int n, int8_
  *   snk_bn_train_sums        d_sums[0..127] = per-channel sum of y, d_sums[128..255] = sum of y * y (deterministic order)
  *   snk_bn_train_apply       out = y * scale + shift (+ residual), then ReLU when relu != 0
  *   snk_bn_train_grad_sums   with g = dout (masked by out > 0 when relu): d_sums = { sum g, sum g * xhat }, xhat = (y - mean) * inv
- *   snk_bn_train_grad_apply  dx = a * (g - b - xhat * c); d_g (optional) = g, the gradient of the residual branch        */
+ *   snk_bn_train_grad_apply  dx = a * (g - b - xhat * c); d_g (optional) = g, the gradient of the residual branch
+ * The two apply kernels can hand on the power-of-two input scale of the convolution that reads their result (what
+ * snk_conv3x3_f16s_input_scale would derive from it): d_out_scale_tail / d_dx_scale_tail (optional) = 4 floats
+ * { ., ., scale, 1 / scale }, taken from the values as they are written -- the tensor is not read again for its maximum. */
 int snk_bn_train_partials(void);
 /* The split-f16 convolution's power-of-two input scale from the data itself, for tensors whose range is not known ahead
  * (gradients): x_scale with 2^11 <= max|x| * x_scale < 2^12 is written into the tail of the weight image d_wS
@@ -328,12 +331,12 @@ int snk_conv3x3_wgrad_f16s(const float *d_x, const float *d_dy, const float *d_x
                            float *d_partials, float *d_dw, int n_images, int height, int width, void *stream);
 int snk_bn_train_sums(const float *d_y, long rows, float *d_partials, float *d_sums, void *stream);
 int snk_bn_train_apply(const float *d_y, const float *d_scale, const float *d_shift, const float *d_residual,
-                       float *d_out, long rows, int relu, void *stream);
+                       float *d_out, long rows, int relu, float *d_partials, float *d_out_scale_tail, void *stream);
 int snk_bn_train_grad_sums(const float *d_dout, const float *d_out, const float *d_y, const float *d_mean,
                            const float *d_inv, long rows, int relu, float *d_partials, float *d_sums, void *stream);
 int snk_bn_train_grad_apply(const float *d_dout, const float *d_out, const float *d_y, const float *d_mean,
                             const float *d_inv, const float *d_a, const float *d_b, const float *d_c, float *d_dx,
-                            float *d_g, long rows, int relu, void *stream);
+                            float *d_g, long rows, int relu, float *d_partials, float *d_dx_scale_tail, void *stream);
 
 #ifdef __cplusplus
 }
