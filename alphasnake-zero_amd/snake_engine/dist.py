@@ -14,6 +14,23 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+BATCH_ROWS = 2048          # trainer.py:63
+MAX_BATCHES = 5            # trainer.py:65
+
+
+def sample_plan(n_records_all_ranks, world=1):
+    """(rows to sample in total, fit batch size, rows per rank) from the number of records of ALL ranks, as
+    trainer.py:63-72 derives them from len(Alice.records): at most 5 batches of 2 048 rows, whole batches only.
+    With fewer than one batch of records the reference draws nothing and fails in `flip` (its `samples > len(records)`
+    branch cannot be taken); here all records form one batch, which is what that branch says."""
+    batches = min(MAX_BATCHES, n_records_all_ranks // BATCH_ROWS)
+    if batches:
+        wanted, batch_size = BATCH_ROWS * batches, BATCH_ROWS
+    else:
+        wanted = batch_size = (n_records_all_ranks // world) * world
+    return wanted, batch_size, wanted // world
+
+
 def sample_share(n_local_records, total_samples, world, rng):
     """indices of this rank's share of the `total_samples` training rows (trainer.py:63-74 draws
     sample(range(len(records)), samples) from one pool; here every rank draws total/world from its own)"""

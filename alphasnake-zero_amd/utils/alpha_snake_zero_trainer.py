@@ -24,8 +24,6 @@ import numpy as np
 from utils.agent import Agent
 from utils.mp_game_runner import MPGameRunner, LOG_FIELDS
 
-BATCH_ROWS = 2048          # trainer.py:63
-MAX_BATCHES = 5            # trainer.py:65
 
 
 def _dist():
@@ -59,6 +57,13 @@ class AlphaSnakeZeroTrainer:
             return 3
         return 9
 
+    # the two constructor calls of trainer.py:52-53; tests replace them to feed recorded start boards and draws
+    def _make_agent(self, nnet, softmax_base, training, max_MCTS_depth, max_MCTS_breadth):
+        return Agent(nnet, softmax_base, training, max_MCTS_depth, max_MCTS_breadth)
+
+    def _make_runner(self, height, width, snake_cnt, health_dec, game_cnt):
+        return MPGameRunner(height, width, snake_cnt, health_dec, game_cnt)
+
     def _self_play(self, nnet, iteration):
         """trainer.py:48-54 (+ the per-rank shard when several GPUs play)"""
         dist = _dist()
@@ -67,8 +72,8 @@ class AlphaSnakeZeroTrainer:
             from snake_engine.dist import shard_range
             lo, hi = shard_range(n_games, dist.get_rank(), dist.get_world_size())
             n_games = hi - lo
-        alice = Agent(nnet, 2 + iteration, True, self.max_MCTS_depth, self.max_MCTS_breadth)
-        runner = MPGameRunner(self.height, self.width, self.snake_cnt, self.health_dec_for(iteration), max(1, n_games))
+        alice = self._make_agent(nnet, 2 + iteration, True, self.max_MCTS_depth, self.max_MCTS_breadth)
+        runner = self._make_runner(self.height, self.width, self.snake_cnt, self.health_dec_for(iteration), max(1, n_games))
         runner.run(alice)
         return alice, runner
 
@@ -88,14 +93,11 @@ class AlphaSnakeZeroTrainer:
 
     def _collect(self, alice):
         """trainer.py:63-77: (X, V, batch_size) with the mirror images appended"""
+        from snake_engine.dist import sample_plan
         n = len(alice.records)
-        batches = min(MAX_BATCHES, n // BATCH_ROWS)
-        batch_size = BATCH_ROWS
-        wanted = batch_size * batches
-        if batches == 0:                       # fewer than one batch of records: take them all as one batch
-            batch_size = wanted = n
         dist = _dist()
         if dist is None:
+            wanted, batch_size, _ = sample_plan(n, 1)
             picked = sample(range(n), wanted)
             X = [alice.records[i] for i in picked]
             V = [alice.values[i] for i in picked]
@@ -103,11 +105,12 @@ class AlphaSnakeZeroTrainer:
             import torch
             from snake_engine.dist import sample_share, all_gather_samples
             world = dist.get_world_size()
-            t = torch.tensor([wanted], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)              # the smallest rank decides the batch count for all
-            wanted = int(t.item())
-            batch_size = min(batch_size, wanted)
+            t = torch.tensor([n], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t)                                    # the batch count comes from ALL records (trainer.py:64-68)
+            wanted, batch_size, _ = sample_plan(int(t.item()), world)
             idx, share = sample_share(n, wanted, world, np.random.RandomState(np.random.randint(1 << 31)))
+            if len(idx) != share:
+                raise RuntimeError(f"rank {dist.get_rank()} recorded no state to sample from")
             Xd = alice.records.fetch_device(idx)
             Vd = torch.as_tensor(alice._values_host()[idx], device=Xd.device)
             Xg, Vg = all_gather_samples(Xd, Vd)

@@ -96,9 +96,11 @@ def stub_q_from_key(klo):
 
 def stub_q(states, legacy=False, which=0):
     """Deterministic Q(left, straight, right) with the reference's obstacle mask applied.
-    ``which`` = 0 / 1 picks the low / high key word: two different "nets" for the pit runs."""
+    ``which`` = 0 / 1 picks the low / high key word, 2 their sum mod 2**64: different "nets" for the pit runs."""
     k = obs_key(states)
-    q = stub_q_from_key(k[:, which])
+    with np.errstate(over="ignore"):
+        word = k[:, which] if which < 2 else k[:, 0] + k[:, 1]
+    q = stub_q_from_key(word)
     q[obstacle_mask(states, legacy)] = np.float32(-1.0)
     return q
 

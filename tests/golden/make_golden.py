@@ -737,9 +737,317 @@ def record_replay(seed=31, H=11, W=11, S=4, hd=9):
     np.savez_compressed(os.path.join(HERE, "replay.npz"), **flat)
 
 
+
+# ----------------------------------------------------------------------------- generation loop (trainer) + pit.py script
+def _tensorflow_stand_in(load_model=None):
+    """TensorFlow is not in this image, so ``utils.alpha_nnet`` (alpha_nnet.py:3-6) -- which
+    ``utils.alpha_snake_zero_trainer`` and ``pit.py`` import -- cannot be imported as is.  Empty stand-in MODULES are put
+    into sys.modules under the names those four import lines ask for; no reference file is edited and nothing of Keras
+    is emulated: the net the recorded runs use is the deterministic StubNet, the module only has to import."""
+    import types
+    names = ["tensorflow", "tensorflow.keras", "tensorflow.keras.layers", "tensorflow.keras.optimizers",
+             "tensorflow.keras.regularizers", "tensorflow.keras.models"]
+    mods = {n: types.ModuleType(n) for n in names}
+    mods["tensorflow"].keras = mods["tensorflow.keras"]
+    for n in names[2:]:
+        setattr(mods["tensorflow.keras"], n.rsplit(".", 1)[1], mods[n])
+    mods["tensorflow.keras.regularizers"].l2 = lambda c: None
+    mods["tensorflow.keras.models"].Model = object
+    mods["tensorflow.keras.models"].clone_model = None
+    mods["tensorflow.keras.models"].load_model = load_model
+    sys.modules.update(mods)
+
+
+class RawUniformTape(UniformTape):
+    """UniformTape whose accepted draws can be rebuilt from the seed: the raw stream is
+    RandomState(seed).random_sample, `rejected` lists the raw positions that fell within 1e-4 of a cdf edge"""
+
+    def __init__(self, seed):
+        super().__init__(seed)
+        self.seed = seed
+        self.raw = 0
+        self.rejected = []
+        outer = self
+
+        class Counting:
+            def random_sample(self_inner):
+                outer.raw += 1
+                return outer._rs.random_sample()
+        self._rs = self.rs
+        self.rs = Counting()
+
+    def __call__(self, a, p=None):
+        before, n_u = self.raw, len(self.u)
+        r = super().__call__(a, p)
+        self.rejected += list(range(before, self.raw - 1))          # every raw draw of this call but the accepted last one
+        assert len(self.u) == n_u + 1
+        return r
+
+
+class _SnakesHashById:
+    """Game.tic removes the snakes that died in a tick by iterating a SET of Snake objects (game.py:167), whose order follows
+    the objects' memory addresses; with several deaths in one tick that order decides the insertion order of
+    `empty_positions` and with it which cell a later `choice(tuple(empty_positions))` means.  Any order is the reference's
+    behaviour; hashing the snakes by id while a run is recorded makes the recorded run independent of what the process
+    allocated before (the older recordings keep the default hash: they are committed as they were made)."""
+
+    def __enter__(self):
+        G.Snake.__hash__ = lambda snake: snake.id
+
+    def __exit__(self, *exc):
+        del G.Snake.__hash__
+
+
+class _StopLoop(Exception):
+    pass
+
+
+def record_trainer():
+    """AlphaSnakeZeroTrainer.train (alpha_snake_zero_trainer.py:33-91), the reference's own unmodified loop, run for two
+    generations from three starting points (generation 0: log header, health_dec 9; 8: 9 -> 3; 32: 3 -> 1) with a stub
+    net object: what it constructs (Agent / MPGameRunner arguments), what it writes (log.csv), what it draws
+    (random.sample indices), what it hands to nnet.train (X, V, batch_size), the learning rates, the save names."""
+    import contextlib
+    import io
+    import tempfile
+    _tensorflow_stand_in()
+    import utils.alpha_snake_zero_trainer as T        # the reference's module, as it is
+    flat = {}
+    runs = [("gen0", 0, 48, 8, 4, 2e-4, 0.9), ("gen8", 8, 44, 8, 4, 1e-4, 0.98), ("gen32", 32, 12, 8, 6, 3e-4, 0.5)]
+    for ri, (tag, start, n_games, breadth, depth, lr0, decay) in enumerate(runs):
+        seed = 300 + ri
+        pyrandom.seed(seed)
+        np.random.seed(seed)
+        tape = RawUniformTape(seed + 1)
+        A.choice = tape
+        L = 11 * 11 + 2
+        log = dict(agent=[], runner=[], init=[], spawn=[], tape_pos=[], sample=[], copy_lr=[], train=[], save=[], which=[])
+
+        class Net:
+            """the slice of AlphaNNet the loop touches; `train` swaps the stub net so that generation n + 1 demonstrably
+            plays with what generation n's training returned"""
+
+            def __init__(self, which):
+                self.which = which
+                self.stub = StubNet(which)
+
+            def v(self, X):
+                return self.stub.v(X)
+
+            def copy_and_compile(self, learning_rate=0.0001, TPU=None):
+                log["copy_lr"].append(learning_rate)
+                return Net(self.which)
+
+            def train(self, X, V, batch_size=2048):
+                Xa, Va = np.array(X, np.float32), np.array(V, np.float32)
+                log["train"].append((Xa, Va, batch_size))
+                self.which = 1 - self.which
+                self.stub = StubNet(self.which)
+
+            def save(self, name):
+                log["save"].append(name)
+                if len(log["save"]) == 2:
+                    raise _StopLoop
+
+        class AgentTap(A.Agent):
+            def __init__(self, nnet, softmax_base=100, training=False, max_MCTS_depth=8, max_MCTS_breadth=128):
+                log["agent"].append((softmax_base, int(training), max_MCTS_depth, max_MCTS_breadth))
+                log["which"].append(nnet.which)
+                log["tape_pos"].append(len(tape.u))
+                super().__init__(nnet, softmax_base, training, max_MCTS_depth, max_MCTS_breadth)
+                log["alice"] = self
+
+        class RunnerTap(R.MPGameRunner):
+            def __init__(self, height=11, width=11, snake_cnt=4, health_dec=1, game_cnt=1):
+                log["runner"].append((height, width, snake_cnt, health_dec, game_cnt))
+                super().__init__(height, width, snake_cnt, health_dec, game_cnt)
+                log["init"].append([snapshot(self.games[g], L) for g in range(game_cnt)])
+                log["spawn"].append({g: [] for g in range(game_cnt)})
+
+        def sample_tap(pop, k):
+            r = pyrandom.sample(pop, k)
+            log["sample"].append((len(pop), np.array(r, np.int32)))
+            alice = log["alice"]                       # the records and values the indices point into (before clear())
+            log.setdefault("records", []).append(np.array([np.frombuffer(
+                hashlib.blake2b(np.ascontiguousarray(x).tobytes(), digest_size=8).digest(), np.uint8) for x in alice.records]))
+            log.setdefault("values", []).append(np.array(alice.values, np.float32))
+            return r
+
+        orig_tic = G.Game.tic
+
+        def tic_log(self, moves, show=False):
+            r = orig_tic(self, moves, show)
+            if self.food_spawn_chance > 0:              # root games only (sub-games: chance 0, game.py:268)
+                sp = self._last_spawn
+                log["spawn"][-1][self.id].append(-1 if sp is None else sp[0] * self.width + sp[1])
+            return r
+        G.Game.tic = tic_log
+        T.Agent, T.MPGameRunner, T.sample = AgentTap, RunnerTap, sample_tap
+        cwd = os.getcwd()
+        with tempfile.TemporaryDirectory() as tmp:
+            os.chdir(tmp)
+            try:
+                with contextlib.redirect_stdout(io.StringIO()), _SnakesHashById():
+                    try:
+                        T.AlphaSnakeZeroTrainer(n_games, depth, breadth, lr0, decay, 11, 11, 4).train(Net(0), "g", start)
+                    except _StopLoop:
+                        pass
+                text = open("log.csv", "rb").read()
+            finally:
+                os.chdir(cwd)
+                G.Game.tic = orig_tic
+                T.Agent, T.MPGameRunner, T.sample = A.Agent, R.MPGameRunner, pyrandom.sample
+        p = f"{tag}_"
+        flat[p + "ctor"] = np.array([n_games, depth, breadth, start], np.int32)
+        flat[p + "lr"] = np.array([lr0, decay], np.float64)
+        flat[p + "log_csv"] = np.frombuffer(text, np.uint8)
+        flat[p + "agent_args"] = np.array(log["agent"], np.int32)
+        flat[p + "runner_args"] = np.array(log["runner"], np.int32)
+        flat[p + "net_which"] = np.array(log["which"], np.int8)
+        flat[p + "copy_lr"] = np.array(log["copy_lr"], np.float64)
+        flat[p + "save_names"] = np.array(log["save"])
+        flat[p + "tape_seed"] = np.int64(tape.seed)
+        flat[p + "tape_len"] = np.int64(len(tape.u))
+        flat[p + "tape_rejected"] = np.array(tape.rejected, np.int64)
+        flat[p + "tape_digest"] = np.frombuffer(hashlib.blake2b(np.array(tape.u, np.float64).tobytes(), digest_size=16).digest(), np.uint8)
+        flat[p + "tape_pos"] = np.array(log["tape_pos"], np.int64)
+        for gi in range(2):
+            q = p + f"g{gi}_"
+            init = log["init"][gi]
+            for k in init[0]:
+                arr = np.stack([s[k] for s in init])
+                flat[q + "init_" + k] = arr[:, :, :4] if k == "nodes" else arr
+            sp = log["spawn"][gi]
+            n_turns = max(len(v) for v in sp.values())
+            spawn = np.full((n_turns, len(sp)), -2, np.int16)
+            for g in sp:
+                spawn[:len(sp[g]), g] = sp[g]
+            flat[q + "spawn"] = spawn
+            n_pop, idx = log["sample"][gi]
+            Xa, Va, bs = log["train"][gi]
+            assert n_pop == len(log["records"][gi]) == len(log["values"][gi])
+            flat[q + "n_records"] = np.int64(n_pop)
+            flat[q + "sample_idx"] = idx
+            flat[q + "records_digest"] = log["records"][gi]
+            flat[q + "values"] = log["values"][gi]
+            flat[q + "batch_size"] = np.int64(bs)
+            flat[q + "X_rows"] = np.int64(len(Xa))
+            flat[q + "X_digest"] = np.frombuffer(hashlib.blake2b(Xa.tobytes(), digest_size=32).digest(), np.uint8)
+            flat[q + "V_digest"] = np.frombuffer(hashlib.blake2b(Va.tobytes(), digest_size=32).digest(), np.uint8)
+            # the values the loop hands to the fit are the recorded ones at the sampled indices, then their mirror images
+            assert np.array_equal(Va[:len(idx)], log["values"][gi][idx]) and np.array_equal(Va[len(idx):], Va[:len(idx), ::-1])
+            print(f"[trainer {tag} gen {gi}] runner={log['runner'][gi]} agent={log['agent'][gi]} turns={n_turns} "
+                  f"records={n_pop} sampled={len(idx)} X={Xa.shape} batch={bs}")
+        print(f"[trainer {tag}] copy_lr={log['copy_lr']} saves={log['save']} draws={len(tape.u)} rejected={len(tape.rejected)}")
+        print(text.decode())
+    flat["names"] = np.array([r[0] for r in runs])
+    np.savez_compressed(os.path.join(HERE, "trainer.npz"), **flat)
+
+
+def record_pit_script():
+    """pit.py (pit.py:1-62), the reference's champion-ladder SCRIPT, executed unmodified with runpy: `input()` answers
+    "m" / "3", generations 3..5 "exist" (the stand-in load_model hands out stub nets, anything else raises OSError as a
+    missing file does), the first `sleep` ends the otherwise endless loop.  Recorded: pit.txt, and per challenger the
+    1 000 start boards, the food-spawn tape and the winner indices."""
+    import builtins
+    import contextlib
+    import io
+    import runpy
+    import tempfile
+    import time as time_mod
+    from oracle.obs_key import stub_q_from_key
+
+    class StubKeras:
+        def __init__(self, which):
+            self.which = which
+
+        def predict(self, X):                       # un-masked: AlphaNNet.v applies alpha_nnet.py:63-76 itself
+            k = obs_key(X)
+            with np.errstate(over="ignore"):
+                return stub_q_from_key(k[:, self.which] if self.which < 2 else k[:, 0] + k[:, 1])
+
+    def load_model(path):
+        gen = int(path[len("models/m"):-len(".h5")])
+        if path != f"models/m{gen}.h5" or not 3 <= gen <= 5:
+            raise OSError("no such file: " + path)
+        return StubKeras(gen - 3)
+    _tensorflow_stand_in(load_model)
+    for m in ("utils.alpha_nnet",):
+        sys.modules.pop(m, None)                    # (re-)import it against the stand-in that has load_model
+    import utils.pit_mp_game_runner as P
+    H = W = 11
+    S = 2
+    L = H * W + 2
+    log = dict(init=[], spawn=[], winners=[], args=[])
+
+    class RunnerTap(P.MPGameRunner):
+        def __init__(self, height=11, width=11, snake_cnt=4, health_dec=1, game_cnt=1):
+            log["args"].append((height, width, snake_cnt, health_dec, game_cnt))
+            super().__init__(height, width, snake_cnt, health_dec, game_cnt)
+            log["init"].append([snapshot(self.games[g], L) for g in range(game_cnt)])
+            log["spawn"].append({g: [] for g in range(game_cnt)})
+
+        def run(self, Alice, Bob, Alice_snake_cnt=None):
+            w = super().run(Alice, Bob, Alice_snake_cnt)
+            log["winners"].append((Alice_snake_cnt, list(w)))
+            return w
+
+    orig_tic = G.Game.tic
+
+    def tic_log(self, moves, show=False):
+        r = orig_tic(self, moves, show)
+        sp = self._last_spawn
+        log["spawn"][-1][self.id].append(-1 if sp is None else sp[0] * W + sp[1])
+        return r
+
+    def stop(_seconds):
+        raise _StopLoop
+    answers = iter(["m", "3"])
+    pyrandom.seed(81)               # of seeds 77..83 the one whose run has both outcomes (a title change, then a failed challenge)
+    np.random.seed(81)
+    orig_runner, orig_sleep, orig_input = P.MPGameRunner, time_mod.sleep, builtins.input
+    P.MPGameRunner, time_mod.sleep, builtins.input = RunnerTap, stop, lambda prompt="": next(answers)
+    G.Game.tic = tic_log
+    cwd = os.getcwd()
+    out = io.StringIO()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            with contextlib.redirect_stdout(out), _SnakesHashById():
+                try:
+                    runpy.run_path("/root/reference/code/pit.py", run_name="__main__")
+                except _StopLoop:
+                    pass
+            text = open("pit.txt", "rb").read()
+        finally:
+            os.chdir(cwd)
+            P.MPGameRunner, time_mod.sleep, builtins.input = orig_runner, orig_sleep, orig_input
+            G.Game.tic = orig_tic
+    flat = dict(pit_txt=np.frombuffer(text, np.uint8), n=len(log["winners"]),
+                stdout=np.array([ln for ln in out.getvalue().splitlines() if not ln.startswith("Competing time")]))
+    for ci in range(len(log["winners"])):
+        p = f"c{ci}_"
+        a_cnt, winners = log["winners"][ci]
+        flat[p + "args"] = np.array(log["args"][ci] + (a_cnt,), np.int32)
+        flat[p + "winners"] = np.array([-1 if w is None else w for w in winners], np.int8)
+        sp = log["spawn"][ci]
+        n_turns = max(len(v) for v in sp.values())
+        spawn = np.full((n_turns, len(sp)), -2, np.int16)
+        for g in sp:
+            spawn[:len(sp[g]), g] = sp[g]
+        flat[p + "spawn"] = spawn
+        init = log["init"][ci]
+        for k in init[0]:
+            arr = np.stack([s[k] for s in init])
+            flat[p + "init_" + k] = arr[:, :, :4] if k == "nodes" else arr
+        print(f"[pit_script challenger {ci}] args={flat[p + 'args'].tolist()} turns={n_turns} "
+              f"winners: A {sum(w == 0 for w in winners)} B {sum(w == 1 for w in winners)} draw {sum(w is None for w in winners)}")
+    print(text.decode())
+    np.savez_compressed(os.path.join(HERE, "pit_script.npz"), **flat)
+
 if __name__ == "__main__":
     os.chdir("/tmp")
-    which = set(sys.argv[1:]) or {"tic", "tic_more", "corner", "tables", "mcts", "mcts_more", "runner", "pit", "replay"}
+    which = set(sys.argv[1:]) or {"tic", "tic_more", "corner", "tables", "mcts", "mcts_more", "runner", "pit", "replay", "trainer", "pit_script"}
     if "tic" in which:
         record_trajectories("11x11x4", 11, 11, 4, 1, 40, seed=1, p_legal=0.92, max_ticks=400, raw_every=23)
         record_trajectories("11x11x4_dec9", 11, 11, 4, 9, 10, seed=2, p_legal=0.97, max_ticks=400, raw_every=29)
@@ -767,3 +1075,7 @@ if __name__ == "__main__":
         record_pit()
     if "replay" in which:
         record_replay()
+    if "trainer" in which:       # needs the tensorflow stand-in modules: after everything that must not see them
+        record_trainer()
+    if "pit_script" in which:
+        record_pit_script()

@@ -461,6 +461,55 @@ def test_large_batch_invariants(se):
         assert not (cst["food"][cells] if cells else np.zeros(0)).any(), "food under a snake"
 
 
+def test_observe_at_bench_size_matches_the_oracle(se, oracle):
+    """the plane-writing form the bench actually runs: from 32 768 observations on the kernel takes two consecutive
+    observations per wavefront (csrc/engine.hip, `reps`).  14 336 games from the device's own reset, 20 ticks of moves
+    that avoid blocked cells -> >= 40 000 observations in ONE default launch; a strided sample of >= 2 000 rows
+    (both members of a wavefront's pair, first and last rows included) byte for byte against the oracle's
+    Game.make_state (game.py:215-257), with masks (alpha_nnet.py:63-76) and keys (agent.py:175)"""
+    import torch
+    from snake_engine.engine import compact_from_state
+    from oracle.obs_key import obs_key, obstacle_mask
+    assert "SNK_OBS_REPS" not in os.environ or os.environ["SNK_OBS_REPS"] != "1"
+    n, T = 14336, 20
+    eng = se.Engine(n, 11, 11, 4, 1, 0.15, seed=4711)
+    eng.reset()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for t in range(T):
+        alive = eng.alive()
+        pairs = torch.nonzero(alive).to(torch.int32).contiguous()
+        _, mask, _ = eng.observe_all(pairs, want_planes=False, want_key=False)
+        free = (mask == 0).to(torch.float32) + 1e-3                     # a legal move whenever there is one
+        pick = torch.multinomial(free, 1, generator=g).squeeze(1).to(torch.uint8)
+        mv = torch.ones((n, 4), dtype=torch.uint8, device="cuda")
+        mv[pairs[:, 0].long(), pairs[:, 1].long()] = pick
+        eng.step(mv)
+    alive = eng.alive()
+    pairs = torch.nonzero(alive).to(torch.int32).contiguous()
+    m = pairs.shape[0]
+    assert m >= 40000, m                                               # beyond the kernel's 32 768-row switch
+    planes, mask, key = eng.observe_all(pairs)
+    pick = np.unique(np.concatenate([np.arange(0, m, 37), np.arange(1, m, 37), np.arange(m - 64, m), np.arange(64)]))
+    assert len(pick) >= 2000
+    ph = planes[torch.as_tensor(pick, device="cuda")].cpu().numpy()
+    mh = mask.cpu().numpy()[pick]
+    kh = key.cpu().numpy().view(np.uint64)[pick]
+    pr = pairs.cpu().numpy()[pick]
+    slots = np.unique(pr[:, 0]).astype(np.int32)
+    games = {int(s): oracle.Game.from_compact(11, 11, 4, 1, 0.15, compact_from_state(st))
+             for s, st in zip(slots, eng.export(slots))}
+    lengths = set()
+    for i, (slot, snake) in enumerate(pr):
+        ref = games[int(slot)].make_state(int(snake))
+        assert ph[i].tobytes() == ref.tobytes(), (int(pick[i]), int(slot), int(snake))
+        assert np.array_equal(mh[i].astype(bool), obstacle_mask(ref)[0]) and np.array_equal(kh[i], obs_key(ref)[0])
+        lengths.add(int(games[int(slot)].g.length[int(snake)]))
+    assert max(lengths) >= 5, lengths                                  # mid-game boards: snakes that ate
+    # every row once more through a different route: the mask + key form, and row digests equal for equal keys
+    _, mask2, key2 = eng.observe_all(pairs, want_planes=False)
+    assert torch.equal(mask2, mask) and torch.equal(key2, key)
+
+
 def test_error_codes_and_empty_inputs(se):
     """C-ABI error behaviour: bad arguments come back as negative codes with a message (no crash); n = 0 is a no-op"""
     import ctypes as C
