@@ -348,7 +348,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
 }
 
 // max |w| of the layer -> k with 256 <= max * 2^k < 512; writes {2^-k, 2^k, x_scale, 1 / x_scale, range flag = 0} behind the fragment image
-__global__ __launch_bounds__(1024) void k_f16s_wscale(const float *__restrict__ w, float *__restrict__ tail, float x_scale)
+__global__ __launch_bounds__(1024) void k_f16s_wscale(const float *__restrict__ w, float *__restrict__ tail, float x_scale,
+                                                      const float *__restrict__ in_tail = nullptr)
 {
     __shared__ float red[1024];
     float m = 0.f;
@@ -366,13 +367,15 @@ __global__ __launch_bounds__(1024) void k_f16s_wscale(const float *__restrict__ 
         k = max(-100, min(100, k));
         tail[0] = ldexpf(1.0f, -k);
         tail[1] = ldexpf(1.0f, k);
-        tail[2] = x_scale;
-        tail[3] = 1.0f / x_scale;
+        tail[2] = in_tail ? in_tail[2] : x_scale;             // the producer of the input measured its range (train.hip)
+        tail[3] = in_tail ? in_tail[3] : 1.0f / x_scale;
         tail[4] = tail[5] = tail[6] = tail[7] = 0.f;          // range flag (an int32, bit pattern 0) + padding
     }
 }
 
 // Keras kernel (kh, kw, cin, cout) float32 -> split f16 fragments in the order the conv kernel's waves load them
+// FLIP: the kernel of the INPUT GRADIENT of the same layer -- taps mirrored, channel axes swapped: w'[tap][ci][co] = w[8 - tap][co][ci]
+template <bool FLIP>
 __global__ void k_f16s_weights(const float *__restrict__ w, _Float16 *__restrict__ wS, const float *__restrict__ tail)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;          // one f16x8 fragment piece
@@ -385,7 +388,7 @@ __global__ void k_f16s_weights(const float *__restrict__ w, _Float16 *__restrict
     const int cout = 32 * wn + l31;
     for (int j = 0; j < 8; ++j) {
         const int cin = HS_KC * c + 8 * h + j;
-        const float val = w[(long)(tap * HS_C + cin) * HS_C + cout] * mul;
+        const float val = (FLIP ? w[(long)((8 - tap) * HS_C + cout) * HS_C + cin] : w[(long)(tap * HS_C + cin) * HS_C + cout]) * mul;
         const _Float16 hi = (_Float16)val;
         wS[(long)v * 8 + j] = hl ? (_Float16)(val - (float)hi) : hi;
     }
@@ -398,7 +401,22 @@ extern "C" int snk_conv3x3_prepare_weights_f16s(const float *d_w_hwio, void *d_w
     SNK_REQUIRE(x_scale > 0.f && frexpf(x_scale, &e_) == 0.5f, "snk_conv3x3_prepare_weights_f16s: x_scale %g is not a power of two", x_scale);
     float *tail = (float *)((_Float16 *)d_wS + HS_WS_ELEMS);
     k_f16s_wscale<<<1, 1024, 0, (hipStream_t)stream>>>(d_w_hwio, tail, x_scale);
-    k_f16s_weights<<<(HS_WS_ELEMS / 8 + 255) / 256, 256, 0, (hipStream_t)stream>>>(d_w_hwio, (_Float16 *)d_wS, tail);
+    k_f16s_weights<false><<<(HS_WS_ELEMS / 8 + 255) / 256, 256, 0, (hipStream_t)stream>>>(d_w_hwio, (_Float16 *)d_wS, tail);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// the training step's form: the input scale is read on the device from d_in_tail = { ., ., scale, 1 / scale } (what
+// snk_bn_train_apply / snk_bn_train_grad_apply measured while writing the tensor this layer reads); input_gradient != 0
+// lays out the kernel of the layer's input gradient (the same convolution with mirrored taps and swapped channel axes)
+extern "C" int snk_conv3x3_prepare_weights_f16s_train(const float *d_w_hwio, void *d_wS, const float *d_in_tail, int input_gradient,
+                                                      void *stream)
+{
+    SNK_REQUIRE(d_w_hwio && d_wS && d_in_tail, "snk_conv3x3_prepare_weights_f16s_train: NULL argument");
+    float *tail = (float *)((_Float16 *)d_wS + HS_WS_ELEMS);
+    k_f16s_wscale<<<1, 1024, 0, (hipStream_t)stream>>>(d_w_hwio, tail, 1.0f, d_in_tail);
+    if (input_gradient) k_f16s_weights<true><<<(HS_WS_ELEMS / 8 + 255) / 256, 256, 0, (hipStream_t)stream>>>(d_w_hwio, (_Float16 *)d_wS, tail);
+    else k_f16s_weights<false><<<(HS_WS_ELEMS / 8 + 255) / 256, 256, 0, (hipStream_t)stream>>>(d_w_hwio, (_Float16 *)d_wS, tail);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }

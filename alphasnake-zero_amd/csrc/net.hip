@@ -587,6 +587,7 @@ struct StemArgs {
     const float *scale, *shift;
     float *out;          // [M][128]
     int M, Hd, Wd;
+    int raw;             // != 0 (k_stem_conv_mfma only): the bare convolution -- no scale / shift (both may be NULL), no ReLU
 };
 
 // 256 pixels per block; thread (pg = tid / 32, cq = tid % 32) computes outputs 4 cq .. 4 cq + 3 of pixels pg + 8 k with its
@@ -769,7 +770,11 @@ __global__ __launch_bounds__(256) void k_stem_conv_mfma(StemArgs p)
         }
     float scl[4], shf[4];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) { scl[nt] = p.scale[32 * nt + l31] * undo; shf[nt] = p.shift[32 * nt + l31]; }
+    for (int nt = 0; nt < 4; ++nt) {
+        scl[nt] = (p.raw ? 1.f : p.scale[32 * nt + l31]) * undo;
+        shf[nt] = p.raw ? 0.f : p.shift[32 * nt + l31];
+    }
+    const float floor_ = p.raw ? -__builtin_inff() : 0.f;
 
     const int n_lds = (Hd + 2) * P3;
     for (int img = blockIdx.x; img < n_img; img += gridDim.x) {
@@ -822,7 +827,7 @@ __global__ __launch_bounds__(256) void k_stem_conv_mfma(StemArgs p)
                 if (row < HW) {
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
-                        const float v = fmaxf(__builtin_fmaf(acc[nt][r], scl[nt], shf[nt]), 0.f);
+                        const float v = fmaxf(__builtin_fmaf(acc[nt][r], scl[nt], shf[nt]), floor_);
                         if (OUT16) out16[(long)row * CV_C + 32 * nt + l31] = (_Float16)fminf(v, 65504.f);
                         else out[(long)row * CV_C + 32 * nt + l31] = v;
                     }
@@ -1044,6 +1049,21 @@ extern "C" int snk_stem_conv_bn_relu_f32(const float *d_x, const float *d_w, con
     if (lds <= 64 * 1024 && !stem_valu) k_stem_conv_mfma<false><<<min(n_images, stem_grid), 256, lds, (hipStream_t)stream>>>(a);
     else if (lds <= 64 * 1024) k_stem_conv_img<false><<<min(n_images, 768), 256, lds, (hipStream_t)stream>>>(a);
     else k_stem_conv<<<(int)((M + ST_PX - 1) / ST_PX), 256, 0, (hipStream_t)stream>>>(a);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// the bare stem convolution (training step: the batch statistics of its output come first, train.hip)
+extern "C" int snk_stem_conv_f32(const float *d_x, const float *d_w, float *d_out, int n_images, int height, int width, void *stream)
+{
+    SNK_REQUIRE(d_x && d_w && d_out, "snk_stem_conv_f32: NULL argument");
+    if (n_images <= 0) return 0;
+    const long M = (long)n_images * height * width;
+    SNK_REQUIRE(M < (1l << 31), "snk_stem_conv_f32: batch too large");
+    const size_t lds = (size_t)(height + 2) * (width + 2) * 3 * sizeof(float);
+    SNK_REQUIRE(lds <= 64 * 1024, "snk_stem_conv_f32: observation %d x %d too large", height, width);
+    StemArgs a = {d_x, d_w, nullptr, nullptr, d_out, (int)M, height, width, 1};
+    k_stem_conv_mfma<false><<<min(n_images, 512), 256, lds, (hipStream_t)stream>>>(a);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -243,6 +243,35 @@ extern "C" int snk_bn_train_grad_sums(const float *d_dout, const float *d_out, c
     return 0;
 }
 
+// the same sums kept in float64 (the manual training step, snake_engine/train_step.py: the ranks all-reduce float64 sums)
+__global__ __launch_bounds__(TR_THREADS) void k_bn_fold_f64(const float *__restrict__ part, int n_blocks, double *__restrict__ out)
+{
+    const int col = threadIdx.x;                   // 2 * TR_C threads
+    double acc = 0.0;
+    int b = 0;
+    for (; b + 8 <= n_blocks; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + u) * (2 * TR_C) + col];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (double)v[u];
+    }
+    for (; b < n_blocks; ++b) acc += (double)part[(size_t)b * (2 * TR_C) + col];
+    out[col] = acc;
+}
+
+extern "C" int snk_bn_train_grad_sums_f64(const float *d_dout, const float *d_out, const float *d_y, const float *d_mean,
+                                          const float *d_inv, long rows, int relu, float *d_partials, double *d_sums, void *stream)
+{
+    SNK_REQUIRE(d_dout && d_y && d_mean && d_inv && d_partials && d_sums && rows > 0 && (!relu || d_out),
+                "snk_bn_train_grad_sums_f64: bad argument");
+    const int grid = tr_grid(rows);
+    k_bn_grad_sums<<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_dout, d_out, d_y, d_mean, d_inv, rows, relu, d_partials);
+    k_bn_fold_f64<<<1, 2 * TR_C, 0, (hipStream_t)stream>>>(d_partials, grid, d_sums);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" int snk_bn_train_grad_apply(const float *d_dout, const float *d_out, const float *d_y, const float *d_mean,
                                        const float *d_inv, const float *d_a, const float *d_b, const float *d_c, float *d_dx,
                                        float *d_g, long rows, int relu, float *d_partials, float *d_dx_scale_tail, void *stream)

@@ -1,6 +1,8 @@
 """Training half of AlphaNNet (reference: AlphaNNet.train / copy_and_compile, alpha_nnet.py:58-59, 78-106) --
-SURVEY.md section 8 row f-1 ("next").  Plain PyTorch (autograd, MIOpen convolutions on the GPU): this is the
-caller-side fit step that consumes the self-play samples, not part of the HIP hot path.
+SURVEY.md section 8 row f-1.  On the GPU a step is sequenced by hand on this library's kernels
+(snake_engine/train_step.py: convolutions, batch norms, head, Adam -- no autograd graph, no library convolution);
+the autograd restatement `_Net` below is the float64 / CPU cross-check of the same formulas (tests/test_trainer_cpu.py)
+and the `SNK_TRAIN_CONV=torch` A/B arm (every operator from PyTorch / MIOpen).
 
 Keras 2.x / TF 2.1 semantics restated (the formulas, not the code; tests/test_trainer_cpu.py cross-checks them against
 an independent float64 NumPy restatement with a hand-written backward pass):
@@ -28,7 +30,11 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-_NATIVE_CONV = os.environ.get("SNK_TRAIN_CONV", "native") != "torch"      # `torch`: every convolution through the library (A/B runs)
+_NATIVE = os.environ.get("SNK_TRAIN_CONV", "native") != "torch"           # `torch`: every operator through PyTorch / MIOpen (A/B runs)
+# steps at learning rate 0 (alpha_nnet.py:79-84: all after the 100th) cannot move a weight; Adam's moments die with the
+# optimizer (copy_and_compile re-creates it): only the forward half -- the batch-norm moving averages -- is run for them.
+# `full` runs the dead backward passes anyway (the equivalence test, A/B timing)
+_DEAD_STEPS_FULL = os.environ.get("SNK_TRAIN_DEAD_STEPS", "skip") == "full"
 
 BN_EPS, BN_MOMENTUM, L2_C = 1e-3, 0.99, 1e-5
 ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-7
@@ -114,29 +120,14 @@ class _Net:
     def _conv_bn(self, x, i, train, residual=None, relu=True):
         """act(batch_norm(conv(x)) (+ residual)), act = ReLU (every layer of the graph has one after its batch norm)"""
         k = self.t[i]
-        if _NATIVE_CONV and x.is_cuda:                       # the tower layers: forward and input gradient on k_conv3x3_f16s
-            from snake_engine import train_ops
-            y = train_ops.SplitConv3x3.apply(x, k) if train_ops.usable(x, k) else None
-        else:
-            y = None
-        if y is None:
-            y = F.conv2d(x, k.permute(3, 2, 0, 1), padding=k.shape[0] // 2)
+        y = F.conv2d(x, k.permute(3, 2, 0, 1), padding=k.shape[0] // 2)
         g, b, mean, var = self.t[i + 1:i + 5]
         if train:
-            fused = False
-            if _NATIVE_CONV and y.is_cuda:                   # batch norm + residual + ReLU on the kernels of csrc/train.hip
-                from snake_engine import train_ops
-                fused = train_ops.bn_usable(y)
-            if fused:
-                out, m, v, n = train_ops.FusedBatchNormAct.apply(y, g, b, residual, relu, _dist())
-            else:
-                out, m, v, n = _SyncBatchNormTrain.apply(y, g, b)
+            out, m, v, n = _SyncBatchNormTrain.apply(y, g, b)
             with torch.no_grad():
                 unbiased = v * (n / (n - 1.0).clamp_min(1.0))
                 mean.mul_(BN_MOMENTUM).add_(m * (1 - BN_MOMENTUM))
                 var.mul_(BN_MOMENTUM).add_(unbiased * (1 - BN_MOMENTUM))
-            if fused:
-                return out
         else:
             out = (y - mean[None, :, None, None]) * (g / torch.sqrt(var + BN_EPS))[None, :, None, None] + b[None, :, None, None]
         if residual is not None:
@@ -198,7 +189,7 @@ def fit(weights, input_shape, X, Y, epochs=32, batch_size=2048, lr_schedule=None
     rank = dist.get_rank() if dist is not None else 0
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
-    net = _Net(weights, device, dtype)        # float64 only for the cross-checks in tests/test_trainer_cpu.py
+    device = torch.device(device)
     Xd = torch.as_tensor(np.ascontiguousarray(X), dtype=dtype, device=device)
     Yd = torch.as_tensor(np.ascontiguousarray(Y), dtype=dtype, device=device)
     n = Xd.shape[0]
@@ -209,28 +200,49 @@ def fit(weights, input_shape, X, Y, epochs=32, batch_size=2048, lr_schedule=None
         seed = int(s.item())
     gen = torch.Generator(device="cpu")
     gen.manual_seed(seed)
-    params = net.params()
-    opt = KerasAdam(params)
+    native = None
+    if _NATIVE and device.type == "cuda" and dtype == torch.float32:
+        from snake_engine import train_step
+        if train_step.supported(input_shape):
+            native = train_step.TrainStep(weights, input_shape, -(-min(batch_size, n) // world), device, dist)
+    if native is None:
+        net = _Net(weights, device, dtype)        # float64 only for the cross-checks in tests/test_trainer_cpu.py
+        params = net.params()
+        opt = KerasAdam(params)
     step = 0
     history = []
+    fit.last_mode = "kernels" if native is not None else "autograd"
     for ep in range(epochs):
         perm = (torch.randperm(n, generator=gen) if shuffle else torch.arange(n)).to(device)
-        tot, cnt = 0.0, 0
+        tot = torch.zeros((), dtype=torch.float64, device=device)      # the epoch's loss stays on the device: one read per epoch
+        cnt = 0
         for s0 in range(0, n, batch_size):
             idx_all = perm[s0:s0 + batch_size]
             idx = idx_all[rank::world]
-            pred = net.forward(Xd[idx], True)
-            # this rank's share of the global batch loss; summed over ranks it is mse + l2 of the whole batch
-            loss = ((pred - Yd[idx]) ** 2).sum() / (3.0 * len(idx_all)) + net.l2() / world
-            grads = torch.autograd.grad(loss, params)
-            flat = torch.cat([g.reshape(-1) for g in grads] + [loss.detach().reshape(1)])
-            if dist is not None:
-                dist.all_reduce(flat)            # one bucket: every gradient + the loss value
-            opt.step(flat[:-1], lr_at(step, lr_schedule))
+            lr = lr_at(step, lr_schedule)
+            if native is not None:
+                if len(idx) == 0:
+                    raise RuntimeError(f"fit: a batch of {len(idx_all)} rows leaves rank {rank} of {world} without a row")
+                xb, yb = Xd[idx].contiguous(), Yd[idx].contiguous()
+                if lr == 0.0 and not _DEAD_STEPS_FULL:
+                    loss2 = native.forward_only(xb, yb, len(idx_all))
+                else:
+                    loss2 = native.step(xb, yb, len(idx_all), lr)
+                tot += loss2.sum().double() * len(idx_all)
+            else:
+                pred = net.forward(Xd[idx], True)
+                # this rank's share of the global batch loss; summed over ranks it is mse + l2 of the whole batch
+                loss = ((pred - Yd[idx]) ** 2).sum() / (3.0 * len(idx_all)) + net.l2() / world
+                grads = torch.autograd.grad(loss, params)
+                flat = torch.cat([g.reshape(-1) for g in grads] + [loss.detach().reshape(1)])
+                if dist is not None:
+                    dist.all_reduce(flat)            # one bucket: every gradient + the loss value
+                opt.step(flat[:-1], lr)
+                tot += flat[-1].double() * len(idx_all)
             step += 1
-            tot += float(flat[-1].item()) * len(idx_all); cnt += len(idx_all)
-        history.append(tot / max(1, cnt))
+            cnt += len(idx_all)
+        history.append(float(tot.item()) / max(1, cnt))
         if verbose and rank == 0:
             print(f"Epoch {ep + 1}/{epochs} - loss: {history[-1]:.6f}")
     fit.last_history = history
-    return net.weights()
+    return native.weights() if native is not None else net.weights()

@@ -1,5 +1,9 @@
-"""snake_engine.train_ops.SplitConv3x3 (the tower convolution of the training half on k_conv3x3_f16s, SURVEY.md section 8
-row f-1) against float64 torch convolutions: forward, input gradient, weight gradient; float32-grade tolerances."""
+"""The training step on this library's kernels (snake_engine/train_step.py) against float64
+PyTorch expressions of the same formulas (test infrastructure: autograd in float64 is the checker, never the product):
+the three passes of the tower convolution, the stem convolution and its weight gradient, the batch-norm kernels (also on
+channels whose mean is a hundred standard deviations from zero), the head, Adam, and one whole step -- every parameter
+gradient to 1e-4 of its largest entry once the ReLU masks of the float64 run are imposed on the float32 run (a mask that
+flips on round-off changes a gradient by far more than round-off; with equal masks the step is a smooth function)."""
 import numpy as np
 import pytest
 
@@ -13,47 +17,283 @@ def torch_gpu():
     return torch
 
 
+def rel(a, b):
+    return float((a.detach().double() - b.detach().double()).abs().max() / (b.detach().double().abs().max() + 1e-300))
+
+
+def _tail_of(torch, L, x):
+    """{., ., scale, 1 / scale} of a tensor, as the element-wise kernels leave it for the convolution that reads it"""
+    from snake_engine.net import F16S_TAIL_OFFSET, F16S_WEIGHT_BYTES
+    from snake_engine._lib import check
+    image = torch.empty(F16S_WEIGHT_BYTES, dtype=torch.uint8, device="cuda")
+    part = torch.empty(L.snk_bn_train_partials(), device="cuda")
+    check(L.snk_conv3x3_f16s_input_scale(x.data_ptr(), x.numel(), image.data_ptr(), part.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    return image[F16S_TAIL_OFFSET:F16S_TAIL_OFFSET + 16].view(torch.float32).clone()
+
+
 @pytest.mark.parametrize("n,hw,xmag,gmag", [(64, 21, 1.0, 1.0), (48, 21, 30.0, 1e-6), (5, 13, 1e-3, 50.0), (3, 37, 1.0, 1e-4)])
-def test_split_conv3x3_forward_and_gradients_match_float64(torch_gpu, n, hw, xmag, gmag):
+def test_tower_convolution_three_passes_match_float64(torch_gpu, n, hw, xmag, gmag):
+    """forward and input gradient on k_conv3x3_f16s (snk_conv3x3_prepare_weights_f16s_train: the mirrored kernel is laid out by
+    the library), weight gradient on k_wgrad_f16s, with the power-of-two scales taken from the data on the device"""
     torch = torch_gpu
     import torch.nn.functional as F
-    from snake_engine import train_ops
+    from snake_engine._lib import lib, check
+    from snake_engine.net import F16S_WEIGHT_BYTES
+    L, st = lib(), torch.cuda.current_stream().cuda_stream
     g = torch.Generator(device="cuda").manual_seed(n)
-    x = (torch.randn(n, hw, hw, 128, device="cuda", generator=g) * xmag).permute(0, 3, 1, 2).requires_grad_(True)   # channels-last
-    k = (torch.randn(3, 3, 128, 128, device="cuda", generator=g) * 0.05).requires_grad_(True)
-    dy = torch.randn(n, hw, hw, 128, device="cuda", generator=g).permute(0, 3, 1, 2) * gmag
-    dy = dy * (torch.rand(n, 1, hw, hw, device="cuda", generator=g) ** 6)            # a wide spread of magnitudes, as real gradients have
-    assert train_ops.usable(x, k)
-    y = train_ops.SplitConv3x3.apply(x, k)
-    dx, dk = torch.autograd.grad(y, (x, k), dy)
-    x64, k64 = x.detach().double().requires_grad_(True), k.detach().double().requires_grad_(True)
+    x = torch.randn(n, hw, hw, 128, device="cuda", generator=g) * xmag
+    k = torch.randn(3, 3, 128, 128, device="cuda", generator=g) * 0.05
+    dy = torch.randn(n, hw, hw, 128, device="cuda", generator=g) * gmag
+    dy = (dy * (torch.rand(n, hw, hw, 1, device="cuda", generator=g) ** 6)).contiguous()    # a wide spread of magnitudes, as real gradients have
+    ones, zeros = torch.ones(128, device="cuda"), torch.zeros(128, device="cuda")
+    image = torch.empty(F16S_WEIGHT_BYTES, dtype=torch.uint8, device="cuda")
+    tx, tdy = _tail_of(torch, L, x), _tail_of(torch, L, dy)
+    y, dx = torch.empty_like(x), torch.empty_like(x)
+    check(L.snk_conv3x3_prepare_weights_f16s_train(k.data_ptr(), image.data_ptr(), tx.data_ptr(), 0, st))
+    check(L.snk_conv3x3_bn_f16s(x.data_ptr(), image.data_ptr(), ones.data_ptr(), zeros.data_ptr(), None, y.data_ptr(), n, hw, hw, 0, st))
+    check(L.snk_conv3x3_prepare_weights_f16s_train(k.data_ptr(), image.data_ptr(), tdy.data_ptr(), 1, st))
+    check(L.snk_conv3x3_bn_f16s(dy.data_ptr(), image.data_ptr(), ones.data_ptr(), zeros.data_ptr(), None, dx.data_ptr(), n, hw, hw, 0, st))
+    need = L.snk_conv3x3_wgrad_partials(hw, hw)
+    assert need > 0, "every square observation the engine supports has a weight-gradient kernel"
+    part = torch.empty(need, device="cuda")
+    dk = torch.empty(3, 3, 128, 128, device="cuda")
+    check(L.snk_conv3x3_wgrad_f16s(x.data_ptr(), dy.data_ptr(), tx.data_ptr(), tdy.data_ptr(), part.data_ptr(), dk.data_ptr(), n, hw, hw, st))
+    torch.cuda.synchronize()
+
+    x64 = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    k64 = k.double().requires_grad_(True)
     y64 = F.conv2d(x64, k64.permute(3, 2, 0, 1), padding=1)
-    dx64, dk64 = torch.autograd.grad(y64, (x64, k64), dy.double())
-
-    def rel(a, b):
-        return float((a.detach().double() - b.detach()).abs().max() / b.detach().abs().max())
-    assert y.shape == y64.shape and y.is_contiguous(memory_format=torch.channels_last)
-    assert rel(y, y64) < 2e-6, rel(y, y64)
-    assert rel(dx, dx64) < 2e-6, rel(dx, dx64)
-    assert rel(dk, dk64) < 2e-5, rel(dk, dk64)                      # the library's float32 weight gradient (a sum over n*h*w terms)
-    # the float32 library convolution is no closer to float64 than the split-f16 kernel
-    y32 = F.conv2d(x.detach(), k.detach().permute(3, 2, 0, 1), padding=1)
-    assert rel(y, y64) <= 4 * rel(y32, y64) + 1e-7
+    dx64, dk64 = torch.autograd.grad(y64, (x64, k64), dy.double().permute(0, 3, 1, 2))
+    assert rel(y, y64.permute(0, 2, 3, 1)) < 2e-6
+    assert rel(dx, dx64.permute(0, 2, 3, 1)) < 2e-6
+    assert rel(dk, dk64) < 3e-6, rel(dk, dk64)
+    y32 = F.conv2d(x.permute(0, 3, 1, 2), k.permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1)
+    assert rel(y, y64.permute(0, 2, 3, 1)) <= 4 * rel(y32, y64.permute(0, 2, 3, 1)) + 1e-7      # no further from float64 than the library's float32
 
 
-def test_zero_input_and_unusable_shapes(torch_gpu):
+@pytest.mark.parametrize("n,hw", [(70, 21), (9, 13), (5, 37)])
+def test_stem_convolution_and_its_weight_gradient_match_float64(torch_gpu, n, hw):
     torch = torch_gpu
-    from snake_engine import train_ops
-    x = torch.zeros(4, 128, 21, 21, device="cuda").contiguous(memory_format=torch.channels_last)
-    k = torch.randn(3, 3, 128, 128, device="cuda")
-    assert float(train_ops.SplitConv3x3.apply(x, k).abs().max()) == 0.0
-    assert not train_ops.usable(x, torch.randn(3, 3, 3, 128, device="cuda"))          # the stem
-    assert not train_ops.usable(x.double(), k.double()) and not train_ops.usable(x.cpu(), k.cpu())
+    import torch.nn.functional as F
+    from snake_engine._lib import lib, check
+    L, st = lib(), torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(n)
+    x = torch.rand(n, hw, hw, 3, device="cuda", generator=g) * 2 - 0.5
+    k = torch.randn(3, 3, 3, 128, device="cuda", generator=g) * 0.2
+    dy = (torch.randn(n, hw, hw, 128, device="cuda", generator=g) * (torch.rand(n, hw, hw, 1, device="cuda", generator=g) ** 4)).contiguous()
+    y = torch.empty(n, hw, hw, 128, device="cuda")
+    check(L.snk_stem_conv_f32(x.data_ptr(), k.data_ptr(), y.data_ptr(), n, hw, hw, st))
+    part = torch.empty(L.snk_stem_wgrad_partials(n, hw, hw), device="cuda")
+    dk = torch.full((3, 3, 3, 128), 7.0, device="cuda")
+    check(L.snk_stem_wgrad_f32(x.data_ptr(), dy.data_ptr(), part.data_ptr(), dk.data_ptr(), n, hw, hw, st))
+    x64, k64 = x.double().permute(0, 3, 1, 2), k.double().requires_grad_(True)
+    y64 = F.conv2d(x64, k64.permute(3, 2, 0, 1), padding=1)
+    dk64, = torch.autograd.grad(y64, (k64,), dy.double().permute(0, 3, 1, 2))
+    assert rel(y, y64.permute(0, 2, 3, 1)) < 2e-6
+    assert rel(dk, dk64) < 3e-6, rel(dk, dk64)
 
 
-def test_fit_with_native_convolutions_tracks_fit_with_library_convolutions(torch_gpu):
-    """utils.trainer_torch.fit on the same rows and shuffle order with the tower convolutions on k_conv3x3_f16s and with
-    every convolution through the library.  Adam's first steps move every weight by about lr * sign(gradient), so weights
+@pytest.mark.parametrize("with_res,n,mean,std", [(False, 33, 0.7, 3.0), (True, 64, 0.7, 3.0), (False, 40, 50.0, 0.5), (True, 17, -300.0, 2.0)])
+def test_batch_norm_kernels_match_float64(torch_gpu, with_res, n, mean, std):
+    """sums (centred on the moving mean, float64) -> finalize -> apply, and the way back, against float64 autograd; the
+    channels of the third and fourth case sit 100 / 150 standard deviations from zero, where E[x^2] - mean^2 in float32
+    loses every digit of the variance"""
+    torch = torch_gpu
+    from snake_engine._lib import lib, check
+    L, st = lib(), torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(7 + n)
+    hw, C = 21, 128
+    rows = n * hw * hw
+    chan_mean = mean * (1.0 + 0.1 * torch.randn(C, device="cuda", generator=g))
+    y = (torch.randn(rows, C, device="cuda", generator=g) * std + chan_mean).contiguous()
+    gamma = torch.rand(C, device="cuda", generator=g) + 0.5
+    beta = torch.randn(C, device="cuda", generator=g) * 0.3
+    res = torch.randn(rows, C, device="cuda", generator=g) if with_res else None
+    dout = torch.randn(rows, C, device="cuda", generator=g)
+    mm = (chan_mean + 0.3 * std * torch.randn(C, device="cuda", generator=g)).contiguous()      # a moving mean near the batch mean
+    mv = torch.ones(C, device="cuda")
+    mm0, mv0 = mm.clone(), mv.clone()
+    f = lambda k, dt=torch.float32: torch.empty(k, dtype=dt, device="cuda")
+    part, sums = f(L.snk_bn_train_partials()), f(2 * C, torch.float64)
+    m_, inv, sc, sh, tail = f(C), f(C), f(C), f(C), f(4)
+    out = torch.empty_like(y)
+    check(L.snk_bn_train_sums_f64(y.data_ptr(), rows, mm.data_ptr(), part.data_ptr(), sums.data_ptr(), st))
+    check(L.snk_bn_train_finalize(sums.data_ptr(), float(rows), mm.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), mv.data_ptr(),
+                                  0.99, 1e-3, m_.data_ptr(), inv.data_ptr(), sc.data_ptr(), sh.data_ptr(), C, st))
+    check(L.snk_bn_train_apply(y.data_ptr(), sc.data_ptr(), sh.data_ptr(), res.data_ptr() if with_res else None, out.data_ptr(), rows, 1,
+                               part.data_ptr(), tail.data_ptr(), st))
+    a, b, c, dg, db = f(C), f(C), f(C), f(C), f(C)
+    dx, gres = torch.empty_like(y), torch.empty_like(y)
+    check(L.snk_bn_train_grad_sums_f64(dout.data_ptr(), out.data_ptr(), y.data_ptr(), m_.data_ptr(), inv.data_ptr(), rows, 1, part.data_ptr(),
+                                       sums.data_ptr(), st))
+    check(L.snk_bn_train_grad_finalize(sums.data_ptr(), sums.data_ptr(), float(rows), gamma.data_ptr(), inv.data_ptr(), a.data_ptr(),
+                                       b.data_ptr(), c.data_ptr(), dg.data_ptr(), db.data_ptr(), C, st))
+    check(L.snk_bn_train_grad_apply(dout.data_ptr(), out.data_ptr(), y.data_ptr(), m_.data_ptr(), inv.data_ptr(), a.data_ptr(), b.data_ptr(),
+                                    c.data_ptr(), dx.data_ptr(), gres.data_ptr() if with_res else None, rows, 1, part.data_ptr(), tail.data_ptr(), st))
+
+    y64, g64, b64 = (t.double().requires_grad_(True) for t in (y, gamma, beta))
+    r64 = res.double().requires_grad_(True) if with_res else None
+    m64, v64 = y64.mean(dim=0), y64.var(dim=0, unbiased=False)
+    z = (y64 - m64) / torch.sqrt(v64 + 1e-3) * g64 + b64
+    if with_res:
+        z = z + r64
+    o64 = torch.relu(z)
+    # the float32 run's mask (out > 0) is imposed on the float64 gradient: identical functions are differentiated
+    ins64 = (y64, g64, b64) + ((r64,) if with_res else ())
+    grads64 = torch.autograd.grad(z, ins64, dout.double() * (out > 0).double())
+    assert float((m_.double() - m64).abs().max()) < 1e-6 * max(1.0, abs(mean))
+    assert float(((1.0 / inv.double() ** 2 - 1e-3) - v64).abs().max() / v64.max()) < 2e-5
+    assert float((out.double() - o64).abs().max()) < 3e-5 * max(1.0, abs(mean) / std / 20)
+    tol = 2e-5 * max(1.0, abs(mean) / std / 20)            # xhat = (y - mean) inv in float32: the mean's rounding error counts in units of std
+    assert rel(dx, grads64[0]) < tol and rel(dg, grads64[1]) < tol and rel(db, grads64[2]) < tol
+    if with_res:
+        assert rel(gres, grads64[3]) < 1e-6
+    unb = v64 * rows / (rows - 1)
+    assert float((mm.double() - (mm0.double() * 0.99 + m64 * 0.01)).abs().max()) < 1e-5 * max(1.0, abs(mean))
+    assert float((mv.double() - (mv0.double() * 0.99 + unb * 0.01)).abs().max()) < 1e-6 * float(unb.max() + 1)
+    amax = float(out.abs().max())
+    assert 2048.0 <= amax * float(tail[2]) < 4096.0 and float(tail[2] * tail[3]) == 1.0
+
+
+def _net64(torch, ws, X, Y):
+    """float64 autograd restatement of the graph on the GPU, returning loss (without the regularizer), the per-tensor
+    gradients and the ReLU inputs of every layer"""
+    import torch.nn.functional as F
+    t = [torch.tensor(np.asarray(w), dtype=torch.float64, device="cuda") for w in ws]
+    blocks = (len(ws) - 14) // 10
+    n_conv = 2 + 2 * blocks
+    pidx = []
+    for l in range(n_conv):
+        pidx += [5 * l, 5 * l + 1, 5 * l + 2]
+    i = 5 * n_conv
+    pidx += [i, i + 1, i + 2, i + 3]
+    for j in pidx:
+        t[j].requires_grad_(True)
+    pre = {}
+
+    def cbr(x, l, res=None):
+        k = t[5 * l]
+        y = F.conv2d(x, k.permute(3, 2, 0, 1), padding=k.shape[0] // 2)
+        m, v = y.mean(dim=(0, 2, 3)), y.var(dim=(0, 2, 3), unbiased=False)
+        z = (y - m[None, :, None, None]) / torch.sqrt(v[None, :, None, None] + 1e-3) * t[5 * l + 1][None, :, None, None] + t[5 * l + 2][None, :, None, None]
+        if res is not None:
+            z = z + res
+        pre[l] = z
+        return torch.relu(z)
+    x = torch.as_tensor(X, dtype=torch.float64, device="cuda").permute(0, 3, 1, 2)
+    h = cbr(x, 0)
+    for b in range(blocks):
+        sc = h
+        h = cbr(h, 2 * b + 1)
+        h = cbr(h, 2 * b + 2, sc)
+    h = cbr(h, n_conv - 1)
+    flat = h.permute(0, 2, 3, 1).reshape(h.shape[0], -1)
+    a1 = flat @ t[i] + t[i + 1]
+    pre["d1"] = a1
+    q = torch.tanh(torch.relu(a1) @ t[i + 2] + t[i + 3])
+    y = torch.as_tensor(Y, dtype=torch.float64, device="cuda")
+    loss = ((q - y) ** 2).sum() / (3.0 * len(X))
+    grads = torch.autograd.grad(loss, [t[j] for j in pidx])
+    return float(loss), dict(zip(pidx, grads)), pre, q.detach(), n_conv
+
+
+@pytest.mark.parametrize("n,blocks", [(40, 2), (23, 4)])
+def test_one_whole_step_matches_float64_with_the_same_relu_masks(torch_gpu, n, blocks):
+    torch = torch_gpu
+    from snake_engine import net
+    from snake_engine.train_step import TrainStep
+    rs = np.random.RandomState(5 + n)
+    X = rs.rand(n, 21, 21, 3).astype(np.float32)
+    Y = np.tanh(rs.randn(n, 3)).astype(np.float32)
+    ws = net.glorot_uniform_weights((21, 21, 3), blocks=blocks, seed=9)
+    for l in range(2 + 2 * blocks):                         # batch-norm parameters away from their initial 1 / 0
+        ws[5 * l + 1] = (ws[5 * l + 1] * (0.6 + 0.8 * rs.rand(*ws[5 * l + 1].shape))).astype(np.float32)
+        ws[5 * l + 2] = (0.2 * rs.randn(*ws[5 * l + 2].shape)).astype(np.float32)
+    loss64, g64, pre, q64, n_conv = _net64(torch, ws, X, Y)
+    ts = TrainStep(ws, (21, 21, 3), n, "cuda")
+    x, y = torch.as_tensor(X, device="cuda"), torch.as_tensor(Y, device="cuda")
+    q = ts.forward(x, y, n)
+    assert float((q.double() - q64).abs().max()) < 1e-5
+    assert abs(float(ts.G[ts.n_params]) - loss64) < 1e-5 * loss64
+    sign = lambda z: torch.where(z > 0, 1.0, -1.0).float().contiguous()
+    for l in range(n_conv - 1):                             # the 128-channel layers: [n, C, h, w] float64 -> channels-last rows
+        ts.mask_override[l] = sign(pre[l].permute(0, 2, 3, 1)).reshape(-1)
+    ts.mask_override["h"] = sign(pre[n_conv - 1].permute(0, 2, 3, 1)).reshape(-1)
+    ts.mask_override["d1"] = sign(pre["d1"]).reshape(-1)
+    ts.backward(y, n)
+    got = ts.gradients()
+    worst = {}
+    for j, ref in g64.items():
+        worst[j] = float((torch.as_tensor(got[j], device="cuda").double() - ref).abs().max() / (ref.abs().max() + 1e-300))
+    assert max(worst.values()) < 1e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    # without the imposed masks the step still agrees to what flipped masks allow
+    ts.mask_override.clear()
+    ts.forward(x, y, n)
+    ts.backward(y, n)
+    got = ts.gradients()
+    loose = max(float((torch.as_tensor(got[j], device="cuda").double() - ref).abs().max() / (ref.abs().max() + 1e-300)) for j, ref in g64.items())
+    assert loose < 5e-2, loose
+
+
+def test_adam_l2_and_loss_follow_the_keras_formulas(torch_gpu):
+    """three steps of TrainStep.step against the float64 formulas (oracle/train_ref.py::KerasAdamRef on the float64 gradients
+    of the same batch is covered on the CPU; here: the flat-buffer kernel itself on given gradients)"""
+    torch = torch_gpu
+    from snake_engine._lib import lib, check
+    L, st = lib(), torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(3)
+    n = 100_003
+    w = torch.randn(n, device="cuda", generator=g)
+    decay = (torch.rand(n, device="cuda", generator=g) < 0.7).to(torch.uint8)
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    w64, m64, v64 = w.double(), m.double(), v.double()
+    part, l2 = torch.empty(512, device="cuda"), torch.empty(1, device="cuda")
+    for t in range(1, 4):
+        grad = torch.randn(n, device="cuda", generator=g) * 10.0 ** (-t)
+        lr = 1e-3 / t
+        check(L.snk_l2_sum(w.data_ptr(), decay.data_ptr(), n, 1e-5, part.data_ptr(), l2.data_ptr(), st))
+        assert abs(float(l2) - 1e-5 * float((w64 ** 2 * decay.double()).sum())) < 1e-6 * float(l2)
+        lr_t = lr * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        check(L.snk_adam_l2_step(w.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), decay.data_ptr(), n, lr_t, 0.9, 0.999, 1e-7, 1e-5, st))
+        g64 = grad.double() + 2e-5 * w64 * decay.double()
+        m64 = 0.9 * m64 + 0.1 * g64
+        v64 = 0.999 * v64 + 0.001 * g64 * g64
+        w64 = w64 - lr_t * m64 / (v64.sqrt() + 1e-7)
+        assert float((w.double() - w64).abs().max()) < 2e-6
+        assert rel(m, m64) < 1e-6 and rel(v, v64) < 1e-6
+    frozen = w.clone()
+    check(L.snk_adam_l2_step(w.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), decay.data_ptr(), n, 0.0, 0.9, 0.999, 1e-7, 1e-5, st))
+    assert torch.equal(w, frozen)                           # learning rate 0 leaves every bit of every weight
+
+
+def test_steps_at_learning_rate_zero_are_forward_only_and_change_nothing_else(torch_gpu, monkeypatch):
+    """alpha_nnet.py:79-84: the rate is 0 after optimizer step 100 -- 220 of a generation's 320 steps.  With the dead backward
+    passes skipped, the weights AND the batch-norm moving averages after the fit are bit-identical to the full path's."""
+    torch = torch_gpu
+    from snake_engine import net
+    from utils import trainer_torch
+    rs = np.random.RandomState(3)
+    X = rs.rand(96, 21, 21, 3).astype(np.float32)
+    Y = np.tanh(rs.randn(96, 3)).astype(np.float32)
+    ws = net.glorot_uniform_weights((21, 21, 3), blocks=2, seed=5)
+    sched = ([2, 4], [1e-3, 2.5e-4, 0.0])                   # 3 epochs x 3 batches = 9 steps, the last 4 at rate 0
+    outs = {}
+    for full in (False, True):
+        monkeypatch.setattr(trainer_torch, "_DEAD_STEPS_FULL", full)
+        outs[full] = trainer_torch.fit(ws, (21, 21, 3), X, Y, 3, 32, sched, seed=11, verbose=False)
+        assert trainer_torch.fit.last_mode == "kernels"
+        hist = list(trainer_torch.fit.last_history)
+        outs[full] = (outs[full], hist)
+    (wa, ha), (wb, hb) = outs[False], outs[True]
+    assert all(np.array_equal(a, b) for a, b in zip(wa, wb))
+    assert ha == hb and ha[2] < ha[0]
+    moved = [float(np.abs(a - np.asarray(b)).max()) for a, b in zip(wa, ws)]
+    assert min(moved[j] for j in (3, 4)) > 0                # moving statistics did move
+
+
+def test_fit_on_the_kernels_tracks_fit_with_library_operators(torch_gpu):
+    """utils.trainer_torch.fit on the same rows and shuffle order on this library's kernels and with every operator from
+    PyTorch / MIOpen (SNK_TRAIN_CONV=torch).  Adam's first steps move every weight by about lr * sign(gradient), so weights
     whose gradient is near zero may part by 2 lr between two float32 implementations: what has to agree is the loss of
     every epoch and what the trained nets predict"""
     import os
@@ -71,7 +311,7 @@ X = rs.rand(512, 21, 21, 3).astype(np.float32); Y = np.tanh(rs.randn(512, 3)).as
 ws = net.glorot_uniform_weights((21, 21, 3), blocks=4, seed=5)
 out = trainer_torch.fit(ws, (21, 21, 3), X, Y, 3, 128, ([4, 8], [1e-3, 2.5e-4, 0.0]), seed=11, verbose=False)
 q = trainer_torch._Net(out, torch.device("cuda")).forward(torch.as_tensor(X[:96], device="cuda"), False).detach().cpu().numpy()
-np.savez(sys.argv[1], hist=np.array(trainer_torch.fit.last_history), q=q)
+np.savez(sys.argv[1], hist=np.array(trainer_torch.fit.last_history), q=q, mode=trainer_torch.fit.last_mode)
 ''' % (REPO, REPO)
     res = {}
     with tempfile.TemporaryDirectory() as d:
@@ -81,82 +321,9 @@ np.savez(sys.argv[1], hist=np.array(trainer_torch.fit.last_history), q=q)
                                text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]
             z = np.load(path)
-            res[mode] = (z["hist"], z["q"])
-    (h_a, q_a), (h_b, q_b) = res["native"], res["torch"]
+            res[mode] = (z["hist"], z["q"], str(z["mode"]))
+    (h_a, q_a, m_a), (h_b, q_b, m_b) = res["native"], res["torch"]
+    assert (m_a, m_b) == ("kernels", "autograd")
     assert len(h_a) == 3 and h_a[2] < h_a[0]                                    # it trains
     assert np.abs(h_a - h_b).max() / np.abs(h_b).max() < 1e-2, (h_a, h_b)
     assert np.abs(q_a - q_b).max() < 5e-2 and np.abs(q_a - q_b).mean() < 5e-3, (np.abs(q_a - q_b).max(), np.abs(q_a - q_b).mean())
-
-
-@pytest.mark.parametrize("with_res,n", [(False, 33), (True, 64)])
-def test_fused_batch_norm_act_matches_float64(torch_gpu, with_res, n):
-    """snake_engine.train_ops.FusedBatchNormAct (csrc/train.hip) against the same expression in float64 autograd:
-    output, batch statistics, and the gradients with respect to the input, gamma, beta and the residual"""
-    torch = torch_gpu
-    from snake_engine import train_ops
-    g = torch.Generator(device="cuda").manual_seed(7 + n)
-    hw = 21
-    y = (torch.randn(n, hw, hw, 128, device="cuda", generator=g) * 3.0 + 0.7).permute(0, 3, 1, 2).requires_grad_(True)
-    gamma = (torch.rand(128, device="cuda", generator=g) + 0.5).requires_grad_(True)
-    beta = (torch.randn(128, device="cuda", generator=g) * 0.3).requires_grad_(True)
-    res = torch.randn(n, hw, hw, 128, device="cuda", generator=g).permute(0, 3, 1, 2).requires_grad_(True) if with_res else None
-    dout = torch.randn(n, hw, hw, 128, device="cuda", generator=g).permute(0, 3, 1, 2)
-    assert train_ops.bn_usable(y)
-    out, mean, var, cnt = train_ops.FusedBatchNormAct.apply(y, gamma, beta, res, True, None)
-    ins = (y, gamma, beta) + ((res,) if with_res else ())
-    grads = torch.autograd.grad(out, ins, dout)
-
-    y64, g64, b64 = (t.detach().double().requires_grad_(True) for t in (y, gamma, beta))
-    r64 = res.detach().double().requires_grad_(True) if with_res else None
-    m64 = y64.mean(dim=(0, 2, 3))
-    v64 = y64.var(dim=(0, 2, 3), unbiased=False)
-    z = (y64 - m64[None, :, None, None]) / torch.sqrt(v64[None, :, None, None] + 1e-3) * g64[None, :, None, None] + b64[None, :, None, None]
-    if with_res:
-        z = z + r64
-    o64 = torch.relu(z)
-    ins64 = (y64, g64, b64) + ((r64,) if with_res else ())
-    grads64 = torch.autograd.grad(o64, ins64, dout.double())
-    assert float(cnt) == n * hw * hw
-    assert float((mean.detach().double() - m64.detach()).abs().max()) < 1e-5
-    assert float((var.detach().double() - v64.detach()).abs().max() / v64.detach().max()) < 1e-5
-    assert float((out.double() - o64).abs().max()) < 2e-5
-    for a, b, name in zip(grads, grads64, ("dy", "dgamma", "dbeta", "dres")):
-        err = float((a.double() - b).abs().max() / b.abs().max())
-        assert err < 2e-5, (name, err)
-
-
-def test_one_training_step_on_the_kernels_matches_float64_autograd(torch_gpu, monkeypatch):
-    """loss and every parameter gradient of one batch: utils.trainer_torch._Net on the GPU in float32 with the tower
-    convolutions on k_conv3x3_f16s and the batch norms on csrc/train.hip, against the same graph on the CPU in float64 --
-    and against the GPU float32 run with the library's operators, which sets the scale of float32 round-off for this graph
-    (a ReLU mask that flips on round-off changes a gradient by far more than round-off: 1e-3 .. 1e-2 of the largest entry
-    in either float32 run; measured, the kernels are the closer of the two in 29 of 34 tensors)"""
-    torch = torch_gpu
-    from snake_engine import net
-    from utils import trainer_torch
-    rs = np.random.RandomState(5)
-    X = rs.rand(96, 21, 21, 3).astype(np.float32)
-    Y = np.tanh(rs.randn(96, 3)).astype(np.float32)
-    ws = net.glorot_uniform_weights((21, 21, 3), blocks=4, seed=9)
-
-    def run(dev, dt, native):
-        monkeypatch.setattr(trainer_torch, "_NATIVE_CONV", native)
-        m = trainer_torch._Net(ws, dev, dt)
-        x, y = torch.as_tensor(X, dtype=dt, device=dev), torch.as_tensor(Y, dtype=dt, device=dev)
-        pred = m.forward(x, True)
-        loss = ((pred - y) ** 2).sum() / (3.0 * len(x)) + m.l2()
-        grads = torch.autograd.grad(loss, m.params())
-        return float(loss.detach()), [g.detach().double().cpu() for g in grads], [t.detach().double().cpu() for t in m.t]
-    l_nat, g_nat, t_nat = run(torch.device("cuda"), torch.float32, True)
-    l_lib, g_lib, t_lib = run(torch.device("cuda"), torch.float32, False)
-    l_64, g_64, t_64 = run(torch.device("cpu"), torch.float64, False)
-    assert abs(l_nat - l_64) < 1e-5 * abs(l_64)
-
-    def errs(gs):
-        return [float((a - b).abs().max() / (b.abs().max() + 1e-30)) for a, b in zip(gs, g_64)]
-    e_nat, e_lib = errs(g_nat), errs(g_lib)
-    assert max(e_nat) < 5e-2, max(e_nat)                        # ReLU masks flip on round-off: the library path shows 1e-3 .. 1e-2 too
-    assert max(e_nat) <= 3.0 * max(e_lib) + 1e-6, (max(e_nat), max(e_lib))
-    assert float(np.median(e_nat)) <= 3.0 * float(np.median(e_lib)) + 1e-7, (np.median(e_nat), np.median(e_lib))
-    for a, b in zip(t_nat, t_64):                                # the moving averages moved the same way
-        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-7
