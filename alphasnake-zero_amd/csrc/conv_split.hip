@@ -353,7 +353,12 @@ __global__ __launch_bounds__(1024) void k_f16s_wscale(const float *__restrict__ 
 {
     __shared__ float red[1024];
     float m = 0.f;
-    for (int i = threadIdx.x; i < 9 * HS_C * HS_C; i += 1024) m = fmaxf(m, fabsf(w[i]));
+    const float4 *w4 = (const float4 *)w;                      // 9 * 128 * 128 / 4 = 36 float4 per thread, all in flight
+#pragma unroll 12
+    for (int i = threadIdx.x; i < 9 * HS_C * HS_C / 4; i += 1024) {
+        const float4 v = w4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
     red[threadIdx.x] = m;
     __syncthreads();
     for (int s = 512; s > 0; s >>= 1) {
@@ -370,6 +375,16 @@ __global__ __launch_bounds__(1024) void k_f16s_wscale(const float *__restrict__ 
         tail[2] = in_tail ? in_tail[2] : x_scale;             // the producer of the input measured its range (train.hip)
         tail[3] = in_tail ? in_tail[3] : 1.0f / x_scale;
         tail[4] = tail[5] = tail[6] = tail[7] = 0.f;          // range flag (an int32, bit pattern 0) + padding
+    }
+}
+
+// the tail of an image of the SAME kernel values (their power-of-two scale is known) with another input's range
+__global__ void k_f16s_tail_from(const float *__restrict__ w_tail, const float *__restrict__ in_tail, float *__restrict__ tail)
+{
+    if (threadIdx.x == 0) {
+        tail[0] = w_tail[0]; tail[1] = w_tail[1];
+        tail[2] = in_tail[2]; tail[3] = in_tail[3];
+        tail[4] = tail[5] = tail[6] = tail[7] = 0.f;
     }
 }
 
@@ -408,13 +423,17 @@ extern "C" int snk_conv3x3_prepare_weights_f16s(const float *d_w_hwio, void *d_w
 
 // the training step's form: the input scale is read on the device from d_in_tail = { ., ., scale, 1 / scale } (what
 // snk_bn_train_apply / snk_bn_train_grad_apply measured while writing the tensor this layer reads); input_gradient != 0
-// lays out the kernel of the layer's input gradient (the same convolution with mirrored taps and swapped channel axes)
+// lays out the kernel of the layer's input gradient (the same convolution with mirrored taps and swapped channel axes);
+// d_wS_same_kernel (optional): an image made from the same d_w_hwio values, whose weight scale is reused instead of
+// scanning the kernel for its largest entry again
 extern "C" int snk_conv3x3_prepare_weights_f16s_train(const float *d_w_hwio, void *d_wS, const float *d_in_tail, int input_gradient,
-                                                      void *stream)
+                                                      const void *d_wS_same_kernel, void *stream)
 {
-    SNK_REQUIRE(d_w_hwio && d_wS && d_in_tail, "snk_conv3x3_prepare_weights_f16s_train: NULL argument");
+    SNK_REQUIRE(d_w_hwio && d_wS && d_in_tail && d_wS != d_wS_same_kernel, "snk_conv3x3_prepare_weights_f16s_train: bad argument");
     float *tail = (float *)((_Float16 *)d_wS + HS_WS_ELEMS);
-    k_f16s_wscale<<<1, 1024, 0, (hipStream_t)stream>>>(d_w_hwio, tail, 1.0f, d_in_tail);
+    if (d_wS_same_kernel)
+        k_f16s_tail_from<<<1, 64, 0, (hipStream_t)stream>>>((const float *)((const _Float16 *)d_wS_same_kernel + HS_WS_ELEMS), d_in_tail, tail);
+    else k_f16s_wscale<<<1, 1024, 0, (hipStream_t)stream>>>(d_w_hwio, tail, 1.0f, d_in_tail);
     if (input_gradient) k_f16s_weights<true><<<(HS_WS_ELEMS / 8 + 255) / 256, 256, 0, (hipStream_t)stream>>>(d_w_hwio, (_Float16 *)d_wS, tail);
     else k_f16s_weights<false><<<(HS_WS_ELEMS / 8 + 255) / 256, 256, 0, (hipStream_t)stream>>>(d_w_hwio, (_Float16 *)d_wS, tail);
     SNK_CHECK_HIP(hipGetLastError());

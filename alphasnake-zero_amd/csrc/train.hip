@@ -13,6 +13,7 @@
 // direction, utils/trainer_torch.py).  Everything here is HBM-bound: the PyTorch expressions these kernels replace made ten to
 // fifteen passes over the activation per layer and direction.
 #include "common.h"
+#include "train_fold.h"
 
 #define TR_C 128
 #define TR_THREADS 256
@@ -244,22 +245,6 @@ extern "C" int snk_bn_train_grad_sums(const float *d_dout, const float *d_out, c
 }
 
 // the same sums kept in float64 (the manual training step, snake_engine/train_step.py: the ranks all-reduce float64 sums)
-__global__ __launch_bounds__(TR_THREADS) void k_bn_fold_f64(const float *__restrict__ part, int n_blocks, double *__restrict__ out)
-{
-    const int col = threadIdx.x;                   // 2 * TR_C threads
-    double acc = 0.0;
-    int b = 0;
-    for (; b + 8 <= n_blocks; b += 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + u) * (2 * TR_C) + col];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc += (double)v[u];
-    }
-    for (; b < n_blocks; ++b) acc += (double)part[(size_t)b * (2 * TR_C) + col];
-    out[col] = acc;
-}
-
 extern "C" int snk_bn_train_grad_sums_f64(const float *d_dout, const float *d_out, const float *d_y, const float *d_mean,
                                           const float *d_inv, long rows, int relu, float *d_partials, double *d_sums, void *stream)
 {
@@ -267,7 +252,7 @@ extern "C" int snk_bn_train_grad_sums_f64(const float *d_dout, const float *d_ou
                 "snk_bn_train_grad_sums_f64: bad argument");
     const int grid = tr_grid(rows);
     k_bn_grad_sums<<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_dout, d_out, d_y, d_mean, d_inv, rows, relu, d_partials);
-    k_bn_fold_f64<<<1, 2 * TR_C, 0, (hipStream_t)stream>>>(d_partials, grid, d_sums);
+    tf_fold<double>(d_partials, grid, 2 * TR_C, 2 * TR_C, 1.0, d_sums, (double *)(d_partials + 2048 * 2 * TR_C), (hipStream_t)stream);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -299,4 +284,5 @@ extern "C" int snk_conv3x3_f16s_input_scale(const float *d_x, long n_floats, voi
     return 0;
 }
 
-extern "C" int snk_bn_train_partials(void) { return 2048 * 2 * TR_C; }      // floats the caller provides for d_partials
+// floats the caller provides for d_partials: 2 048 blocks' partials and, behind them, the scratch of the float64 folds
+extern "C" int snk_bn_train_partials(void) { return 2048 * 2 * TR_C + TF_SCRATCH_FLOATS(2 * TR_C); }

@@ -16,6 +16,7 @@
 //
 // Reductions are two-stage and deterministic (block partials, then one block adding them in float64 in a fixed order).
 #include "common.h"
+#include "train_fold.h"
 
 #define TN_WAVE_SYNC()                                                                          \
     do {                                                                                        \
@@ -28,26 +29,6 @@
 #define TN_THREADS 256
 
 typedef float tn_f32x16 __attribute__((ext_vector_type(16)));
-
-// ---------------------------------------------------------------------------------------------------------------------
-// generic deterministic fold: out[i] = scale * sum over g of part[g * stride + i], float64 accumulation, fixed order
-// ---------------------------------------------------------------------------------------------------------------------
-template <typename OUT>
-__global__ __launch_bounds__(TN_THREADS) void k_tn_fold(const float *__restrict__ part, int groups, long stride, int n,
-                                                       double scale, OUT *__restrict__ out)
-{
-    const int i = blockIdx.x * TN_THREADS + threadIdx.x;
-    if (i >= n) return;
-    double acc = 0.0;
-    int g = 0;
-    for (; g + 4 <= groups; g += 4) {
-        const float a = part[(long)g * stride + i], b = part[(long)(g + 1) * stride + i];
-        const float c = part[(long)(g + 2) * stride + i], d = part[(long)(g + 3) * stride + i];
-        acc += (double)a; acc += (double)b; acc += (double)c; acc += (double)d;
-    }
-    for (; g < groups; ++g) acc += (double)part[(long)g * stride + i];
-    out[i] = (OUT)(acc * scale);
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // batch norm: sums of (y - center) and (y - center)^2 per channel (center = the layer's moving mean: the variance is then
@@ -119,6 +100,7 @@ __global__ void k_bn_grad_finalize(const double *__restrict__ sums_global, const
     dgamma[c] = (float)sums_local[C + c];
 }
 
+#define TN_BN_PART (2048 * 2 * TN_C)                       // floats of block partials in a snk_bn_train_partials() buffer; fold scratch behind
 static int tn_grid(long rows)
 {
     const long want = (rows + 7) / 8;
@@ -131,7 +113,7 @@ extern "C" int snk_bn_train_sums_f64(const float *d_y, long rows, const float *d
     SNK_REQUIRE(d_y && d_partials && d_sums && rows > 0, "snk_bn_train_sums_f64: bad argument");
     const int grid = tn_grid(rows);
     k_bn_sums_c<<<grid, TN_THREADS, 0, (hipStream_t)stream>>>(d_y, rows, d_center, d_partials);
-    k_tn_fold<double><<<1, TN_THREADS, 0, (hipStream_t)stream>>>(d_partials, grid, 2 * TN_C, 2 * TN_C, 1.0, d_sums);
+    tf_fold<double>(d_partials, grid, 2 * TN_C, 2 * TN_C, 1.0, d_sums, (double *)(d_partials + TN_BN_PART), (hipStream_t)stream);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -157,14 +139,6 @@ extern "C" int snk_bn_train_grad_finalize(const double *d_sums_global, const dou
                 count > 0, "snk_bn_train_grad_finalize: bad argument");
     k_bn_grad_finalize<<<(channels + 127) / 128, 128, 0, (hipStream_t)stream>>>(d_sums_global, d_sums_local, count, d_gamma, d_inv,
                                                                                d_a, d_b, d_c, d_dgamma, d_dbeta, channels);
-    SNK_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
-extern "C" int snk_fold_partials_f64(const float *d_partials, int groups, long stride, int n, double scale, double *d_out, void *stream)
-{
-    SNK_REQUIRE(d_partials && d_out && groups > 0 && n > 0, "snk_fold_partials_f64: bad argument");
-    k_tn_fold<double><<<(n + TN_THREADS - 1) / TN_THREADS, TN_THREADS, 0, (hipStream_t)stream>>>(d_partials, groups, stride, n, scale, d_out);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -241,7 +215,7 @@ extern "C" long snk_stem_wgrad_partials(int n_images, int height, int width)
     const long lds = (long)4 * (height + 2) * (width + 2) * 3 * sizeof(float);
     if (height < 1 || width < 1 || lds > 150 * 1024) return -1;
     const int grid = n_images < 4 ? 1 : (n_images / 4 < 512 ? n_images / 4 : 512);
-    return (long)grid * 32 * TN_C;
+    return (long)grid * 32 * TN_C + TF_SCRATCH_FLOATS(27 * TN_C);
 }
 
 extern "C" int snk_stem_wgrad_f32(const float *d_x, const float *d_dy, float *d_partials, float *d_dw, int n_images, int height,
@@ -250,14 +224,13 @@ extern "C" int snk_stem_wgrad_f32(const float *d_x, const float *d_dy, float *d_
     SNK_REQUIRE(d_x && d_dy && d_partials && d_dw && n_images > 0, "snk_stem_wgrad_f32: bad argument");
     const long need = snk_stem_wgrad_partials(n_images, height, width);
     SNK_REQUIRE(need > 0, "snk_stem_wgrad_f32: %d x %d image does not fit the LDS", height, width);
-    const int grid = (int)(need / (32 * TN_C));
+    const int grid = (int)((need - TF_SCRATCH_FLOATS(27 * TN_C)) / (32 * TN_C));
     size_t lds = (size_t)4 * (height + 2) * (width + 2) * 3 * sizeof(float);
     if (lds < (size_t)4 * 32 * TN_C * sizeof(float)) lds = (size_t)4 * 32 * TN_C * sizeof(float);
     StemWgArgs a = {d_x, d_dy, d_partials, n_images, height, width};
     k_stem_wgrad<<<grid, 256, lds, (hipStream_t)stream>>>(a);
     // rows 0..26 of the 32-row tile are the Keras kernel (kh, kw, cin, cout) flattened: 27 x 128
-    k_tn_fold<float><<<(27 * TN_C + TN_THREADS - 1) / TN_THREADS, TN_THREADS, 0, (hipStream_t)stream>>>(d_partials, grid, 32 * TN_C,
-                                                                                                     27 * TN_C, 1.0, d_dw);
+    tf_fold<float>(d_partials, grid, 32 * TN_C, 27 * TN_C, 1.0, d_dw, (double *)(d_partials + (long)grid * 32 * TN_C), (hipStream_t)stream);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -316,7 +289,7 @@ extern "C" int snk_head_conv1x1_sums(const float *d_a, const float *d_w1x1, long
     SNK_REQUIRE(d_a && d_w1x1 && d_z && d_partials && d_sums && rows > 0, "snk_head_conv1x1_sums: bad argument");
     const int grid = tn_grid(rows);
     k_head1x1<<<grid, TN_THREADS, 0, (hipStream_t)stream>>>(d_a, d_w1x1, rows, d_center, d_z, d_partials);
-    k_tn_fold<double><<<1, TN_THREADS, 0, (hipStream_t)stream>>>(d_partials, grid, 2, 2, 1.0, d_sums);
+    tf_fold<double>(d_partials, grid, 2, 2, 1.0, d_sums, (double *)(d_partials + TN_BN_PART), (hipStream_t)stream);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -413,7 +386,7 @@ extern "C" int snk_head_dense_train_fwd(const float *d_z, const float *d_scale_s
     HeadTrainArgs a = {d_z, d_scale_shift, d_fc1_w, d_fc1_b, d_fc2_w, d_fc2_b, d_target, d_h, d_d1, d_q,
                        d_sq_err ? d_partials : nullptr, n_images, height * width};
     k_head_dense_train_fwd<<<grid, 256, lds, (hipStream_t)stream>>>(a);
-    if (d_sq_err) k_tn_fold<float><<<1, TN_THREADS, 0, (hipStream_t)stream>>>(d_partials, grid, 1, 1, err_scale, d_sq_err);
+    if (d_sq_err) tf_fold<float>(d_partials, grid, 1, 1, err_scale, d_sq_err, (double *)(d_partials + TN_BN_PART), (hipStream_t)stream);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -539,7 +512,10 @@ __global__ __launch_bounds__(256) void k_head_dw1(const float *__restrict__ h, c
     }
 }
 
-extern "C" int snk_head_dense_train_bwd_partials(int n_images) { return ((n_images + TN_S - 1) / TN_S) * TN_BWD_STRIDE; }
+extern "C" int snk_head_dense_train_bwd_partials(int n_images)
+{
+    return ((n_images + TN_S - 1) / TN_S) * TN_BWD_STRIDE + TF_SCRATCH_FLOATS(TN_BWD_STRIDE);
+}
 
 // outputs: d_dpre1 [n][128] (scratch), d_g [n][HW], d_dw1 [HW][128], d_small[517] = dW2 [128][3], db2 [3], db1 [128],
 // then as float64 d_gsums[2] = {sum g, sum g zhat}
@@ -557,8 +533,9 @@ extern "C" int snk_head_dense_train_bwd(const float *d_q, const float *d_target,
     const size_t lds = (size_t)(2 * TN_S * 128 + TN_S * 4) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     k_head_dense_train_bwd<<<grid, 256, lds, st>>>(a);
-    k_tn_fold<float><<<(515 + TN_THREADS - 1) / TN_THREADS, TN_THREADS, 0, st>>>(d_partials, grid, TN_BWD_STRIDE, 515, 1.0, d_small);
-    k_tn_fold<double><<<1, TN_THREADS, 0, st>>>(d_partials + 515, grid, TN_BWD_STRIDE, 2, 1.0, d_gsums);
+    double *scratch = (double *)(d_partials + (long)grid * TN_BWD_STRIDE);
+    tf_fold<float>(d_partials, grid, TN_BWD_STRIDE, 515, 1.0, d_small, scratch, st);
+    tf_fold<double>(d_partials + 515, grid, TN_BWD_STRIDE, 2, 1.0, d_gsums, scratch, st);
     k_head_dw1<<<(HW + 1) / 2, 256, 0, st>>>(d_h, d_dpre1, d_dw1, n_images, HW);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
@@ -600,7 +577,7 @@ extern "C" int snk_head_conv1x1_bwd(const float *d_g, const float *d_z, const fl
                 "snk_head_conv1x1_bwd: bad argument");
     const int grid = tn_grid(rows);
     k_head_expand<<<grid, TN_THREADS, 0, (hipStream_t)stream>>>(d_g, d_z, d_mean_inv, d_abc, d_a_last, d_w1x1, d_da, d_partials, rows);
-    k_tn_fold<float><<<1, TN_THREADS, 0, (hipStream_t)stream>>>(d_partials, grid, TN_C, TN_C, 1.0, d_dw1x1);
+    tf_fold<float>(d_partials, grid, TN_C, TN_C, 1.0, d_dw1x1, (double *)(d_partials + TN_BN_PART), (hipStream_t)stream);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -611,14 +588,14 @@ extern "C" int snk_head_conv1x1_bwd(const float *d_g, const float *d_z, const fl
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TN_THREADS) void k_adam(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m,
                                                     float *__restrict__ v, const uint8_t *__restrict__ decay, long n, float lr_t,
-                                                    float b1, float b2, float eps, float l2c2)
+                                                    float b1, float b2, float omb1, float omb2, float eps, float l2c2)
 {
     const long i = (long)blockIdx.x * TN_THREADS + threadIdx.x;
     if (i >= n) return;
     const float wi = w[i];
     const float gi = g[i] + (decay[i] ? l2c2 * wi : 0.f);
-    const float mi = m[i] * b1 + gi * (1.f - b1);
-    const float vi = v[i] * b2 + (gi * gi) * (1.f - b2);
+    const float mi = m[i] * b1 + gi * omb1;                 // omb = 1 - beta, rounded once from float64 (1.f - 0.999f is 1.3e-5 off)
+    const float vi = v[i] * b2 + (gi * gi) * omb2;
     m[i] = mi;
     v[i] = vi;
     w[i] = wi - lr_t * (mi / (sqrtf(vi) + eps));
@@ -638,8 +615,8 @@ extern "C" int snk_adam_l2_step(float *d_w, const float *d_g, float *d_m, float 
 {
     SNK_REQUIRE(d_w && d_g && d_m && d_v && d_decay && n > 0, "snk_adam_l2_step: bad argument");
     k_adam<<<(int)((n + TN_THREADS - 1) / TN_THREADS), TN_THREADS, 0, (hipStream_t)stream>>>(d_w, d_g, d_m, d_v, d_decay, n, (float)lr_t,
-                                                                                            (float)beta1, (float)beta2, (float)epsilon,
-                                                                                            (float)(2.0 * l2));
+                                                                                            (float)beta1, (float)beta2, (float)(1.0 - beta1),
+                                                                                            (float)(1.0 - beta2), (float)epsilon, (float)(2.0 * l2));
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -650,7 +627,7 @@ extern "C" int snk_l2_sum(const float *d_w, const uint8_t *d_decay, long n, doub
     SNK_REQUIRE(d_w && d_decay && d_partials && d_out && n > 0, "snk_l2_sum: bad argument");
     const int grid = 256;
     k_sumsq<<<grid, TN_THREADS, 0, (hipStream_t)stream>>>(d_w, d_decay, n, d_partials);
-    k_tn_fold<float><<<1, TN_THREADS, 0, (hipStream_t)stream>>>(d_partials, grid, 2, 1, scale, d_out);
+    tf_fold<float>(d_partials, grid, 2, 1, scale, d_out, (double *)(d_partials + 512), (hipStream_t)stream);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }

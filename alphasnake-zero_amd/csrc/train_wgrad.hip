@@ -5,30 +5,32 @@
 //     dW[dy][dx][ci][co] = sum over images n and pixels (y, x) of  X[n][y + dy][x + dx][ci] * dY[n][y][x][co]      (X zero-padded)
 //
 // A GEMM whose reduction runs over PIXELS -- the slow axis of the channels-last tensors, while an MFMA operand wants eight
-// consecutive k values per lane.  A block owns a 32 x 32 slice (ci, co) of all nine taps and a group of images.  Per image it
-// lays its slices of X and dY into LDS in the order they have in HBM, [padded pixel][32 channels] as f16 hi / lo images with
-// 64-byte rows (pixel (y, x) in row (y + 1) * P + x, P = W + 1 rounded up to 8: the zero rows behind an image row are the
-// next row's left border, image rows 0 and H + 1 are zero): a float4 load and one 8-byte LDS store per image and item.  The MFMA
-// fragments are taken with gfx950's transposing LDS read (ds_read_b64_tr_b16: a 16-lane group reads 4 rows x 16 channels and
-// every lane receives ITS channel's four rows), so a tap (dy, dx) is simply the X image read dy * P + dx ROWS further on; the
-// three dx taps of a dy share three reads of twelve consecutive rows and one 16-bit funnel shift (v_alignbit).  Every wave
-// runs a quarter of the 16-pixel k-steps for all nine taps (nine 32 x 32 accumulators); products are hi*hi + hi*lo + lo*hi as in
-// the forward kernel; the operands' power-of-two scales are the ones the forward / input-gradient calls derived from the data;
-// the next image's values travel from HBM into registers while the current image's MFMAs run.  The image groups' partial
-// results are summed in a fixed order by k_wgrad_fold (float64): a run repeats bit for bit.
+// consecutive k values per lane.  A block owns a 32 x 32 slice (ci, co) of all nine taps and a group of images, and works
+// through them in SLABS of RB image rows.  A slab's slices of dY (RB rows) and X (RB + 2 rows: one above, one below, zero
+// outside the image) lie in LDS in the order they have in HBM, [pixel][32 channels] as f16 hi / lo images with 64-byte rows
+// and pitch P = W + 1 (the zero cell behind an image row is the next row's left border).  The MFMA fragments are taken with
+// gfx950's transposing LDS read (ds_read_b64_tr_b16: a 16-lane group reads 4 rows x 16 channels and every lane receives ITS
+// channel's four rows), so a tap (dy, dx) is simply the X image read (dy + 1) * P + dx ROWS further on; the three dx taps of
+// a dy share three reads of twelve consecutive rows and one 16-bit funnel shift (v_alignbit).  Products are hi*hi + hi*lo +
+// lo*hi as in the forward kernel; the operands' power-of-two scales are the ones the element-wise kernels measured.
 //
-// Measured (MI355X, 2 048 images of 21 x 21, tools/wgrad_time.py): 1.27 ms = 210 TFLOP/s algorithmic, error 3e-7 against float64;
-// the library's float32 kernel (igemm_wrw, f32 matrix pipe) takes 2.35 ms.  The MFMA phase alone is 0.64 ms (the pipe's rate for
-// its 3 x 1.25 -- split, padded positions -- executed flops); staging does not overlap it (one wave per SIMD: the block fills
-// the LDS).  The first form of this kernel kept [channel][padded pixel] planes (taps = element offsets, dx = +-1 fragments
-// funnel-shifted from two aligned reads): 1.41 ms whichever way its staging was written -- float4 loads + sixteen 2-byte LDS
-// stores per item (bank conflicts) or 4-byte loads + 16-byte stores (128 load instructions per thread and image).
+// Round 3: the block is 8 wavefronts with two ROLES and two LDS buffers.  Wavefronts 0-3 run the MFMAs of slab t from buffer
+// t & 1 (a quarter of the 16-pixel k-steps each, nine 32 x 32 accumulators); wavefronts 4-7 meanwhile split slab t + 1 into
+// the other buffer and fetch slab t + 2 from HBM into registers; one block barrier per slab.  Every SIMD holds one MFMA
+// wavefront and one staging wavefront, whose vector instructions issue in the gaps of the other's MFMAs.  (Round 2's form --
+// 4 wavefronts, a whole image per barrier pair, staging and MFMA phases in sequence -- took 1.27 ms per layer at 2 048
+// images of 21 x 21 with an MFMA phase of 0.64 ms; it also kept whole images in LDS and so refused 37 x 37.)  Slabs make the
+// GEMM's k range follow the real pixels more closely (32 k-steps per 21 x 21 image instead of 35).
+// The image groups' partial results are summed in a fixed order by k_wgrad_fold (float64): a run repeats bit for bit.
 #include "common.h"
 
 typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
 typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
 
 #define WG_GROUPS 16                 // image groups: 16 slices x 16 groups = 256 blocks, one per CU (the block fills its LDS)
+#define WG_GX 8                      // rows in front of the X image (the dx = -1 tap of the first pixel reads one row back)
+#define WG_MAXX 9                    // (pixel, four channels) items per staging thread and slab: X, then dY
+#define WG_MAXY 8
 
 __device__ static inline wg_f16x8 wg_frag(uint4 v)
 {
@@ -44,7 +46,7 @@ struct WgArgs {
     const float *x, *dy;
     float *part;
     const float *x_tail, *dy_tail;
-    int n_images, H, W, P, nk, rows_x, per_group, gx;     // gx: rows in front of the X image (the taps reach P + 1 rows back)
+    int n_images, H, W, P, RB, n_slabs, nk, rows_x, per_group, nx_items, ny_items;
 };
 
 __device__ static inline wg_f16x8 wg_join(wg_s4 a, wg_s4 b)
@@ -54,107 +56,156 @@ __device__ static inline wg_f16x8 wg_join(wg_s4 a, wg_s4 b)
     return c.f;
 }
 
-__global__ __launch_bounds__(256) void k_wgrad_f16s(WgArgs p)
+__device__ static inline void wg_split4(float4 v, float s, uint2 &hi, uint2 &lo)
+{
+    const float a[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+    union { _Float16 f[4]; uint2 u; } H_, L_;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { H_.f[e] = (_Float16)a[e]; L_.f[e] = (_Float16)(a[e] - (float)H_.f[e]); }
+    hi = H_.u; lo = L_.u;
+}
+
+__global__ __launch_bounds__(512) void k_wgrad_f16s(WgArgs p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char *XH = smem, *XL = XH + p.rows_x * 64, *YH = XL + p.rows_x * 64, *YL = YH + p.nk * 16 * 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
     static_assert(WG_GROUPS == 16, "256 workgroups = 8 XCDs x 2 image groups x 16 slices");
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
     const int grp = 2 * xcd + (local >> 4), slice = local & 15, cs = slice >> 2, os = slice & 3;
-    const float sx = p.x_tail[2], sy = p.dy_tail[2];
-    const int lds_bytes = 2 * 64 * (p.rows_x + p.nk * 16);
-    for (int o = tid * 16; o < lds_bytes; o += 256 * 16) *(uint4 *)(smem + o) = make_uint4(0u, 0u, 0u, 0u);   // borders stay zero
-    wg_f32x16 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    __syncthreads();
-
-    // a transposing read of rows R .. R + 3: lane 4 q + p of a 16-lane group gives the address of row R + q, channels
-    // 16 (group & 1) + 4 p .. + 3; the group's lane i receives channel 16 (group & 1) + i = lane & 31, row q in element q
-    const int i16 = lane & 15, g4 = lane >> 4;
-    const int lane_off = (i16 >> 2) * 64 + (16 * (g4 & 1) + 4 * (i16 & 3)) * 2;
-    const int HW = p.H * p.W, P = p.P, items = HW * 8;
-    const float invW = 1.0f / (float)p.W;
+    const int P = p.P, W = p.W, H = p.H;
+    const int y_rows = p.nk * 16;
+    const int buf_bytes = 2 * 64 * (p.rows_x + y_rows);               // XH | XL | YH | YL of one buffer
+    for (int o = tid * 16; o < 2 * buf_bytes; o += 512 * 16) *(uint4 *)(smem + o) = make_uint4(0u, 0u, 0u, 0u);   // borders stay zero
     const int n0 = grp * p.per_group, n1 = min(n0 + p.per_group, p.n_images);
-    constexpr int MAXIT = 14;                          // (pixel, four channels) items per thread: h * w * 8 / 256 <= 14 (21 x 21)
-    float4 xv[MAXIT], yv[MAXIT];
-    auto fetch = [&](int n) {
-        const float *xn = p.x + (long)n * HW * 128 + 32 * cs, *yn = p.dy + (long)n * HW * 128 + 32 * os;
+    const int T = max(n1 - n0, 0) * p.n_slabs;                        // slabs this block works through
+    float *red = (float *)smem;
+
+    if (wv >= 4) {
+        // ---------------- staging role: 256 threads lay slab after slab into the buffers ----------------
+        const int st = tid - 256;
+        const float sx = p.x_tail[2], sy = p.dy_tail[2];
+        const float invW = 1.0f / (float)W;
+        int xl[WG_MAXX], xg[WG_MAXX], xr[WG_MAXX];                    // LDS byte offset, element offset in the slab, slab row
+        int yl[WG_MAXY], yg[WG_MAXY], yr[WG_MAXY];
 #pragma unroll
-        for (int j = 0; j < MAXIT; ++j) {
-            const int it = min(tid + 256 * j, items - 1);       // clamped: every load is in range, unused ones are not stored
-            xv[j] = *(const float4 *)(xn + (long)(it >> 3) * 128 + 4 * (it & 7));
-            yv[j] = *(const float4 *)(yn + (long)(it >> 3) * 128 + 4 * (it & 7));
+        for (int j = 0; j < WG_MAXX; ++j) {
+            const int it = min(st + 256 * j, p.nx_items - 1);
+            const int pix = it >> 3, c4 = it & 7;
+            const int yy = (int)(((float)pix + 0.5f) * invW), xx = pix - yy * W;      // yy = 0 .. RB + 1: image row r0 - 1 + yy
+            xl[j] = (WG_GX + yy * P + xx) * 64 + 8 * c4;
+            xg[j] = (yy * W + xx) * 128 + 4 * c4;
+            xr[j] = st + 256 * j < p.nx_items ? yy : -100000;
         }
-    };
-    auto split4 = [](float4 v, float s, uint2 &hi, uint2 &lo) {
-        const float a[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
-        union { _Float16 f[4]; uint2 u; } H_, L_;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { H_.f[e] = (_Float16)a[e]; L_.f[e] = (_Float16)(a[e] - (float)H_.f[e]); }
-        hi = H_.u; lo = L_.u;
-    };
-    if (n0 < n1) fetch(n0);
-    for (int n = n0; n < n1; ++n) {
-        int tid_v = tid;
-        asm volatile("" : "+v"(tid_v));                // opaque per image: the unrolled loop's LDS addresses are not hoisted
+        for (int j = 0; j < WG_MAXY; ++j) {
+            const int it = min(st + 256 * j, p.ny_items - 1);
+            const int pix = it >> 3, c4 = it & 7;
+            const int yy = (int)(((float)pix + 0.5f) * invW), xx = pix - yy * W;      // yy = 0 .. RB - 1: image row r0 + yy
+            yl[j] = (yy * P + xx) * 64 + 8 * c4;
+            yg[j] = (yy * W + xx) * 128 + 4 * c4;
+            yr[j] = st + 256 * j < p.ny_items ? yy : -100000;
+        }
+        float4 xv[WG_MAXX], yv[WG_MAXY];
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto fetch = [&](int t) {                                     // slab t of this block -> registers (rows outside the image: zeros)
+            const int n = n0 + t / p.n_slabs, r0 = (t % p.n_slabs) * p.RB;
+            const float *xn = p.x + ((long)n * H + (r0 - 1)) * W * 128 + 32 * cs;
+            const float *yn = p.dy + ((long)n * H + r0) * W * 128 + 32 * os;
 #pragma unroll
-        for (int j = 0; j < MAXIT; ++j) {
-            const int it = tid_v + 256 * j;
-            if (it < items) {
-                const int pix = it >> 3, c4 = it & 7;
-                const int y = (int)(((float)pix + 0.5f) * invW), x = pix - y * p.W;
-                const int q = (y + 1) * P + x;
-                uint2 hi, lo;
-                split4(xv[j], sx, hi, lo);
-                *(uint2 *)(XH + (q + p.gx) * 64 + 8 * c4) = hi; *(uint2 *)(XL + (q + p.gx) * 64 + 8 * c4) = lo;
-                split4(yv[j], sy, hi, lo);
-                *(uint2 *)(YH + q * 64 + 8 * c4) = hi; *(uint2 *)(YL + q * 64 + 8 * c4) = lo;
+            for (int j = 0; j < WG_MAXX; ++j) {
+                const int row = r0 - 1 + xr[j];
+                xv[j] = zero4;
+                if (row >= 0 && row < H) xv[j] = *(const float4 *)(xn + xg[j]);
             }
-        }
-        __syncthreads();
-        if (n + 1 < n1) fetch(n + 1);
-        for (int ks = wv; ks < p.nk; ks += 4) {
-            const int R = 16 * ks + 8 * h;
-            const wg_f16x8 bh = wg_join(WG_TR(YH + R * 64 + lane_off), WG_TR(YH + (R + 4) * 64 + lane_off));
-            const wg_f16x8 bl = wg_join(WG_TR(YL + R * 64 + lane_off), WG_TR(YL + (R + 4) * 64 + lane_off));
 #pragma unroll
-            for (int dyi = 0; dyi < 3; ++dyi) {
-                const int Rx = R + p.gx + (dyi - 1) * P - 1;           // rows Rx .. Rx + 11 hold the three dx taps' elements
-                union { struct { wg_s4 a, b, c; } s; unsigned d[6]; } uh, ul;
-                uh.s.a = WG_TR(XH + Rx * 64 + lane_off); uh.s.b = WG_TR(XH + (Rx + 4) * 64 + lane_off); uh.s.c = WG_TR(XH + (Rx + 8) * 64 + lane_off);
-                ul.s.a = WG_TR(XL + Rx * 64 + lane_off); ul.s.b = WG_TR(XL + (Rx + 4) * 64 + lane_off); ul.s.c = WG_TR(XL + (Rx + 8) * 64 + lane_off);
+            for (int j = 0; j < WG_MAXY; ++j) {
+                const int row = r0 + yr[j];
+                yv[j] = zero4;
+                if (row >= 0 && row < H) yv[j] = *(const float4 *)(yn + yg[j]);
+            }
+        };
+        auto store = [&](int b) {                                     // registers -> buffer b, split into f16 hi / lo
+            unsigned char *XH = smem + b * buf_bytes, *XL = XH + p.rows_x * 64, *YH = XL + p.rows_x * 64, *YL = YH + y_rows * 64;
+#pragma unroll
+            for (int j = 0; j < WG_MAXX; ++j)
+                if (xr[j] >= 0) {
+                    uint2 hi, lo;
+                    wg_split4(xv[j], sx, hi, lo);
+                    *(uint2 *)(XH + xl[j]) = hi; *(uint2 *)(XL + xl[j]) = lo;
+                }
+#pragma unroll
+            for (int j = 0; j < WG_MAXY; ++j)
+                if (yr[j] >= 0) {
+                    uint2 hi, lo;
+                    wg_split4(yv[j], sy, hi, lo);
+                    *(uint2 *)(YH + yl[j]) = hi; *(uint2 *)(YL + yl[j]) = lo;
+                }
+        };
+        if (T > 0) fetch(0);
+        __syncthreads();                                              // the zero fill is complete
+        if (T > 0) store(0);
+        if (T > 1) fetch(1);
+        __syncthreads();                                              // slab 0 is in buffer 0
+        for (int t = 0; t < T; ++t) {
+            if (t + 1 < T) store((t + 1) & 1);
+            if (t + 2 < T) fetch(t + 2);
+            __syncthreads();
+        }
+    } else {
+        // ---------------- MFMA role: wavefront wv runs k-steps wv, wv + 4, ... of every slab ----------------
+        // a transposing read of rows R .. R + 3: lane 4 q + p of a 16-lane group gives the address of row R + q, channels
+        // 16 (group & 1) + 4 p .. + 3; the group's lane i receives channel 16 (group & 1) + i = lane & 31, row q in element q
+        const int i16 = lane & 15, g4 = lane >> 4;
+        const int lane_off = (i16 >> 2) * 64 + (16 * (g4 & 1) + 4 * (i16 & 3)) * 2;
+        const int xoff = WG_GX + P;                                   // X row of the pixel at dY position 0
+        wg_f32x16 acc[9];                                             // live in this role only: the staging role's registers hold slabs
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        __syncthreads();
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            const unsigned char *XH = smem + (t & 1) * buf_bytes, *XL = XH + p.rows_x * 64, *YH = XL + p.rows_x * 64, *YL = YH + y_rows * 64;
+            for (int ks = wv; ks < p.nk; ks += 4) {
+                const int R = 16 * ks + 8 * h;
+                const wg_f16x8 bh = wg_join(WG_TR(YH + R * 64 + lane_off), WG_TR(YH + (R + 4) * 64 + lane_off));
+                const wg_f16x8 bl = wg_join(WG_TR(YL + R * 64 + lane_off), WG_TR(YL + (R + 4) * 64 + lane_off));
+#pragma unroll
+                for (int dyi = 0; dyi < 3; ++dyi) {
+                    const int Rx = R + xoff + (dyi - 1) * P - 1;       // rows Rx .. Rx + 11 hold the three dx taps' elements
+                    union { struct { wg_s4 a, b, c; } s; unsigned d[6]; } uh, ul;
+                    uh.s.a = WG_TR(XH + Rx * 64 + lane_off); uh.s.b = WG_TR(XH + (Rx + 4) * 64 + lane_off); uh.s.c = WG_TR(XH + (Rx + 8) * 64 + lane_off);
+                    ul.s.a = WG_TR(XL + Rx * 64 + lane_off); ul.s.b = WG_TR(XL + (Rx + 4) * 64 + lane_off); ul.s.c = WG_TR(XL + (Rx + 8) * 64 + lane_off);
 #define WG_AB(hi_, lo_) __builtin_amdgcn_alignbit((hi_), (lo_), 16)
-                const wg_f16x8 ah[3] = {wg_frag(make_uint4(uh.d[0], uh.d[1], uh.d[2], uh.d[3])),                                              // dx = -1
-                                        wg_frag(make_uint4(WG_AB(uh.d[1], uh.d[0]), WG_AB(uh.d[2], uh.d[1]), WG_AB(uh.d[3], uh.d[2]), WG_AB(uh.d[4], uh.d[3]))),
-                                        wg_frag(make_uint4(uh.d[1], uh.d[2], uh.d[3], uh.d[4]))};                                              // dx = +1
-                const wg_f16x8 al[3] = {wg_frag(make_uint4(ul.d[0], ul.d[1], ul.d[2], ul.d[3])),
-                                        wg_frag(make_uint4(WG_AB(ul.d[1], ul.d[0]), WG_AB(ul.d[2], ul.d[1]), WG_AB(ul.d[3], ul.d[2]), WG_AB(ul.d[4], ul.d[3]))),
-                                        wg_frag(make_uint4(ul.d[1], ul.d[2], ul.d[3], ul.d[4]))};
+                    const wg_f16x8 ah[3] = {wg_frag(make_uint4(uh.d[0], uh.d[1], uh.d[2], uh.d[3])),                                              // dx = -1
+                                            wg_frag(make_uint4(WG_AB(uh.d[1], uh.d[0]), WG_AB(uh.d[2], uh.d[1]), WG_AB(uh.d[3], uh.d[2]), WG_AB(uh.d[4], uh.d[3]))),
+                                            wg_frag(make_uint4(uh.d[1], uh.d[2], uh.d[3], uh.d[4]))};                                              // dx = +1
+                    const wg_f16x8 al[3] = {wg_frag(make_uint4(ul.d[0], ul.d[1], ul.d[2], ul.d[3])),
+                                            wg_frag(make_uint4(WG_AB(ul.d[1], ul.d[0]), WG_AB(ul.d[2], ul.d[1]), WG_AB(ul.d[3], ul.d[2]), WG_AB(ul.d[4], ul.d[3]))),
+                                            wg_frag(make_uint4(ul.d[1], ul.d[2], ul.d[3], ul.d[4]))};
 #undef WG_AB
 #pragma unroll
-                for (int dxi = 0; dxi < 3; ++dxi) {
-                    const int t = 3 * dyi + dxi;
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[dxi], bh, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[dxi], bl, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[dxi], bh, acc[t], 0, 0, 0);
+                    for (int dxi = 0; dxi < 3; ++dxi) {
+                        const int tp = 3 * dyi + dxi;
+                        acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[dxi], bh, acc[tp], 0, 0, 0);
+                        acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[dxi], bl, acc[tp], 0, 0, 0);
+                        acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[dxi], bh, acc[tp], 0, 0, 0);
+                    }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
+        // the four MFMA wavefronts' accumulators are added through LDS (all slabs are done: the buffers are free)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                red[((wv * 9 + t) * 32 + ((r & 3) + 8 * (r >> 2) + 4 * h)) * 32 + l31] = acc[t][r];
     }
-    float *red = (float *)smem;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            red[((wv * 9 + t) * 32 + ((r & 3) + 8 * (r >> 2) + 4 * h)) * 32 + l31] = acc[t][r];
     __syncthreads();
     const float inv = p.x_tail[3] * p.dy_tail[3];
-    for (int i = tid; i < 9 * 1024; i += 256) {
+    for (int i = tid; i < 9 * 1024; i += 512) {
         const float s = ((red[i] + red[9216 + i]) + red[2 * 9216 + i]) + red[3 * 9216 + i];
         const int t = i >> 10, row = (i >> 5) & 31, col = i & 31;
         p.part[(((long)grp * 9 + t) * 128 + 32 * cs + row) * 128 + 32 * os + col] = s * inv;
@@ -169,35 +220,44 @@ __global__ __launch_bounds__(256) void k_wgrad_fold(const float *__restrict__ pa
     dw[i] = (float)acc;
 }
 
-struct WgShape { int P, nk, rows_x, gx, lds; };
-static WgShape wg_shape(int h, int w)
+struct WgShape { int P, RB, n_slabs, nk, rows_x, lds, nx_items, ny_items; };
+static bool wg_shape(int h, int w, WgShape &s)
 {
-    WgShape s;
-    s.P = (w + 1 + 7) / 8 * 8;
-    s.nk = ((h + 2) * s.P + 15) / 16;
-    s.gx = s.P + 8;
-    s.rows_x = 16 * s.nk + 2 * s.P + 16;
-    s.lds = 2 * 64 * (s.rows_x + 16 * s.nk);
-    return s;
+    if (h < 1 || w < 3) return false;
+    s.P = w + 1;
+    // slab height: the staging threads hold a slab's items in registers, both buffers share the LDS with nothing else
+    for (s.n_slabs = 1; s.n_slabs <= h; ++s.n_slabs) {
+        s.RB = (h + s.n_slabs - 1) / s.n_slabs;
+        s.nx_items = (s.RB + 2) * w * 8;
+        s.ny_items = s.RB * w * 8;
+        s.nk = (s.RB * s.P + 15) / 16;
+        s.rows_x = 16 * s.nk + WG_GX + 2 * s.P + 8;
+        s.lds = 2 * 2 * 64 * (s.rows_x + 16 * s.nk);
+        if (s.nx_items <= WG_MAXX * 256 && s.ny_items <= WG_MAXY * 256 && s.lds <= 150 * 1024) {
+            if (s.lds < 4 * 9 * 1024 * 4) s.lds = 4 * 9 * 1024 * 4;          // or the four wavefronts' accumulators at the end
+            return true;
+        }
+    }
+    return false;
 }
 
 extern "C" long snk_conv3x3_wgrad_partials(int height, int width)
 {
-    const WgShape s = wg_shape(height, width);
-    if (height != width || width < 3 || s.lds > 160 * 1024 || height * width * 8 > 14 * 256) return -1;   // the images of one
-    return (long)WG_GROUPS * 9 * 128 * 128;                                  // slice must fit the LDS, its items the registers
+    WgShape s;
+    if (!wg_shape(height, width, s)) return -1;
+    return (long)WG_GROUPS * 9 * 128 * 128;
 }
 
 extern "C" int snk_conv3x3_wgrad_f16s(const float *d_x, const float *d_dy, const float *d_x_tail, const float *d_dy_tail,
                                       float *d_partials, float *d_dw, int n_images, int height, int width, void *stream)
 {
     SNK_REQUIRE(d_x && d_dy && d_x_tail && d_dy_tail && d_partials && d_dw && n_images > 0, "snk_conv3x3_wgrad_f16s: bad argument");
-    SNK_REQUIRE(snk_conv3x3_wgrad_partials(height, width) > 0, "snk_conv3x3_wgrad_f16s: %d x %d does not fit the LDS images", height, width);
-    const WgShape s = wg_shape(height, width);
-    WgArgs a = {d_x, d_dy, d_partials, d_x_tail, d_dy_tail, n_images, height, width, s.P, s.nk, s.rows_x,
-                (n_images + WG_GROUPS - 1) / WG_GROUPS, s.gx};
-    const int lds = s.lds > 4 * 9 * 1024 * 4 ? s.lds : 4 * 9 * 1024 * 4;      // the images, or the four waves' accumulators at the end
-    k_wgrad_f16s<<<16 * WG_GROUPS, 256, lds, (hipStream_t)stream>>>(a);
+    WgShape s;
+    SNK_REQUIRE(wg_shape(height, width, s), "snk_conv3x3_wgrad_f16s: %d x %d images are not supported (width 3 .. 96)", height, width);
+    SNK_REQUIRE((long)n_images * height * width * 128 < (1l << 40), "snk_conv3x3_wgrad_f16s: batch too large");
+    WgArgs a = {d_x, d_dy, d_partials, d_x_tail, d_dy_tail, n_images, height, width, s.P, s.RB, s.n_slabs, s.nk, s.rows_x,
+                (n_images + WG_GROUPS - 1) / WG_GROUPS, s.nx_items, s.ny_items};
+    k_wgrad_f16s<<<16 * WG_GROUPS, 512, s.lds, (hipStream_t)stream>>>(a);
     k_wgrad_fold<<<9 * 128 * 128 / 256, 256, 0, (hipStream_t)stream>>>(d_partials, WG_GROUPS, d_dw);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;

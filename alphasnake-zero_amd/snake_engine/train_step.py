@@ -99,7 +99,7 @@ class TrainStep:
         self.img_b = torch.empty(F16S_WEIGHT_BYTES, dtype=torch.uint8, device=self.dev)
         self.ones, self.zeros = torch.ones(C, device=self.dev), f(C)
         self.sums, self.sums_local = f(2 * C, torch.float64), f(2 * C, torch.float64)
-        self.partials = f(max(self.L.snk_bn_train_partials(), 1024))
+        self.partials = f(self.L.snk_bn_train_partials())
         self.wg_partials = f(int(self.L.snk_conv3x3_wgrad_partials(self.h, self.w)))
         self.sw_partials = f(int(self.L.snk_stem_wgrad_partials(self.max_rows, self.h, self.w)))
         # head
@@ -110,7 +110,7 @@ class TrainStep:
         self.h_sums, self.h_sums_local = f(2, torch.float64), f(2, torch.float64)
         self.small = f(515)
         self.hb_partials = f(self.L.snk_head_dense_train_bwd_partials(self.max_rows))
-        self.l2_partials = f(512)
+        self.l2_partials = f(1024)
         self.l2_value = f(1)
         self.mask_override = {}          # tests: layer -> tensor whose sign replaces out > 0 as the ReLU mask ('h', 'd1': the head's)
         self.saved_rows = 0
@@ -157,7 +157,7 @@ class TrainStep:
         self._bn_forward(0, n, count, None, self.out[0], self.tail_out[0])
         for l in range(1, self.n_layers):
             k = self._k(l)
-            check(L.snk_conv3x3_prepare_weights_f16s_train(_p(self.view[k]), _p(self.img_f[l]), _p(self.tail_out[l - 1]), 0, st))
+            check(L.snk_conv3x3_prepare_weights_f16s_train(_p(self.view[k]), _p(self.img_f[l]), _p(self.tail_out[l - 1]), 0, None, st))
             self._conv(self.out[l - 1], self.img_f[l], None, self.y[l], n)
             res = self.out[l - 2] if l % 2 == 0 else None                # a block's second layer adds the block's input
             self._bn_forward(l, n, count, res, self.out[l], self.tail_out[l])
@@ -219,7 +219,7 @@ class TrainStep:
             self._bn_backward(l, n, count, want_res=second, tail=self.tail_dy)         # dA -> dY (+ gres: the shortcut's gradient)
             check(L.snk_conv3x3_wgrad_f16s(_p(self.out[l - 1]), _p(self.dY), _p(self.tail_out[l - 1]), _p(self.tail_dy),
                                            _p(self.wg_partials), _p(self.gview[k]), n, self.h, self.w, st))
-            check(L.snk_conv3x3_prepare_weights_f16s_train(_p(self.view[k]), _p(self.img_b), _p(self.tail_dy), 1, st))
+            check(L.snk_conv3x3_prepare_weights_f16s_train(_p(self.view[k]), _p(self.img_b), _p(self.tail_dy), 1, _p(self.img_f[l]), st))
             self._conv(self.dY, self.img_b, None if second else self.gres, self.dA, n)  # gradient at out[l - 1]
         self._bn_backward(0, n, count, want_res=False, tail=None)
         check(L.snk_stem_wgrad_f32(_p(self.x0), _p(self.dY), _p(self.sw_partials), _p(self.gview[0]), n, self.h, self.w, st))

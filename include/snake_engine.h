@@ -343,7 +343,8 @@ int snk_bn_train_grad_apply(const float *d_dout, const float *d_out, const float
  * step runs on this library alone.  Sums travel as float64 (the ranks all-reduce them between a *_sums and its *_finalize).
  *   snk_conv3x3_prepare_weights_f16s_train  weight image of a tower layer for the forward pass (input_gradient = 0) or for its
  *        input gradient (1: taps mirrored, channel axes swapped); the input's power-of-two scale is read on the device from
- *        d_in_tail = { ., ., scale, 1 / scale } as snk_bn_train_apply / snk_bn_train_grad_apply left it
+ *        d_in_tail = { ., ., scale, 1 / scale } as snk_bn_train_apply / snk_bn_train_grad_apply left it; d_wS_same_kernel
+ *        (optional): an image already made from the same kernel values -- its weight scale is reused
  *   snk_stem_conv_f32        the bare 3 -> 128 convolution of alpha_nnet.py:21 (no batch norm, no ReLU); d_w = Keras kernel (3,3,3,128)
  *   snk_stem_wgrad_f32       its weight gradient d_dw[3][3][3][128]; d_partials: snk_stem_wgrad_partials(n, h, w) floats
  *   snk_bn_train_sums_f64    d_sums[0..127] = sum (y - center), [128..255] = sum (y - center)^2 (d_center: 128 floats or NULL)
@@ -352,11 +353,10 @@ int snk_bn_train_grad_apply(const float *d_dout, const float *d_out, const float
  *        variance (TF fused batch norm).  d_center may be d_moving_mean.  Works for any channel count (the head's is 1).
  *   snk_bn_train_grad_sums_f64 / snk_bn_train_grad_finalize   { sum g, sum g xhat } -> a, b, c of snk_bn_train_grad_apply (from the
  *        sums of all ranks) and this rank's dgamma, dbeta (from its own sums)
- *   snk_fold_partials_f64    d_out[i] = scale * sum_g d_partials[g * stride + i]
  *   snk_head_conv1x1_sums    z[row] = dot(a[row][0..127], w1x1) (alpha_nnet.py:49) + d_sums[2] = sum (z - center), sum (z - center)^2
  *   snk_head_dense_train_fwd h = relu(z * scale + shift) [n][hw], d1 = relu(h W1 + b1) [n][128], q = tanh(d1 W2 + b2) [n][3]
  *        (alpha_nnet.py:50-54); d_scale_shift: 2 floats in device memory; d_sq_err (optional) = err_scale * sum (q - target)^2;
- *        d_h / d_d1 optional; d_partials: ceil(n / 16) floats
+ *        d_h / d_d1 optional; d_partials: snk_bn_train_partials() floats
  *   snk_head_dense_train_bwd the way back: d_g[n][hw] (gradient at the 1-channel batch norm's output, ReLU applied), d_dw1[hw][128],
  *        d_small[515] = dW2[128][3], db2[3], db1[128], d_gsums[2] = sum g, sum g zhat; norm = 1 / (3 * rows of the global
  *        batch); d_h_mask / d_d1_mask (optional): tensors whose SIGN replaces h > 0 / d1 > 0 as the ReLU masks;
@@ -365,9 +365,9 @@ int snk_bn_train_grad_apply(const float *d_dout, const float *d_out, const float
  *        sum_row a_last[row][c] * dz[row]; d_partials: snk_bn_train_partials() floats
  *   snk_adam_l2_step         tf.keras Adam on flat buffers: g += 2 * l2 * w where d_decay[i] != 0 (Conv2D / Dense kernels,
  *        kernel_regularizer = l2(1e-5)); m, v updated; w -= lr_t * m / (sqrt(v) + epsilon)
- *   snk_l2_sum               d_out[0] = scale * sum of w[i]^2 over d_decay[i] != 0; d_partials: 512 floats                      */
+ *   snk_l2_sum               d_out[0] = scale * sum of w[i]^2 over d_decay[i] != 0; d_partials: 1 024 floats                      */
 int snk_conv3x3_prepare_weights_f16s_train(const float *d_w_hwio, void *d_wS, const float *d_in_tail, int input_gradient,
-                                           void *stream);
+                                           const void *d_wS_same_kernel, void *stream);
 int snk_stem_conv_f32(const float *d_x, const float *d_w, float *d_out, int n_images, int height, int width, void *stream);
 long snk_stem_wgrad_partials(int n_images, int height, int width);
 int snk_stem_wgrad_f32(const float *d_x, const float *d_dy, float *d_partials, float *d_dw, int n_images, int height, int width,
@@ -381,7 +381,6 @@ int snk_bn_train_grad_sums_f64(const float *d_dout, const float *d_out, const fl
 int snk_bn_train_grad_finalize(const double *d_sums_global, const double *d_sums_local, double count, const float *d_gamma,
                                const float *d_inv, float *d_a, float *d_b, float *d_c, float *d_dgamma, float *d_dbeta,
                                int channels, void *stream);
-int snk_fold_partials_f64(const float *d_partials, int groups, long stride, int n, double scale, double *d_out, void *stream);
 int snk_head_conv1x1_sums(const float *d_a, const float *d_w1x1, long rows, const float *d_center, float *d_z, float *d_partials,
                           double *d_sums, void *stream);
 int snk_head_dense_train_fwd(const float *d_z, const float *d_scale_shift, const float *d_fc1_w, const float *d_fc1_b,

@@ -47,12 +47,13 @@ def test_tower_convolution_three_passes_match_float64(torch_gpu, n, hw, xmag, gm
     dy = (dy * (torch.rand(n, hw, hw, 1, device="cuda", generator=g) ** 6)).contiguous()    # a wide spread of magnitudes, as real gradients have
     ones, zeros = torch.ones(128, device="cuda"), torch.zeros(128, device="cuda")
     image = torch.empty(F16S_WEIGHT_BYTES, dtype=torch.uint8, device="cuda")
+    image_b = torch.empty_like(image)                       # the mirrored kernel of the input gradient reuses the first image's weight scale
     tx, tdy = _tail_of(torch, L, x), _tail_of(torch, L, dy)
     y, dx = torch.empty_like(x), torch.empty_like(x)
-    check(L.snk_conv3x3_prepare_weights_f16s_train(k.data_ptr(), image.data_ptr(), tx.data_ptr(), 0, st))
+    check(L.snk_conv3x3_prepare_weights_f16s_train(k.data_ptr(), image.data_ptr(), tx.data_ptr(), 0, None, st))
     check(L.snk_conv3x3_bn_f16s(x.data_ptr(), image.data_ptr(), ones.data_ptr(), zeros.data_ptr(), None, y.data_ptr(), n, hw, hw, 0, st))
-    check(L.snk_conv3x3_prepare_weights_f16s_train(k.data_ptr(), image.data_ptr(), tdy.data_ptr(), 1, st))
-    check(L.snk_conv3x3_bn_f16s(dy.data_ptr(), image.data_ptr(), ones.data_ptr(), zeros.data_ptr(), None, dx.data_ptr(), n, hw, hw, 0, st))
+    check(L.snk_conv3x3_prepare_weights_f16s_train(k.data_ptr(), image_b.data_ptr(), tdy.data_ptr(), 1, image.data_ptr(), st))
+    check(L.snk_conv3x3_bn_f16s(dy.data_ptr(), image_b.data_ptr(), ones.data_ptr(), zeros.data_ptr(), None, dx.data_ptr(), n, hw, hw, 0, st))
     need = L.snk_conv3x3_wgrad_partials(hw, hw)
     assert need > 0, "every square observation the engine supports has a weight-gradient kernel"
     part = torch.empty(need, device="cuda")
@@ -122,14 +123,14 @@ def test_batch_norm_kernels_match_float64(torch_gpu, with_res, n, mean, std):
                                   0.99, 1e-3, m_.data_ptr(), inv.data_ptr(), sc.data_ptr(), sh.data_ptr(), C, st))
     check(L.snk_bn_train_apply(y.data_ptr(), sc.data_ptr(), sh.data_ptr(), res.data_ptr() if with_res else None, out.data_ptr(), rows, 1,
                                part.data_ptr(), tail.data_ptr(), st))
-    a, b, c, dg, db = f(C), f(C), f(C), f(C), f(C)
+    a, b, c, dg, db, tail_dx = f(C), f(C), f(C), f(C), f(C), f(4)
     dx, gres = torch.empty_like(y), torch.empty_like(y)
     check(L.snk_bn_train_grad_sums_f64(dout.data_ptr(), out.data_ptr(), y.data_ptr(), m_.data_ptr(), inv.data_ptr(), rows, 1, part.data_ptr(),
                                        sums.data_ptr(), st))
     check(L.snk_bn_train_grad_finalize(sums.data_ptr(), sums.data_ptr(), float(rows), gamma.data_ptr(), inv.data_ptr(), a.data_ptr(),
                                        b.data_ptr(), c.data_ptr(), dg.data_ptr(), db.data_ptr(), C, st))
     check(L.snk_bn_train_grad_apply(dout.data_ptr(), out.data_ptr(), y.data_ptr(), m_.data_ptr(), inv.data_ptr(), a.data_ptr(), b.data_ptr(),
-                                    c.data_ptr(), dx.data_ptr(), gres.data_ptr() if with_res else None, rows, 1, part.data_ptr(), tail.data_ptr(), st))
+                                    c.data_ptr(), dx.data_ptr(), gres.data_ptr() if with_res else None, rows, 1, part.data_ptr(), tail_dx.data_ptr(), st))
 
     y64, g64, b64 = (t.double().requires_grad_(True) for t in (y, gamma, beta))
     r64 = res.double().requires_grad_(True) if with_res else None
@@ -152,7 +153,8 @@ def test_batch_norm_kernels_match_float64(torch_gpu, with_res, n, mean, std):
     assert float((mm.double() - (mm0.double() * 0.99 + m64 * 0.01)).abs().max()) < 1e-5 * max(1.0, abs(mean))
     assert float((mv.double() - (mv0.double() * 0.99 + unb * 0.01)).abs().max()) < 1e-6 * float(unb.max() + 1)
     amax = float(out.abs().max())
-    assert 2048.0 <= amax * float(tail[2]) < 4096.0 and float(tail[2] * tail[3]) == 1.0
+    assert 2048.0 <= amax * float(tail[2]) < 4096.0 and float(tail[2] * tail[3]) == 1.0       # the range handed to the next convolution
+    assert 2048.0 <= float(dx.abs().max()) * float(tail_dx[2]) < 4096.0
 
 
 def _net64(torch, ws, X, Y):
@@ -247,7 +249,7 @@ def test_adam_l2_and_loss_follow_the_keras_formulas(torch_gpu):
     decay = (torch.rand(n, device="cuda", generator=g) < 0.7).to(torch.uint8)
     m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
     w64, m64, v64 = w.double(), m.double(), v.double()
-    part, l2 = torch.empty(512, device="cuda"), torch.empty(1, device="cuda")
+    part, l2 = torch.empty(1024, device="cuda"), torch.empty(1, device="cuda")
     for t in range(1, 4):
         grad = torch.randn(n, device="cuda", generator=g) * 10.0 ** (-t)
         lr = 1e-3 / t
