@@ -56,12 +56,17 @@ __device__ static inline wg_f16x8 wg_join(wg_s4 a, wg_s4 b)
     return c.f;
 }
 
+// hi = f16(v s), lo = f16(v s - hi): s is a power of two, so both are single fused operations on the unscaled value
+// (v_fma_mixlo / mixhi_f16: float32 operands and an f16 addend in, f16 out) -- two instructions per element
 __device__ static inline void wg_split4(float4 v, float s, uint2 &hi, uint2 &lo)
 {
-    const float a[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+    const float a[4] = {v.x, v.y, v.z, v.w};
     union { _Float16 f[4]; uint2 u; } H_, L_;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { H_.f[e] = (_Float16)a[e]; L_.f[e] = (_Float16)(a[e] - (float)H_.f[e]); }
+    for (int e = 0; e < 4; ++e) {
+        H_.f[e] = (_Float16)__builtin_fmaf(a[e], s, 0.0f);
+        L_.f[e] = (_Float16)__builtin_fmaf(a[e], s, -(float)H_.f[e]);
+    }
     hi = H_.u; lo = L_.u;
 }
 
@@ -85,16 +90,16 @@ __global__ __launch_bounds__(512) void k_wgrad_f16s(WgArgs p)
         const int st = tid - 256;
         const float sx = p.x_tail[2], sy = p.dy_tail[2];
         const float invW = 1.0f / (float)W;
-        int xl[WG_MAXX], xg[WG_MAXX], xr[WG_MAXX];                    // LDS byte offset, element offset in the slab, slab row
-        int yl[WG_MAXY], yg[WG_MAXY], yr[WG_MAXY];
+        int xl[WG_MAXX], xg[WG_MAXX];                                 // LDS byte offset, byte offset inside the image (slab at row 0)
+        int yl[WG_MAXY], yg[WG_MAXY];
+        // items past the slab's last one repeat it (same value to the same LDS address): no predication, no branches
 #pragma unroll
         for (int j = 0; j < WG_MAXX; ++j) {
             const int it = min(st + 256 * j, p.nx_items - 1);
             const int pix = it >> 3, c4 = it & 7;
             const int yy = (int)(((float)pix + 0.5f) * invW), xx = pix - yy * W;      // yy = 0 .. RB + 1: image row r0 - 1 + yy
             xl[j] = (WG_GX + yy * P + xx) * 64 + 8 * c4;
-            xg[j] = (yy * W + xx) * 128 + 4 * c4;
-            xr[j] = st + 256 * j < p.nx_items ? yy : -100000;
+            xg[j] = (((yy - 1) * W + xx) * 128 + 4 * c4) * 4;
         }
 #pragma unroll
         for (int j = 0; j < WG_MAXY; ++j) {
@@ -102,44 +107,42 @@ __global__ __launch_bounds__(512) void k_wgrad_f16s(WgArgs p)
             const int pix = it >> 3, c4 = it & 7;
             const int yy = (int)(((float)pix + 0.5f) * invW), xx = pix - yy * W;      // yy = 0 .. RB - 1: image row r0 + yy
             yl[j] = (yy * P + xx) * 64 + 8 * c4;
-            yg[j] = (yy * W + xx) * 128 + 4 * c4;
-            yr[j] = st + 256 * j < p.ny_items ? yy : -100000;
+            yg[j] = ((yy * W + xx) * 128 + 4 * c4) * 4;
         }
         float4 xv[WG_MAXX], yv[WG_MAXY];
-        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        auto fetch = [&](int t) {                                     // slab t of this block -> registers (rows outside the image: zeros)
-            const int n = n0 + t / p.n_slabs, r0 = (t % p.n_slabs) * p.RB;
-            const float *xn = p.x + ((long)n * H + (r0 - 1)) * W * 128 + 32 * cs;
-            const float *yn = p.dy + ((long)n * H + r0) * W * 128 + 32 * os;
+        // One buffer descriptor per image and tensor: rows above the image have negative offsets, rows below it offsets past
+        // the image's bytes -- the hardware's range check returns zeros for both, which is exactly the padding the taps need
+        const int img_bytes = H * W * 128 * 4;
+        auto fetch = [&](int t) {                                     // slab t of this block -> registers
+            const int n = __builtin_amdgcn_readfirstlane(n0 + t / p.n_slabs);
+            const int slab = __builtin_amdgcn_readfirstlane((t % p.n_slabs) * p.RB * W * 128 * 4);
+            const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + (long)n * H * W * 128 + 32 * cs), 0, img_bytes - 128 * cs, 0x00020000);
+            const auto ry = __builtin_amdgcn_make_buffer_rsrc((void *)(p.dy + (long)n * H * W * 128 + 32 * os), 0, img_bytes - 128 * os, 0x00020000);
 #pragma unroll
             for (int j = 0; j < WG_MAXX; ++j) {
-                const int row = r0 - 1 + xr[j];
-                xv[j] = zero4;
-                if (row >= 0 && row < H) xv[j] = *(const float4 *)(xn + xg[j]);
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(rx, xg[j] + slab, 0, 0);
+                xv[j] = __builtin_bit_cast(float4, v);
             }
 #pragma unroll
             for (int j = 0; j < WG_MAXY; ++j) {
-                const int row = r0 + yr[j];
-                yv[j] = zero4;
-                if (row >= 0 && row < H) yv[j] = *(const float4 *)(yn + yg[j]);
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(ry, yg[j] + slab, 0, 0);
+                yv[j] = __builtin_bit_cast(float4, v);
             }
         };
         auto store = [&](int b) {                                     // registers -> buffer b, split into f16 hi / lo
             unsigned char *XH = smem + b * buf_bytes, *XL = XH + p.rows_x * 64, *YH = XL + p.rows_x * 64, *YL = YH + y_rows * 64;
 #pragma unroll
-            for (int j = 0; j < WG_MAXX; ++j)
-                if (xr[j] >= 0) {
-                    uint2 hi, lo;
-                    wg_split4(xv[j], sx, hi, lo);
-                    *(uint2 *)(XH + xl[j]) = hi; *(uint2 *)(XL + xl[j]) = lo;
-                }
+            for (int j = 0; j < WG_MAXX; ++j) {
+                uint2 hi, lo;
+                wg_split4(xv[j], sx, hi, lo);
+                *(uint2 *)(XH + xl[j]) = hi; *(uint2 *)(XL + xl[j]) = lo;
+            }
 #pragma unroll
-            for (int j = 0; j < WG_MAXY; ++j)
-                if (yr[j] >= 0) {
-                    uint2 hi, lo;
-                    wg_split4(yv[j], sy, hi, lo);
-                    *(uint2 *)(YH + yl[j]) = hi; *(uint2 *)(YL + yl[j]) = lo;
-                }
+            for (int j = 0; j < WG_MAXY; ++j) {
+                uint2 hi, lo;
+                wg_split4(yv[j], sy, hi, lo);
+                *(uint2 *)(YH + yl[j]) = hi; *(uint2 *)(YL + yl[j]) = lo;
+            }
         };
         if (T > 0) fetch(0);
         __syncthreads();                                              // the zero fill is complete

@@ -65,6 +65,29 @@ def activation_scales(weights, target_log2=9):
     return scales
 
 
+class ClockProbe:
+    """Samples of the shader clock while other streams work (csrc/probe.hip): every `launch` puts one wavefront on a
+    stream of its own that sits on a compute unit for `microseconds` and records shader cycles against the constant
+    100 MHz counter.  `mhz()` -> the samples taken so far."""
+
+    def __init__(self, device, capacity=8192, microseconds=200):
+        self.L = lib()
+        self.buf = torch.zeros((capacity, 2), dtype=torch.int64, device=device)
+        self.stream = torch.cuda.Stream(device=device)
+        self.us, self.n = int(microseconds), 0
+
+    def launch(self):
+        if self.n < self.buf.shape[0]:
+            check(self.L.snk_clock_probe(self.buf[self.n].data_ptr(), self.us, self.stream.cuda_stream))
+            self.n += 1
+
+    def mhz(self):
+        self.stream.synchronize()
+        a = self.buf[:self.n].cpu().numpy().astype(np.float64)
+        a = a[a[:, 1] > 0]
+        return a[:, 0] / a[:, 1] * 100.0
+
+
 def n_blocks_of(weights):
     return (len(weights) - 14) // 10
 
@@ -81,6 +104,7 @@ class QNet:
         self.max_chunk = int(max_chunk)
         self._ws = None
         self.conv_timing = None      # set to a list to collect (start_event, end_event, flops) per conv3x3 launch
+        self.clock_probe = None      # set to a ClockProbe to sample the chip's clock beside every forward chunk
         # "f16s" (default): float32-accurate split-f16 MFMA kernel (csrc/conv_split.hip); "winograd": F(2x2,3x3) fp32 MFMA
         # kernel; "direct": implicit-GEMM fp32 MFMA kernel; reduced precision for configs[4], NOT within the 1e-5 parity
         # tolerance: "f16" (the f16s kernel with the hi parts only, one MFMA per product) and "bf16" (im2col bf16 MFMA)
@@ -287,6 +311,8 @@ class QNet:
                              0 if mk is None else mk.data_ptr(), out[s0:s0 + m].data_ptr(), m, h, w, st))
 
     def _forward_chunk(self, planes, mask, out, s0, m, k):
+        if self.clock_probe is not None:          # bench.py: a one-wavefront clock sample beside this chunk's kernels
+            self.clock_probe.launch()
         if self.conv_algo == "f16a" and self.blocks > 0:
             return self._forward_chunk_f16a(planes, mask, out, s0, m, k)
         st = torch.cuda.current_stream().cuda_stream

@@ -7,7 +7,7 @@ training=True (trainer.py:52), Glorot-initialised gen-0 net (seed 0), synthetic 
 One "step" = one root turn of MPGameRunner.run over all live games (mp_game_runner.py:31-68): the full
 MCTS behind every root Game.tic.  value = root env-steps of all ranks / max-over-ranks wall time.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--games G] [--breadth B] [--no-cpu-baseline]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--games G | --games-total T] [--breadth B] [--no-cpu-baseline]
 N > 1: one rank per GPU, either under torch.distributed.run (RANK / WORLD_SIZE in the environment) or started by
 this script itself (`python bench.py --gpus N` spawns N fresh rank processes before touching the GPU and relays
 rank 0's JSON line).  Games shard across ranks (weak scaling: G games per GPU), no collective in the self-play
@@ -253,6 +253,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--games", type=int, default=4096, help="parallel root games per GPU")
+    ap.add_argument("--games-total", type=int, default=None,
+                    help="root games of the whole job, split evenly over the GPUs (BASELINE configs[3]: --gpus 8 --games-total 262144 "
+                         "--breadth 200); overrides --games; the run is then strong scaling")
     ap.add_argument("--breadth", type=int, default=50)
     ap.add_argument("--chunk", type=int, default=8192, help="states per net forward chunk")
     ap.add_argument("--conv-algo", choices=["winograd", "direct", "bf16", "f16s", "f16", "f16a"], default=None,
@@ -267,6 +270,10 @@ def main():
     ap.add_argument("--no-kernel-rooflines", action="store_true")
     args = ap.parse_args()
 
+    if args.games_total is not None:
+        if args.games_total % args.gpus:
+            sys.exit(f"bench.py: --games-total {args.games_total} does not split evenly over {args.gpus} GPUs")
+        args.games = args.games_total // args.gpus
     if args.gpus > 1 and "RANK" not in os.environ:
         # `python bench.py --gpus N` without a launcher: this process stays off the GPU (nothing above touches it;
         # torch.cuda.device_count() does not initialise HIP on this image) and starts N fresh rank processes.
@@ -326,31 +333,60 @@ def main():
     m = alice._mcts
     ev0, sim0 = (m.stats["net_evals"], m.stats["sim_steps"]) if m is not None else (0, 0)     # --warmup 0: nothing ran yet
     nnet._qnet.conv_timing = None if args.no_conv_timing else []
+    probe = net.ClockProbe(torch.device("cuda", dev_index)) if rank == 0 else None
+    nnet._qnet.clock_probe = probe
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
+
+    def sync_clock():
+        torch.cuda.synchronize()
+        return time.time()
     barrier()
     t0 = time.time()
-    gr.run(alice, max_turns=args.steps)
-    env_steps = gr.env_steps
-    # iteration-end exchange (trainer.py:63-75 across ranks): sampled rows all-gathered, counters all-reduced
+    env_steps = 0
+    for k in range(args.steps):                # one root turn per call: the same launches, plus a progress line per step
+        gr.run(alice, max_turns=1)
+        env_steps += gr.env_steps
+        if rank == 0:
+            log(f"[rank 0] step {k + 1}/{args.steps}: {gr.env_steps} env-steps, {time.time() - t0:.1f} s since the start of the timed region")
+    t_play = sync_clock() - t0
+    # iteration-end exchange (trainer.py:63-75 across ranks): the row count comes from the records of ALL ranks, every rank
+    # sends its share of the sampled rows (all-gather), the six log counters are all-reduced
+    n_rec = torch.tensor([len(alice.records)], dtype=torch.int64, device=coll_dev)
+    if world > 1:
+        dist.all_reduce(n_rec)
+    wanted, _, share = sdist.sample_plan(max(int(n_rec.item()), world), world)
     rng = np.random.RandomState(rank)
-    idx, share = sdist.sample_share(len(alice.records), 5 * 2048, world, rng)
+    idx, share = sdist.sample_share(len(alice.records), wanted, world, rng)
     X = alice.records.fetch_device(idx) if len(idx) else torch.zeros((share, OBS, OBS, 3), dtype=torch.float32, device="cuda")
     if X.shape[0] < share:
         X = torch.cat([X, X.new_zeros((share - X.shape[0], OBS, OBS, 3))])
     Vs = torch.as_tensor(alice._values_host()[idx] if len(idx) else np.zeros((share, 3), np.float32), device="cuda")
     if Vs.shape[0] < share:
         Vs = torch.cat([Vs, Vs.new_zeros((share - Vs.shape[0], 3))])
+    t1 = sync_clock()
     Xg, Vg = sdist.all_gather_samples(X, Vs)
+    t2 = sync_clock()
     sdist.all_reduce_counters(gr.engine.sum_counters(), args.games, "cuda")
+    t3 = sync_clock()
+    wall_rank = t3 - t0                        # this rank's own time, before it waits for the others
     barrier()
     dt = time.time() - t0
-    tt = torch.tensor([dt, float(env_steps)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-    if world > 1:
-        tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt, env_steps = float(tmax[0].item()), float(tsum[1].item())
     m = alice._mcts
     evals = m.stats["net_evals"] - ev0
     sims = m.stats["sim_steps"] - sim0
+    # per-rank figures for reading a scaling curve: every rank's env-steps, self-play time, sampling, the two collectives
+    mine = torch.tensor([float(env_steps), t_play, t1 - t0 - t_play, t2 - t1, t3 - t2, wall_rank, float(evals), float(len(alice.records))],
+                        dtype=torch.float64, device=coll_dev)
+    per_rank = mine.unsqueeze(0)
+    if world > 1:
+        per_rank = torch.empty((world, mine.numel()), dtype=torch.float64, device=coll_dev)
+        dist.all_gather_into_tensor(per_rank, mine)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    per_rank = per_rank.cpu().numpy()
+    env_steps_rank0 = env_steps
+    env_steps = float(per_rank[:, 0].sum())
 
     if rank == 0:
         tm = nnet._qnet.conv_timing or []
@@ -370,7 +406,8 @@ def main():
         res = {
             "metric": "self-play env-steps/sec (11x11, 4 snakes, 50 MCTS sims)",
             "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if args.games_total is not None else "weak", "vs_baseline": None,
             "dtype": {"bf16": "bf16 operands, f32 accumulate (outside the 1e-5 parity tolerance)",
                       "f16": "f16 operands, f32 accumulate (outside the 1e-5 parity tolerance)",
                       "f16a": "f16 operands and f16 activations in HBM, f32 accumulate (outside the 1e-5 parity tolerance)",
@@ -381,7 +418,8 @@ def main():
                                    f"{args.breadth} (= {args.breadth // 8 * 8} rollouts), depth 8, health_dec 1, softmax_base 2, "
                                    "training=True, gen-0 Glorot net (seed 0), fp32 Q-net",
                        "games_per_gpu": args.games, "breadth": args.breadth, "parallelism": f"games sharded x{world}", "dist_backend": backend if world > 1 else None,
-                       "net_evals_per_env_step": evals / max(1, gr.env_steps), "sim_steps_per_env_step": sims / max(1, gr.env_steps),
+                       "games_total": args.games * world,
+                       "net_evals_per_env_step": evals / max(1, env_steps_rank0), "sim_steps_per_env_step": sims / max(1, env_steps_rank0),
                        "net_evals_per_s_rank0": evals / dt, "sample_rows_gathered": int(Xg.shape[0]),
                        "graph_replays": m.stats.get("graph_replays", 0)},
             "roofline": {"bound": "mfma",
@@ -403,7 +441,24 @@ def main():
                                                    algo, "implicit GEMM on v_mfma_f32_32x32x2_f32"),
                          "avg_launch_ms": conv_s / max(1, len(tm)) * 1e3,
                          "share_of_step_time": conv_s / dt},
+            # what a non-linear scaling curve is made of: one row per rank (rank r = GPU r of the node)
+            "ranks": [{"rank": r, "env_steps": int(v[0]), "self_play_s": v[1], "sample_rows_s": v[2], "all_gather_s": v[3],
+                       "all_reduce_s": v[4], "wall_s": v[5], "env_steps_per_s": v[0] / v[5], "net_evals": int(v[6]),
+                       "records": int(v[7])} for r, v in enumerate(per_rank)],
+            "exchange": {"dist_backend": backend if world > 1 else None, "rows_per_rank": int(share), "rows_gathered": int(Xg.shape[0]),
+                         "bytes_per_rank": int(share) * (OBS * OBS * 3 + 3) * 4,
+                         "all_gather_s_max": float(per_rank[:, 3].max()), "all_reduce_s_max": float(per_rank[:, 4].max())},
         }
+        clk = probe.mhz() if probe is not None else np.zeros(0)
+        nnet._qnet.clock_probe = None
+        if len(clk):
+            held = float(np.median(clk))
+            res["roofline"]["clock_mhz"] = {"median": held, "p10": float(np.percentile(clk, 10)), "p90": float(np.percentile(clk, 90)),
+                                            "samples": int(len(clk)), "nominal": 2400.0,
+                                            "how": "one-wavefront probe kernel on its own stream beside every forward chunk: "
+                                                   "s_memtime / s_memrealtime x 100 MHz over 200 us (csrc/probe.hip)"}
+            if res["roofline"]["executed_frac"]:
+                res["roofline"]["executed_frac_of_held_clock_peak"] = res["roofline"]["executed_frac"] * 2400.0 / held
         if not args.no_kernel_rooflines and world == 1 and judged:
             del alice, gr
             torch.cuda.empty_cache()

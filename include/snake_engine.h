@@ -398,6 +398,11 @@ int snk_adam_l2_step(float *d_w, const float *d_g, float *d_m, float *d_v, const
                      double beta1, double beta2, double epsilon, double l2, void *stream);
 int snk_l2_sum(const float *d_w, const uint8_t *d_decay, long n, double scale, float *d_partials, float *d_out, void *stream);
 
+/* Measurement aid (bench.py): one wavefront that sits on a compute unit for ~microseconds and reports d_out[0] = shader cycles
+ * (s_memtime) and d_out[1] = ticks of the constant 100 MHz counter (s_memrealtime) that passed meanwhile: launched on its
+ * own stream beside the measured kernels it gives the clock the chip holds under their load, cycles / ticks x 100 MHz. */
+int snk_clock_probe(uint64_t *d_out, int microseconds, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

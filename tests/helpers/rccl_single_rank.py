@@ -23,6 +23,15 @@ dist.all_reduce(t, op=dist.ReduceOp.MAX)                                        
 flat = torch.rand(1_244_807 + 1, device="cuda")                                   # the trainer's one gradient bucket
 ref = flat.clone()
 dist.all_reduce(flat)
+sums = torch.rand(256, dtype=torch.float64, device="cuda")                        # the training step's batch-norm sums (float64)
+sums_ref = sums.clone()
+dist.all_reduce(sums)
+n_rec = torch.tensor([4711], dtype=torch.int64, device="cuda")                    # record counts of all ranks -> the sample plan
+dist.all_reduce(n_rec)
+mine = torch.arange(8, dtype=torch.float64, device="cuda")                        # bench.py's per-rank row
+rows = torch.empty((1, 8), dtype=torch.float64, device="cuda")
+dist.all_gather_into_tensor(rows, mine)
+assert torch.equal(sums, sums_ref) and int(n_rec) == 4711 and torch.equal(rows[0], mine)
 seed = torch.tensor([123], dtype=torch.int64, device="cuda")
 dist.broadcast(seed, 0)
 dist.barrier()

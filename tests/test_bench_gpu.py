@@ -29,6 +29,9 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and r["kernel"] == "k_conv3x3_f16s" and r["achieved"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
+    clk = r["clock_mhz"]                                            # the clock the chip held beside the measured kernels
+    assert clk["samples"] >= 1 and 500.0 < clk["p10"] <= clk["median"] <= clk["p90"] < 2700.0
+    assert len(d["ranks"]) == 1 and d["ranks"][0]["env_steps"] == 32 and d["exchange"]["dist_backend"] is None
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "env-steps/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     for k in ("step", "clone", "observe"):
@@ -48,11 +51,35 @@ def test_bench_gpus_2_launches_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2
     assert d["config"]["games_per_gpu"] == 16 and d["config"]["parallelism"] == "games sharded x2"
-    assert d["config"]["sample_rows_gathered"] == 10240            # 2 x 5120 rows all-gathered
+    # the row count of the exchange follows trainer.py:63-72 on the records of BOTH ranks: 2 turns x 16 games x 4 snakes each,
+    # fewer than one batch of 2 048 -> all 256 rows form the batch, 128 from each rank
+    assert d["config"]["sample_rows_gathered"] == 256 and d["exchange"]["rows_per_rank"] == 128
+    assert d["exchange"]["dist_backend"] in ("nccl", "gloo") and d["exchange"]["bytes_per_rank"] == 128 * (21 * 21 * 3 + 3) * 4
+    assert d["exchange"]["all_gather_s_max"] > 0 and d["exchange"]["all_reduce_s_max"] > 0
+    # one row per rank: what a scaling curve is read with
+    assert [r["rank"] for r in d["ranks"]] == [0, 1]
+    for r in d["ranks"]:
+        assert r["env_steps"] == 32 and r["records"] == 128 and r["net_evals"] > 0
+        assert 0 < r["self_play_s"] <= r["wall_s"] <= d["ms_per_step"] * 2e-3 * 1.001
+        assert r["all_gather_s"] > 0 and r["all_reduce_s"] > 0 and r["env_steps_per_s"] > 0
     # whole-job value: both ranks' root env-steps (2 turns x 16 games each, nobody dies in two turns) over the slowest rank's time
     assert abs(d["value"] - 2 * 2 * 16 / (d["ms_per_step"] * 2e-3)) / d["value"] < 0.05
     assert "cpu_baseline" not in d                                 # rank 0 at N = 1 only
     assert d["config"]["dist_backend"] in ("nccl", "gloo")
+
+
+def test_bench_games_total_splits_the_job_over_the_ranks():
+    """--games-total T (BASELINE configs[3] is `--gpus 8 --games-total 262144 --breadth 200`): T / N games per GPU, strong scaling"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--games-total", "24", "--breadth", "8",
+                          "--steps", "1", "--warmup", "1", "--no-conv-timing"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip()][0])
+    assert d["scaling"] == "strong" and d["config"]["games_per_gpu"] == 12 and d["config"]["games_total"] == 24
+    assert sum(r["env_steps"] for r in d["ranks"]) == 24
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--games-total", "25"], capture_output=True,
+                         text=True, env=env, timeout=120)
+    assert out.returncode != 0 and "does not split evenly" in out.stderr
 
 
 def test_bench_refuses_a_world_size_mismatch_before_touching_the_gpu():
