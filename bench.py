@@ -379,8 +379,9 @@ def main():
                         dtype=torch.float64, device=coll_dev)
     per_rank = mine.unsqueeze(0)
     if world > 1:
-        per_rank = torch.empty((world, mine.numel()), dtype=torch.float64, device=coll_dev)
-        dist.all_gather_into_tensor(per_rank, mine)
+        flat_rows = torch.empty(world * mine.numel(), dtype=torch.float64, device=coll_dev)
+        dist.all_gather_into_tensor(flat_rows, mine)
+        per_rank = flat_rows.view(world, mine.numel())
         tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())

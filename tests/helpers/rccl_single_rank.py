@@ -29,9 +29,9 @@ dist.all_reduce(sums)
 n_rec = torch.tensor([4711], dtype=torch.int64, device="cuda")                    # record counts of all ranks -> the sample plan
 dist.all_reduce(n_rec)
 mine = torch.arange(8, dtype=torch.float64, device="cuda")                        # bench.py's per-rank row
-rows = torch.empty((1, 8), dtype=torch.float64, device="cuda")
+rows = torch.empty(8, dtype=torch.float64, device="cuda")
 dist.all_gather_into_tensor(rows, mine)
-assert torch.equal(sums, sums_ref) and int(n_rec) == 4711 and torch.equal(rows[0], mine)
+assert torch.equal(sums, sums_ref) and int(n_rec) == 4711 and torch.equal(rows, mine)
 seed = torch.tensor([123], dtype=torch.int64, device="cuda")
 dist.broadcast(seed, 0)
 dist.barrier()

@@ -51,15 +51,15 @@ def test_bench_gpus_2_launches_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2
     assert d["config"]["games_per_gpu"] == 16 and d["config"]["parallelism"] == "games sharded x2"
-    # the row count of the exchange follows trainer.py:63-72 on the records of BOTH ranks: 2 turns x 16 games x 4 snakes each,
-    # fewer than one batch of 2 048 -> all 256 rows form the batch, 128 from each rank
-    assert d["config"]["sample_rows_gathered"] == 256 and d["exchange"]["rows_per_rank"] == 128
-    assert d["exchange"]["dist_backend"] in ("nccl", "gloo") and d["exchange"]["bytes_per_rank"] == 128 * (21 * 21 * 3 + 3) * 4
+    # the row count of the exchange follows trainer.py:63-72 on the records of BOTH ranks: (1 warm-up + 2 timed) turns x 16 games
+    # x 4 snakes each, fewer than one batch of 2 048 -> all 384 rows form the batch, 192 from each rank
+    assert d["config"]["sample_rows_gathered"] == 384 and d["exchange"]["rows_per_rank"] == 192
+    assert d["exchange"]["dist_backend"] in ("nccl", "gloo") and d["exchange"]["bytes_per_rank"] == 192 * (21 * 21 * 3 + 3) * 4
     assert d["exchange"]["all_gather_s_max"] > 0 and d["exchange"]["all_reduce_s_max"] > 0
     # one row per rank: what a scaling curve is read with
     assert [r["rank"] for r in d["ranks"]] == [0, 1]
     for r in d["ranks"]:
-        assert r["env_steps"] == 32 and r["records"] == 128 and r["net_evals"] > 0
+        assert r["env_steps"] == 32 and r["records"] == 192 and r["net_evals"] > 0
         assert 0 < r["self_play_s"] <= r["wall_s"] <= d["ms_per_step"] * 2e-3 * 1.001
         assert r["all_gather_s"] > 0 and r["all_reduce_s"] > 0 and r["env_steps_per_s"] > 0
     # whole-job value: both ranks' root env-steps (2 turns x 16 games each, nobody dies in two turns) over the slowest rank's time
