@@ -215,6 +215,7 @@ class QNet:
         limit: a net whose moving statistics do not describe its activations (freshly trained, loaded from a checkpoint)
         gets scales from data instead.  Returns the activation report."""
         if self.conv_algo not in ("f16s", "f16"):
+            self.calibrated = True              # nothing to fit: callers must not come back with observations every turn
             return []
         rep = self.activation_report(planes)
         for i, (amax, scale, _) in enumerate(rep):

@@ -23,7 +23,19 @@ os.chdir(out_dir)
 MPGameRunner.verbose = False
 nnet = AlphaNNet(input_shape=(21, 21, 3), _weights=glorot_uniform_weights((21, 21, 3), 4, seed=0))
 trainer = AlphaSnakeZeroTrainer(10, 4, 8, 1e-3, 0.98, 11, 11, 4, None)
+collect = trainer._collect
+seen = {}
+
+
+def counting_collect(alice):
+    seen["records"] = len(alice.records)
+    X, V, batch = collect(alice)
+    seen["rows"], seen["batch"] = len(X), batch
+    return X, V, batch
+trainer._collect = counting_collect
 last = trainer.train(nnet, name="dp", iteration=0, max_iterations=1)
+import json
+json.dump(seen, open(os.path.join(out_dir, f"collect_r{rank}.json"), "w"))
 np.savez(os.path.join(out_dir, f"weights_r{rank}.npz"), *last.v_net.get_weights())
 dist.barrier()
 dist.destroy_process_group()

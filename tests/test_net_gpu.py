@@ -449,6 +449,39 @@ def test_agent_calibrates_new_weights_and_checks_the_range_every_turn(env, monke
     assert nn_._qnet.calibrated and nn_._qnet.range_flags() == [0] * 8 and gr.env_steps == 16
 
 
+def test_agent_recovers_from_a_tripped_range_guard_inside_a_root_turn(env, monkeypatch):
+    """scales that are far too large for the activations (set after the calibration, as a weight update would leave them):
+    the first search of the turn clamps, the guard widens the scales, the agent forgets the table and searches the turn
+    again -- make_moves returns moves computed from float32-accurate values instead of raising into the training loop"""
+    torch, se, net = env
+    monkeypatch.setenv("SNK_CONV_ALGO", "f16s")
+    from utils.agent import Agent
+    from utils.alpha_nnet import AlphaNNet
+    from utils.mp_game_runner import MPGameRunner
+    MPGameRunner.verbose = False
+    ws = net.glorot_uniform_weights((21, 21, 3), blocks=4, seed=2)
+    nn_ = AlphaNNet(input_shape=(21, 21, 3), _weights=ws)
+    alice = Agent(nn_, 2, True, 4, 8, seed=3)
+    gr = MPGameRunner(11, 11, 4, 1, 8, seed=5)
+    gr.run(alice, max_turns=1)                                      # calibrates
+    good = list(nn_._qnet.conv_x_scale)
+    nn_._qnet.set_x_scale(3, good[3] * 2.0 ** 12)                   # far beyond the f16 range for this layer's inputs
+    searches = []
+    orig = alice._mcts.search
+    alice._mcts.search = lambda *a, **k: (searches.append(1), orig(*a, **k))[1]
+    gr.run(alice, max_turns=1)
+    assert len(searches) == 2, "one clamped search, one repeated with the widened scale"
+    assert nn_._qnet.conv_x_scale[3] == good[3] * 64.0 and nn_._qnet.range_flags() == [0] * 8
+    gr.run(alice, max_turns=1)
+    assert len(searches) == 3 and gr.env_steps == 8
+    # a net without a range to watch is "calibrated" at once: no observation pass per root turn
+    monkeypatch.setenv("SNK_CONV_ALGO", "winograd")
+    nw = AlphaNNet(input_shape=(21, 21, 3), _weights=ws)
+    assert not nw._qnet.calibrated
+    nw.calibrate(torch.zeros((1, 21, 21, 3), device="cuda"))
+    assert nw._qnet.calibrated
+
+
 def test_f16_activation_tower_layer_and_net(env, monkeypatch):
     """configs[4]'s fastest reduced-precision option (`SNK_CONV_ALGO=f16a`): f16 operands AND f16 activations in HBM.
     One layer against a float64 convolution of the same f16 inputs (f16 output: within half an f16 ulp + float32 rounding;

@@ -214,6 +214,15 @@ def test_trainer_generation_on_two_ranks(tmp_path):
     vals = [float(v) for v in lines[2].split(", ")[1:]]
     assert abs(vals[5] * 10 - round(vals[5] * 10)) < 1e-9            # game_length averaged over all 10 games
     assert os.path.exists(tmp_path / "models" / "dp1.h5") and not os.path.exists(tmp_path / "models" / "dp2.h5")
+    # the rows the fit gets = what ONE process would sample from the same total number of records (trainer.py:63-72),
+    # times two for the mirror images -- not what the smaller rank's count alone would give
+    import json
+    from snake_engine.dist import sample_plan
+    c0, c1 = (json.load(open(tmp_path / f"collect_r{r}.json")) for r in range(2))
+    total = c0["records"] + c1["records"]
+    wanted, batch, _ = sample_plan(total, 2)
+    assert c0["rows"] == c1["rows"] == 2 * wanted and c0["batch"] == c1["batch"] == batch
+    assert wanted == ((total // 2) * 2 if total < 2048 else 2048 * min(5, total // 2048))
 
 
 def test_pit_scripts_call_sequence_with_real_nets(tmp_path, monkeypatch):
