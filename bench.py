@@ -400,7 +400,7 @@ def main():
         # MFMA flops the kernel executes per algorithmic (direct-convolution) flop
         executed = {"f16s": 3.0 * 448 / 441, "f16": 448 / 441.0, "f16a": 448 / 441.0, "winograd": 16 * 121 / (441 * 9.0)}.get(algo, 1.0)
         traffic = None      # HBM bytes per average launch, from the committed rocprofv3 --pmc passes (profiles/)
-        tfile = os.path.join(REPO, "profiles", {"f16s": "r2_conv_f16s_traffic.json", "winograd": "r1_conv_traffic.json"}.get(algo, "none"))
+        tfile = os.path.join(REPO, "profiles", {"f16s": "r3_conv_f16s_traffic.json", "winograd": "r1_conv_traffic.json"}.get(algo, "none"))
         if os.path.exists(tfile) and tm:
             per_state_layer = json.load(open(tfile))["hbm_bytes_per_state_layer"]
             traffic = per_state_layer * (conv_flops / len(tm)) / (2.0 * 441 * 9 * 128 * 128) if judged else None

@@ -199,20 +199,21 @@ def _net64(torch, ws, X, Y):
     return float(loss), dict(zip(pidx, grads)), pre, q.detach(), n_conv
 
 
-@pytest.mark.parametrize("n,blocks", [(40, 2), (23, 4)])
-def test_one_whole_step_matches_float64_with_the_same_relu_masks(torch_gpu, n, blocks):
+@pytest.mark.parametrize("n,blocks,hw", [(40, 2, 21), (23, 4, 21), (5, 1, 37), (9, 1, 13)])
+def test_one_whole_step_matches_float64_with_the_same_relu_masks(torch_gpu, n, blocks, hw):
+    """hw = 37: BASELINE configs[4]'s 19 x 19 board (its weight gradient runs in slabs of five image rows), 13: a 7 x 7 board"""
     torch = torch_gpu
     from snake_engine import net
     from snake_engine.train_step import TrainStep
     rs = np.random.RandomState(5 + n)
-    X = rs.rand(n, 21, 21, 3).astype(np.float32)
+    X = rs.rand(n, hw, hw, 3).astype(np.float32)
     Y = np.tanh(rs.randn(n, 3)).astype(np.float32)
-    ws = net.glorot_uniform_weights((21, 21, 3), blocks=blocks, seed=9)
+    ws = net.glorot_uniform_weights((hw, hw, 3), blocks=blocks, seed=9)
     for l in range(2 + 2 * blocks):                         # batch-norm parameters away from their initial 1 / 0
         ws[5 * l + 1] = (ws[5 * l + 1] * (0.6 + 0.8 * rs.rand(*ws[5 * l + 1].shape))).astype(np.float32)
         ws[5 * l + 2] = (0.2 * rs.randn(*ws[5 * l + 2].shape)).astype(np.float32)
     loss64, g64, pre, q64, n_conv = _net64(torch, ws, X, Y)
-    ts = TrainStep(ws, (21, 21, 3), n, "cuda")
+    ts = TrainStep(ws, (hw, hw, 3), n, "cuda")
     x, y = torch.as_tensor(X, device="cuda"), torch.as_tensor(Y, device="cuda")
     q = ts.forward(x, y, n)
     assert float((q.double() - q64).abs().max()) < 1e-5
@@ -329,3 +330,33 @@ np.savez(sys.argv[1], hist=np.array(trainer_torch.fit.last_history), q=q, mode=t
     assert len(h_a) == 3 and h_a[2] < h_a[0]                                    # it trains
     assert np.abs(h_a - h_b).max() / np.abs(h_b).max() < 1e-2, (h_a, h_b)
     assert np.abs(q_a - q_b).max() < 5e-2 and np.abs(q_a - q_b).mean() < 5e-3, (np.abs(q_a - q_b).max(), np.abs(q_a - q_b).mean())
+
+
+def test_two_rank_fit_on_the_kernels_equals_the_one_rank_fit(torch_gpu, tmp_path):
+    """data-parallel fit (rows r::2 of every batch per rank, float64 batch-norm sums and ONE gradient bucket all-reduced, here
+    over gloo with both ranks on the box's GPU) against the same fit in one process: both ranks end bit-identical, and equal to
+    the one-rank result up to float32 summation order -- 6 optimizer steps, the last one at rate 0 (forward only)"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import REPO
+    helper = os.path.join(REPO, "tests", "helpers", "fit_rank.py")
+    env1 = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, helper, str(tmp_path)], env=env1, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = [subprocess.Popen([sys.executable, helper, str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                              env=dict(env1, RANK=str(k), WORLD_SIZE="2", LOCAL_RANK=str(k), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
+             for k in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[0][-2000:] + outs[1][-2000:]
+    one, a, b = (np.load(tmp_path / f) for f in ("fit_w1_r0.npz", "fit_w2_r0.npz", "fit_w2_r1.npz"))
+    keys = [k for k in one.files if k != "hist"]
+    for k in keys:
+        assert np.array_equal(a[k], b[k]), k                                         # the ranks agree bit for bit
+        # every weight moved by up to 6 x 1e-3 (Adam's first steps are +- the rate); the two runs may part by a percent of that
+        assert float(np.abs(a[k] - one[k]).max()) <= 1e-4 * max(1.0, float(np.abs(one[k]).max())), (k, float(np.abs(a[k] - one[k]).max()))
+    assert np.allclose(a["hist"], one["hist"], rtol=1e-3) and np.array_equal(a["hist"], b["hist"])
+    moved = max(float(np.abs(one[k] - w).max()) for k, w in zip(keys, __import__("snake_engine.net", fromlist=["x"]).glorot_uniform_weights((21, 21, 3), blocks=2, seed=5)))
+    assert moved > 1e-3                                                               # it trained
