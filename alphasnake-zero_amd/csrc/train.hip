@@ -3,10 +3,13 @@
 // model.fit), fused with the ReLU and the residual add around it, forward and backward.  Activations are channels-last
 // float32 [rows = n * h * w][128]; a thread owns four channels (one float4 column) of every eighth row of its block's share.
 //
-//   forward   k_bn_sums           per-channel sum and sum of squares          (1 read)
-//             k_bn_apply          out = act(y * scale + shift (+ residual))    (1-2 reads, 1 write)
-//   backward  k_bn_grad_sums      per-channel sum(g), sum(g * xhat), g = dout masked by the ReLU   (2-3 reads)
-//             k_bn_grad_apply     dx = a (g - b - xhat c)  (+ g itself for the residual branch)    (2-3 reads, 1-2 writes)
+//   forward   k_bn_sums_c         per-channel sums about the moving mean (train_net.hip)           (1 read)
+//             k_bn_apply          out = act(y * scale + shift (+ residual)), + 1 bit per element: out > 0   (1-2 reads, 1 write)
+//   backward  k_bn_grad_sums      per-channel sum(g), sum(g * xhat), g = dout masked by the ReLU   (2 reads + the bits)
+//             k_bn_grad_apply     dx = a (g - b - xhat c)  (+ g itself for the residual branch)    (2 reads + the bits, 1-2 writes)
+// The ReLU mask travels as one BYTE per thread-quad of channels (4 bits used: 29 MB per layer at 2 048 x 21 x 21 instead of
+// re-reading the 462 MB activation in both backward kernels); a caller may still hand the activation itself (or any tensor
+// whose sign is the mask) instead.
 //
 // The reductions are two-stage and deterministic: every block writes its 256 partial sums, one block adds them in
 // float64 in a fixed order (a run repeats bit for bit; ranks all-reduce the 256 numbers between the two kernels of each
@@ -35,39 +38,6 @@ __device__ static inline void tr_block_reduce_store(float4 a, float4 b, float *_
         }
         *(float4 *)(part + (size_t)blockIdx.x * (2 * TR_C) + rl * TR_C + 4 * cq) = s;
     }
-}
-
-__global__ __launch_bounds__(TR_THREADS) void k_bn_sums(const float *__restrict__ y, long rows, float *__restrict__ part)
-{
-    const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
-    for (long r = (long)blockIdx.x * TR_ROWLANES + rl; r < rows; r += (long)gridDim.x * TR_ROWLANES) {
-        const float4 v = *(const float4 *)(y + r * TR_C + 4 * cq);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
-    }
-    tr_block_reduce_store(s, q, part);
-}
-
-// out[2 * 128] = column sums of part[n_blocks][2 * 128] in float64, in a fixed order: four row groups per column, each
-// adding every fourth block with eight loads in flight, then the four group sums in order
-__global__ __launch_bounds__(8 * TR_C) void k_bn_fold(const float *__restrict__ part, int n_blocks, float *__restrict__ out)
-{
-    __shared__ double sh[4][2 * TR_C];
-    const int col = threadIdx.x & (2 * TR_C - 1), grp = threadIdx.x / (2 * TR_C);
-    double acc = 0.0;
-    int b = grp;
-    for (; b + 28 < n_blocks; b += 32) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + 4 * u) * (2 * TR_C) + col];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc += (double)v[u];
-    }
-    for (; b < n_blocks; b += 4) acc += (double)part[(size_t)b * (2 * TR_C) + col];
-    sh[grp][col] = acc;
-    __syncthreads();
-    if (grp == 0) out[col] = (float)(((sh[0][col] + sh[1][col]) + sh[2][col]) + sh[3][col]);
 }
 
 // largest magnitude of a float32 array -> the power-of-two input scale of the split-f16 convolution, written into the
@@ -128,7 +98,7 @@ __device__ static inline void tr_block_amax(float m, float *__restrict__ amax_pa
 __global__ __launch_bounds__(TR_THREADS) void k_bn_apply(const float *__restrict__ y, const float *__restrict__ scale,
                                                         const float *__restrict__ shift, const float *__restrict__ res,
                                                         float *__restrict__ out, long rows, int relu,
-                                                        float *__restrict__ amax_part)
+                                                        float *__restrict__ amax_part, uint8_t *__restrict__ mask_out)
 {
     const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const float4 sc = *(const float4 *)(scale + 4 * cq), sh = *(const float4 *)(shift + 4 * cq);
@@ -143,6 +113,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_bn_apply(const float *__restrict
         }
         if (relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
         *(float4 *)(out + o) = t;
+        if (mask_out) mask_out[r * 32 + cq] = (uint8_t)((t.x > 0.f ? 1 : 0) | (t.y > 0.f ? 2 : 0) | (t.z > 0.f ? 4 : 0) | (t.w > 0.f ? 8 : 0));
         am = fmaxf(fmaxf(am, fmaxf(fabsf(t.x), fabsf(t.y))), fmaxf(fabsf(t.z), fabsf(t.w)));
     }
     if (amax_part) tr_block_amax(am, amax_part);
@@ -150,8 +121,24 @@ __global__ __launch_bounds__(TR_THREADS) void k_bn_apply(const float *__restrict
 
 // g = dout where the layer's output is positive (ReLU) or everywhere (no ReLU); xhat = (y - mean) * inv
 #define TR_G(dv, ov) (relu ? make_float4(ov.x > 0.f ? dv.x : 0.f, ov.y > 0.f ? dv.y : 0.f, ov.z > 0.f ? dv.z : 0.f, ov.w > 0.f ? dv.w : 0.f) : dv)
+// the ReLU decision of a quad of channels: from the mask byte k_bn_apply wrote, or from the sign of a tensor
+#define TR_MASKED(dv, o)                                                                        \
+    ({                                                                                          \
+        float4 g_ = dv;                                                                         \
+        if (relu) {                                                                             \
+            if (mask) {                                                                         \
+                const unsigned m_ = mask[(o) >> 2];                                             \
+                g_ = make_float4((m_ & 1u) ? dv.x : 0.f, (m_ & 2u) ? dv.y : 0.f, (m_ & 4u) ? dv.z : 0.f, (m_ & 8u) ? dv.w : 0.f); \
+            } else {                                                                            \
+                const float4 ov_ = *(const float4 *)(out + (o));                                \
+                g_ = TR_G(dv, ov_);                                                             \
+            }                                                                                   \
+        }                                                                                       \
+        g_;                                                                                     \
+    })
 
 __global__ __launch_bounds__(TR_THREADS) void k_bn_grad_sums(const float *__restrict__ dout, const float *__restrict__ out,
+                                                            const uint8_t *__restrict__ mask,
                                                             const float *__restrict__ y, const float *__restrict__ mean,
                                                             const float *__restrict__ inv, long rows, int relu,
                                                             float *__restrict__ part)
@@ -162,9 +149,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_bn_grad_sums(const float *__rest
     for (long r = (long)blockIdx.x * TR_ROWLANES + rl; r < rows; r += (long)gridDim.x * TR_ROWLANES) {
         const long o = r * TR_C + 4 * cq;
         const float4 dv = *(const float4 *)(dout + o);
-        float4 ov = dv;
-        if (relu) ov = *(const float4 *)(out + o);
-        const float4 g = TR_G(dv, ov);
+        const float4 g = TR_MASKED(dv, o);
         const float4 v = *(const float4 *)(y + o);
         s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
         q.x += g.x * ((v.x - mu.x) * iv.x); q.y += g.y * ((v.y - mu.y) * iv.y);
@@ -175,6 +160,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_bn_grad_sums(const float *__rest
 
 // dx = a (g - b - xhat c) with a = gamma * inv, b = sum(g) / count, c = sum(g * xhat) / count; g_out (optional) = g
 __global__ __launch_bounds__(TR_THREADS) void k_bn_grad_apply(const float *__restrict__ dout, const float *__restrict__ out,
+                                                             const uint8_t *__restrict__ mask,
                                                              const float *__restrict__ y, const float *__restrict__ mean,
                                                              const float *__restrict__ inv, const float *__restrict__ a,
                                                              const float *__restrict__ b, const float *__restrict__ c,
@@ -188,9 +174,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_bn_grad_apply(const float *__res
     for (long r = (long)blockIdx.x * TR_ROWLANES + rl; r < rows; r += (long)gridDim.x * TR_ROWLANES) {
         const long o = r * TR_C + 4 * cq;
         const float4 dv = *(const float4 *)(dout + o);
-        float4 ov = dv;
-        if (relu) ov = *(const float4 *)(out + o);
-        const float4 g = TR_G(dv, ov);
+        const float4 g = TR_MASKED(dv, o);
         const float4 v = *(const float4 *)(y + o);
         float4 d;
         d.x = a4.x * (g.x - b4.x - ((v.x - mu.x) * iv.x) * c4.x);
@@ -210,61 +194,42 @@ static int tr_grid(long rows)
     return (int)(want < 2048 ? (want > 0 ? want : 1) : 2048);      // eight blocks per CU; every thread strides over its rows
 }
 
-extern "C" int snk_bn_train_sums(const float *d_y, long rows, float *d_partials, float *d_sums, void *stream)
-{
-    SNK_REQUIRE(d_y && d_partials && d_sums && rows > 0, "snk_bn_train_sums: bad argument");
-    const int grid = tr_grid(rows);
-    k_bn_sums<<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_y, rows, d_partials);
-    k_bn_fold<<<1, 8 * TR_C, 0, (hipStream_t)stream>>>(d_partials, grid, d_sums);
-    SNK_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
 extern "C" int snk_bn_train_apply(const float *d_y, const float *d_scale, const float *d_shift, const float *d_residual,
-                                  float *d_out, long rows, int relu, float *d_partials, float *d_out_scale_tail, void *stream)
+                                  float *d_out, long rows, int relu, float *d_partials, float *d_out_scale_tail,
+                                  uint8_t *d_relu_mask, void *stream)
 {
     SNK_REQUIRE(d_y && d_scale && d_shift && d_out && rows > 0 && (!d_out_scale_tail || d_partials), "snk_bn_train_apply: bad argument");
     const int grid = tr_grid(rows);
     k_bn_apply<<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_y, d_scale, d_shift, d_residual, d_out, rows, relu,
-                                                              d_out_scale_tail ? d_partials : nullptr);
+                                                              d_out_scale_tail ? d_partials : nullptr, d_relu_mask);
     if (d_out_scale_tail) k_amax_scale<<<1, 1024, 0, (hipStream_t)stream>>>(d_partials, grid, d_out_scale_tail);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
-extern "C" int snk_bn_train_grad_sums(const float *d_dout, const float *d_out, const float *d_y, const float *d_mean,
-                                      const float *d_inv, long rows, int relu, float *d_partials, float *d_sums, void *stream)
-{
-    SNK_REQUIRE(d_dout && d_y && d_mean && d_inv && d_partials && d_sums && rows > 0 && (!relu || d_out),
-                "snk_bn_train_grad_sums: bad argument");
-    const int grid = tr_grid(rows);
-    k_bn_grad_sums<<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_dout, d_out, d_y, d_mean, d_inv, rows, relu, d_partials);
-    k_bn_fold<<<1, 8 * TR_C, 0, (hipStream_t)stream>>>(d_partials, grid, d_sums);
-    SNK_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
 // the same sums kept in float64 (the manual training step, snake_engine/train_step.py: the ranks all-reduce float64 sums)
-extern "C" int snk_bn_train_grad_sums_f64(const float *d_dout, const float *d_out, const float *d_y, const float *d_mean,
-                                          const float *d_inv, long rows, int relu, float *d_partials, double *d_sums, void *stream)
+extern "C" int snk_bn_train_grad_sums_f64(const float *d_dout, const float *d_out, const uint8_t *d_relu_mask, const float *d_y,
+                                          const float *d_mean, const float *d_inv, long rows, int relu, float *d_partials,
+                                          double *d_sums, void *stream)
 {
-    SNK_REQUIRE(d_dout && d_y && d_mean && d_inv && d_partials && d_sums && rows > 0 && (!relu || d_out),
+    SNK_REQUIRE(d_dout && d_y && d_mean && d_inv && d_partials && d_sums && rows > 0 && (!relu || d_out || d_relu_mask),
                 "snk_bn_train_grad_sums_f64: bad argument");
     const int grid = tr_grid(rows);
-    k_bn_grad_sums<<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_dout, d_out, d_y, d_mean, d_inv, rows, relu, d_partials);
+    k_bn_grad_sums<<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_dout, d_out, d_relu_mask, d_y, d_mean, d_inv, rows, relu, d_partials);
     tf_fold<double>(d_partials, grid, 2 * TR_C, 2 * TR_C, 1.0, d_sums, (double *)(d_partials + 2048 * 2 * TR_C), (hipStream_t)stream);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
-extern "C" int snk_bn_train_grad_apply(const float *d_dout, const float *d_out, const float *d_y, const float *d_mean,
-                                       const float *d_inv, const float *d_a, const float *d_b, const float *d_c, float *d_dx,
-                                       float *d_g, long rows, int relu, float *d_partials, float *d_dx_scale_tail, void *stream)
+extern "C" int snk_bn_train_grad_apply(const float *d_dout, const float *d_out, const uint8_t *d_relu_mask, const float *d_y,
+                                       const float *d_mean, const float *d_inv, const float *d_a, const float *d_b, const float *d_c,
+                                       float *d_dx, float *d_g, long rows, int relu, float *d_partials, float *d_dx_scale_tail,
+                                       void *stream)
 {
-    SNK_REQUIRE(d_dout && d_y && d_mean && d_inv && d_a && d_b && d_c && d_dx && rows > 0 && (!relu || d_out) &&
+    SNK_REQUIRE(d_dout && d_y && d_mean && d_inv && d_a && d_b && d_c && d_dx && rows > 0 && (!relu || d_out || d_relu_mask) &&
                 (!d_dx_scale_tail || d_partials), "snk_bn_train_grad_apply: bad argument");
     const int grid = tr_grid(rows);
-    k_bn_grad_apply<<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_dout, d_out, d_y, d_mean, d_inv, d_a, d_b, d_c, d_dx, d_g, rows,
+    k_bn_grad_apply<<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_dout, d_out, d_relu_mask, d_y, d_mean, d_inv, d_a, d_b, d_c, d_dx, d_g, rows,
                                                                    relu, d_dx_scale_tail ? d_partials : nullptr);
     if (d_dx_scale_tail) k_amax_scale<<<1, 1024, 0, (hipStream_t)stream>>>(d_partials, grid, d_dx_scale_tail);
     SNK_CHECK_HIP(hipGetLastError());

@@ -88,17 +88,15 @@ PROTOTYPES = {
     "snk_conv3x3_f16s_input_scale": (i32, [vp, C.c_long, vp, vp, vp]),
     "snk_conv3x3_wgrad_partials": (C.c_long, [i32, i32]),
     "snk_conv3x3_wgrad_f16s": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
-    "snk_bn_train_sums": (i32, [vp, C.c_long, vp, vp, vp]),
-    "snk_bn_train_apply": (i32, [vp, vp, vp, vp, vp, C.c_long, i32, vp, vp, vp]),
-    "snk_bn_train_grad_sums": (i32, [vp, vp, vp, vp, vp, C.c_long, i32, vp, vp, vp]),
-    "snk_bn_train_grad_apply": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_long, i32, vp, vp, vp]),
+    "snk_bn_train_apply": (i32, [vp, vp, vp, vp, vp, C.c_long, i32, vp, vp, vp, vp]),
+    "snk_bn_train_grad_apply": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_long, i32, vp, vp, vp]),
     "snk_conv3x3_prepare_weights_f16s_train": (i32, [vp, vp, vp, i32, vp, vp]),
     "snk_stem_conv_f32": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "snk_stem_wgrad_partials": (C.c_long, [i32, i32, i32]),
     "snk_stem_wgrad_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "snk_bn_train_sums_f64": (i32, [vp, C.c_long, vp, vp, vp, vp]),
     "snk_bn_train_finalize": (i32, [vp, f64, vp, vp, vp, vp, vp, f64, f64, vp, vp, vp, vp, i32, vp]),
-    "snk_bn_train_grad_sums_f64": (i32, [vp, vp, vp, vp, vp, C.c_long, i32, vp, vp, vp]),
+    "snk_bn_train_grad_sums_f64": (i32, [vp, vp, vp, vp, vp, vp, C.c_long, i32, vp, vp, vp]),
     "snk_bn_train_grad_finalize": (i32, [vp, vp, f64, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "snk_head_conv1x1_sums": (i32, [vp, vp, C.c_long, vp, vp, vp, vp, vp]),
     "snk_head_dense_train_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f64, i32, i32, i32, vp]),

@@ -93,6 +93,7 @@ class TrainStep:
         self.scale = [f(C) for _ in range(self.n_layers)]
         self.shift = [f(C) for _ in range(self.n_layers)]
         self.tail_out = [f(4) for _ in range(self.n_layers)]
+        self.relu_mask = [f(self.max_rows * self.hw * 32, torch.uint8) for _ in range(self.n_layers)]     # 4 bits per byte: out > 0
         self.tail_dy = f(4)
         self.abc = f(3 * C)
         self.img_f = [torch.empty(F16S_WEIGHT_BYTES, dtype=torch.uint8, device=self.dev) for _ in range(self.n_layers)]
@@ -139,7 +140,7 @@ class TrainStep:
         check(L.snk_bn_train_finalize(_p(self.sums), float(count), _p(mm), _p(self.view[k + 1]), _p(self.view[k + 2]), _p(mm), _p(mv),
                                       BN_MOMENTUM, BN_EPS, _p(self.mean[l]), _p(self.inv[l]), _p(self.scale[l]), _p(self.shift[l]), C, st))
         check(L.snk_bn_train_apply(_p(self.y[l]), _p(self.scale[l]), _p(self.shift[l]), _p(res), _p(relu_out), rows, 1,
-                                   _p(self.partials), _p(tail), st))
+                                   _p(self.partials), _p(tail), _p(self.relu_mask[l]), st))
 
     def _conv(self, x, image, res, out, n):
         check(self.L.snk_conv3x3_bn_f16s(_p(x), _p(image), _p(self.ones), _p(self.zeros), _p(res), _p(out), n, self.h, self.w, 0, self._st()))
@@ -178,8 +179,9 @@ class TrainStep:
     # ---- backward --------------------------------------------------------------------------------------------------
     def _bn_backward(self, l, n, count, want_res, tail):
         L, st, rows, k = self.L, self._st(), n * self.hw, self._k(l)
-        mask = self.mask_override.get(l, self.out[l])
-        check(L.snk_bn_train_grad_sums_f64(_p(self.dA), _p(mask), _p(self.y[l]), _p(self.mean[l]), _p(self.inv[l]), rows, 1,
+        sign = self.mask_override.get(l)                          # tests: a tensor whose sign replaces the recorded ReLU mask
+        bits = None if sign is not None else self.relu_mask[l]
+        check(L.snk_bn_train_grad_sums_f64(_p(self.dA), _p(sign), _p(bits), _p(self.y[l]), _p(self.mean[l]), _p(self.inv[l]), rows, 1,
                                            _p(self.partials), _p(self.sums), st))
         local = self.sums
         if self.dist is not None:
@@ -189,7 +191,7 @@ class TrainStep:
         a, b, c = self.abc[:C], self.abc[C:2 * C], self.abc[2 * C:]
         check(L.snk_bn_train_grad_finalize(_p(self.sums), _p(local), float(count), _p(self.view[k + 1]), _p(self.inv[l]), _p(a), _p(b), _p(c),
                                            _p(self.gview[k + 1]), _p(self.gview[k + 2]), C, st))
-        check(L.snk_bn_train_grad_apply(_p(self.dA), _p(mask), _p(self.y[l]), _p(self.mean[l]), _p(self.inv[l]), _p(a), _p(b), _p(c),
+        check(L.snk_bn_train_grad_apply(_p(self.dA), _p(sign), _p(bits), _p(self.y[l]), _p(self.mean[l]), _p(self.inv[l]), _p(a), _p(b), _p(c),
                                         _p(self.dY), _p(self.gres) if want_res else None, rows, 1, _p(self.partials), _p(tail), st))
 
     def backward(self, target, n_global):

@@ -307,12 +307,14 @@ int snk_engine_rewards(const snk_engine *e, const int32_t *d_slots, int n, int8_
 /* ---- training half: AlphaNNet.train = model.fit (alpha_nnet.py:58-59) -------------------------
  * Training-mode batch normalisation of a 128-channel channels-last float32 activation [rows = n * h * w][128] (the
  * BatchNormalization layers of alpha_nnet.py:23-46 as Keras runs them under fit), fused with the ReLU / residual add around
- * it.  The caller (utils/trainer_torch.py) turns the sums into mean / variance / scales between the two kernels of each
- * direction -- and all-reduces them over the ranks there.  d_partials: snk_bn_train_partials() floats of scratch.
- *   snk_bn_train_sums        d_sums[0..127] = per-channel sum of y, d_sums[128..255] = sum of y * y (deterministic order)
- *   snk_bn_train_apply       out = y * scale + shift (+ residual), then ReLU when relu != 0
- *   snk_bn_train_grad_sums   with g = dout (masked by out > 0 when relu): d_sums = { sum g, sum g * xhat }, xhat = (y - mean) * inv
- *   snk_bn_train_grad_apply  dx = a * (g - b - xhat * c); d_g (optional) = g, the gradient of the residual branch
+ * it.  Between the sums and the apply kernel of a direction sit snk_bn_train_finalize / snk_bn_train_grad_finalize (below),
+ * and the caller's all-reduce of the float64 sums when it runs data-parallel.  d_partials: snk_bn_train_partials() floats.
+ *   snk_bn_train_apply          out = y * scale + shift (+ residual), then ReLU when relu != 0; d_relu_mask (optional): one byte
+ *                               per row and quad of channels, byte [row * 32 + c / 4] bit (c % 4) = out[row][c] > 0
+ *   snk_bn_train_grad_sums_f64  with g = dout masked by the ReLU: d_sums = { sum g, sum g * xhat }, xhat = (y - mean) * inv.  The
+ *                               mask is d_relu_mask (what snk_bn_train_apply wrote: 1/16 of the bytes) or, when that is NULL,
+ *                               the sign of d_out (the activation itself, or any tensor whose sign is the mask)
+ *   snk_bn_train_grad_apply     dx = a * (g - b - xhat * c); d_g (optional) = g, the gradient of the residual branch
  * The two apply kernels can hand on the power-of-two input scale of the convolution that reads their result (what
  * snk_conv3x3_f16s_input_scale would derive from it): d_out_scale_tail / d_dx_scale_tail (optional) = 4 floats
  * { ., ., scale, 1 / scale }, taken from the values as they are written -- the tensor is not read again for its maximum. */
@@ -329,14 +331,16 @@ int snk_conv3x3_f16s_input_scale(const float *d_x, long n_floats, void *d_wS, fl
 long snk_conv3x3_wgrad_partials(int height, int width);
 int snk_conv3x3_wgrad_f16s(const float *d_x, const float *d_dy, const float *d_x_tail, const float *d_dy_tail,
                            float *d_partials, float *d_dw, int n_images, int height, int width, void *stream);
-int snk_bn_train_sums(const float *d_y, long rows, float *d_partials, float *d_sums, void *stream);
 int snk_bn_train_apply(const float *d_y, const float *d_scale, const float *d_shift, const float *d_residual,
-                       float *d_out, long rows, int relu, float *d_partials, float *d_out_scale_tail, void *stream);
-int snk_bn_train_grad_sums(const float *d_dout, const float *d_out, const float *d_y, const float *d_mean,
-                           const float *d_inv, long rows, int relu, float *d_partials, float *d_sums, void *stream);
-int snk_bn_train_grad_apply(const float *d_dout, const float *d_out, const float *d_y, const float *d_mean,
-                            const float *d_inv, const float *d_a, const float *d_b, const float *d_c, float *d_dx,
-                            float *d_g, long rows, int relu, float *d_partials, float *d_dx_scale_tail, void *stream);
+                       float *d_out, long rows, int relu, float *d_partials, float *d_out_scale_tail, uint8_t *d_relu_mask,
+                       void *stream);
+int snk_bn_train_grad_sums_f64(const float *d_dout, const float *d_out, const uint8_t *d_relu_mask, const float *d_y,
+                               const float *d_mean, const float *d_inv, long rows, int relu, float *d_partials, double *d_sums,
+                               void *stream);
+int snk_bn_train_grad_apply(const float *d_dout, const float *d_out, const uint8_t *d_relu_mask, const float *d_y,
+                            const float *d_mean, const float *d_inv, const float *d_a, const float *d_b, const float *d_c,
+                            float *d_dx, float *d_g, long rows, int relu, float *d_partials, float *d_dx_scale_tail,
+                            void *stream);
 
 /* ---- the rest of the training step (csrc/train_net.hip; driven by snake_engine/train_step.py) ------------------------------
  * Everything AlphaNNet.train (alpha_nnet.py:58-59: Keras fit = forward, backward, Adam) needs besides the calls above, so that a
@@ -376,8 +380,6 @@ int snk_bn_train_sums_f64(const float *d_y, long rows, const float *d_center, fl
 int snk_bn_train_finalize(const double *d_sums, double count, const float *d_center, const float *d_gamma, const float *d_beta,
                           float *d_moving_mean, float *d_moving_var, double momentum, double eps, float *d_mean, float *d_inv,
                           float *d_scale, float *d_shift, int channels, void *stream);
-int snk_bn_train_grad_sums_f64(const float *d_dout, const float *d_out, const float *d_y, const float *d_mean, const float *d_inv,
-                               long rows, int relu, float *d_partials, double *d_sums, void *stream);
 int snk_bn_train_grad_finalize(const double *d_sums_global, const double *d_sums_local, double count, const float *d_gamma,
                                const float *d_inv, float *d_a, float *d_b, float *d_c, float *d_dgamma, float *d_dbeta,
                                int channels, void *stream);

@@ -121,16 +121,27 @@ def test_batch_norm_kernels_match_float64(torch_gpu, with_res, n, mean, std):
     check(L.snk_bn_train_sums_f64(y.data_ptr(), rows, mm.data_ptr(), part.data_ptr(), sums.data_ptr(), st))
     check(L.snk_bn_train_finalize(sums.data_ptr(), float(rows), mm.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), mv.data_ptr(),
                                   0.99, 1e-3, m_.data_ptr(), inv.data_ptr(), sc.data_ptr(), sh.data_ptr(), C, st))
+    bits = torch.zeros(rows * 32, dtype=torch.uint8, device="cuda")
     check(L.snk_bn_train_apply(y.data_ptr(), sc.data_ptr(), sh.data_ptr(), res.data_ptr() if with_res else None, out.data_ptr(), rows, 1,
-                               part.data_ptr(), tail.data_ptr(), st))
+                               part.data_ptr(), tail.data_ptr(), bits.data_ptr(), st))
+    want_bits = ((out > 0).reshape(rows, 32, 4).to(torch.uint8) * torch.tensor([1, 2, 4, 8], dtype=torch.uint8, device="cuda")).sum(dim=2)
+    assert torch.equal(bits.reshape(rows, 32), want_bits.to(torch.uint8))             # one byte per quad of channels: out > 0
     a, b, c, dg, db, tail_dx = f(C), f(C), f(C), f(C), f(C), f(4)
     dx, gres = torch.empty_like(y), torch.empty_like(y)
-    check(L.snk_bn_train_grad_sums_f64(dout.data_ptr(), out.data_ptr(), y.data_ptr(), m_.data_ptr(), inv.data_ptr(), rows, 1, part.data_ptr(),
+    check(L.snk_bn_train_grad_sums_f64(dout.data_ptr(), None, bits.data_ptr(), y.data_ptr(), m_.data_ptr(), inv.data_ptr(), rows, 1, part.data_ptr(),
                                        sums.data_ptr(), st))
+    sums_from_sign = torch.empty_like(sums)                    # the other way to give the mask: the sign of a tensor
+    check(L.snk_bn_train_grad_sums_f64(dout.data_ptr(), out.data_ptr(), None, y.data_ptr(), m_.data_ptr(), inv.data_ptr(), rows, 1, part.data_ptr(),
+                                       sums_from_sign.data_ptr(), st))
+    assert torch.equal(sums, sums_from_sign)
     check(L.snk_bn_train_grad_finalize(sums.data_ptr(), sums.data_ptr(), float(rows), gamma.data_ptr(), inv.data_ptr(), a.data_ptr(),
                                        b.data_ptr(), c.data_ptr(), dg.data_ptr(), db.data_ptr(), C, st))
-    check(L.snk_bn_train_grad_apply(dout.data_ptr(), out.data_ptr(), y.data_ptr(), m_.data_ptr(), inv.data_ptr(), a.data_ptr(), b.data_ptr(),
+    check(L.snk_bn_train_grad_apply(dout.data_ptr(), None, bits.data_ptr(), y.data_ptr(), m_.data_ptr(), inv.data_ptr(), a.data_ptr(), b.data_ptr(),
                                     c.data_ptr(), dx.data_ptr(), gres.data_ptr() if with_res else None, rows, 1, part.data_ptr(), tail_dx.data_ptr(), st))
+    dx_sign = torch.empty_like(dx)
+    check(L.snk_bn_train_grad_apply(dout.data_ptr(), out.data_ptr(), None, y.data_ptr(), m_.data_ptr(), inv.data_ptr(), a.data_ptr(), b.data_ptr(),
+                                    c.data_ptr(), dx_sign.data_ptr(), None, rows, 1, part.data_ptr(), tail_dx.data_ptr(), st))
+    assert torch.equal(dx, dx_sign)
 
     y64, g64, b64 = (t.double().requires_grad_(True) for t in (y, gamma, beta))
     r64 = res.double().requires_grad_(True) if with_res else None
