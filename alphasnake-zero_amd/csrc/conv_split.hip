@@ -28,6 +28,7 @@
 // epilogue also reduces the head's 1x1 convolution per pixel and skips the layer output.  Workgroups map to (image,
 // part) XCD-aware: the parts of an image, which share halo rows, run on the same XCD (same L2) back to back.
 #include "common.h"
+#include "train_fold.h"
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -60,6 +61,8 @@ struct ConvHsArgs {
     float s1, b1;
     int Hd, Wd, n_blk, tiles_base, tiles_rem, relu;      // block b of an image has tiles_base + (b < tiles_rem) M tiles
     int n_img_grouped;         // images (a multiple of 8) that use the XCD-aware block order
+    const float *center;       // MODE 4 (training forward): per-channel centre of the batch-norm sums (or NULL = 0)
+    float *stat_part;          // MODE 4: [gridDim.x][2][128] sums of (out - center) and (out - center)^2 over the block's pixels
 };
 
 #ifdef HS_STAMPS       // development build only (tools/conv_stamps.py): s_memtime at the phase boundaries of every block
@@ -77,7 +80,9 @@ extern "C" int snk_dbg_conv_stamps(unsigned long long *h_out, int n_blocks)
 #endif
 
 // NI: M tiles (of 32 GEMM rows) per block, <= 8.  MODE fixes the epilogue's options at compile time (no branches per row):
-//   0 all read from the arguments; 1 ReLU, no residual; 2 ReLU + residual; 3 ReLU + residual + fused head, no layer output
+//   0 all read from the arguments; 1 ReLU, no residual; 2 ReLU + residual; 3 ReLU + residual + fused head, no layer output;
+//   4 the training step's forward pass: the bare convolution (no scale / shift / ReLU / residual) plus the per-channel sums its
+//     batch norm needs, taken from the values on their way out (one pass over the activation less per layer and step)
 #define hs_dpp(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
 // SPLIT = false: the reduced-precision form for BASELINE configs[4] ("bf16 MFMA conv"): the same kernel with the hi parts
 //   only, one MFMA per product instead of three (f16 operands: 11 significand bits against bf16's 8, float32 accumulate).
@@ -90,10 +95,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
 {
     static_assert(IO16 == 0 || !SPLIT, "f16 activations only exist in the reduced-precision form");
     constexpr bool IN16 = (IO16 & 1) != 0, OUT16 = (IO16 & 2) != 0;
-    const bool has_res = MODE == 0 ? p.res != nullptr : MODE >= 2;
+    constexpr bool STATS = MODE == 4;
+    const bool has_res = MODE == 0 ? p.res != nullptr : (MODE == 2 || MODE == 3);
     const bool has_head = MODE == 0 ? p.w1x1 != nullptr : MODE == 3;
     const bool has_out = MODE == 0 ? p.out != nullptr : MODE != 3;
-    const float relu_floor = (MODE != 0 || p.relu) ? 0.f : -__builtin_inff();
+    const float relu_floor = ((MODE != 0 && MODE != 4) || (MODE == 0 && p.relu)) ? 0.f : -__builtin_inff();
     __shared__ __align__(16) unsigned char smem[HS_SMEM];
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;        // wave wn owns outputs 32 wn .. 32 wn + 31
     const int h = lane >> 5, l31 = lane & 31;
@@ -272,9 +278,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
     //      stored; one block barrier per pass (the other block of the CU computes meanwhile).
     const int cq = tid & 31, rr0 = tid >> 5;
     const float winv = p.wscale_inv[0] * p.wscale_inv[3];
-    float4 sc4 = *(const float4 *)(p.scale + 4 * cq);
-    const float4 sh4 = *(const float4 *)(p.shift + 4 * cq);
+    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!STATS) { sc4 = *(const float4 *)(p.scale + 4 * cq); sh4 = *(const float4 *)(p.shift + 4 * cq); }
     sc4.x *= winv; sc4.y *= winv; sc4.z *= winv; sc4.w *= winv;
+    float4 cen4 = make_float4(0.f, 0.f, 0.f, 0.f), st_s = cen4, st_q = cen4;
+    if (STATS && p.center) cen4 = *(const float4 *)(p.center + 4 * cq);
     float *Ms = (float *)smem;                                      // [2][64 rows][HS_MLD]
     const long obase = (long)img * HW * HS_C + 4 * cq;
     float4 wh = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -324,6 +332,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
                 v.x += r_.x; v.y += r_.y; v.z += r_.z; v.w += r_.w;
             }
             v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
+            if (STATS && off[pass & 1][j] >= 0) {
+                const float ex = v.x - cen4.x, ey = v.y - cen4.y, ez = v.z - cen4.z, ew = v.w - cen4.w;
+                st_s.x += ex; st_s.y += ey; st_s.z += ez; st_s.w += ew;
+                st_q.x += ex * ex; st_q.y += ey * ey; st_q.z += ez * ez; st_q.w += ew * ew;
+            }
             if (has_out && off[pass & 1][j] >= 0) {
                 if (OUT16) {
                     f16x4 o16_;                                    // saturating: an f16 infinity would turn the next layer into NaNs
@@ -344,6 +357,19 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
     }
 #undef HS_ROWS
 #undef HS_EPI_PREP
+    if (STATS) {                           // the eight row lanes' sums of a channel quad are added through LDS, in a fixed order
+        __syncthreads();
+        float4 *R = (float4 *)smem;        // [2][8][32]
+        R[rr0 * 32 + cq] = st_s;
+        R[(8 + rr0) * 32 + cq] = st_q;
+        __syncthreads();
+        if (rr0 < 2) {
+            float4 t = R[(8 * rr0) * 32 + cq];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) { const float4 u = R[(8 * rr0 + r) * 32 + cq]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+            *(float4 *)(p.stat_part + (size_t)blockIdx.x * 256 + rr0 * 128 + 4 * cq) = t;
+        }
+    }
     HS_STAMP(4)
 }
 
@@ -442,7 +468,8 @@ extern "C" int snk_conv3x3_prepare_weights_f16s_train(const float *d_w_hwio, voi
 
 static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
                             const float *d_residual, float *d_out, const float *d_w1x1, float s1, float b1, float *d_h1,
-                            int n_images, int height, int width, int relu, bool split, void *stream, int io16 = 0)
+                            int n_images, int height, int width, int relu, bool split, void *stream, int io16 = 0,
+                            const float *d_center = nullptr, float *d_stat_part = nullptr, int *grid_out = nullptr)
 {
     SNK_REQUIRE(n_images >= 0 && height >= 1 && width >= 3, "snk_conv3x3_bn_f16s: bad shape %d x %d x %d", n_images, height, width);
     SNK_REQUIRE(d_out != d_x, "snk_conv3x3_bn_f16s: in-place convolution is not possible (blocks read their neighbours' input rows)");
@@ -471,9 +498,25 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
     const int tiles_base = T / n_blk, tiles_rem = T % n_blk;
     SNK_REQUIRE((long)n_images * n_blk < (1l << 31) && (long)HW * HS_C < (1l << 31), "snk_conv3x3_bn_f16s: batch too large");
     ConvHsArgs a = {d_x, (const f16x8 *)d_wS, (const float *)((const _Float16 *)d_wS + HS_WS_ELEMS), d_scale, d_shift,
-                    d_residual, d_out, d_w1x1, d_h1, s1, b1, height, width, n_blk, tiles_base, tiles_rem, relu, (n_images / 8) * 8};
+                    d_residual, d_out, d_w1x1, d_h1, s1, b1, height, width, n_blk, tiles_base, tiles_rem, relu, (n_images / 8) * 8,
+                    d_center, d_stat_part};
     const int n_mt = tiles_max, grid = n_images * n_blk;
     hipStream_t st = (hipStream_t)stream;
+    if (grid_out) *grid_out = grid;
+    if (d_stat_part) {                   // the training step's forward pass: bare convolution + batch-norm sums
+        switch (n_mt) {
+        case 1: k_conv3x3_f16s<1, 4><<<grid, 256, 0, st>>>(a); break;
+        case 2: k_conv3x3_f16s<2, 4><<<grid, 256, 0, st>>>(a); break;
+        case 3: k_conv3x3_f16s<3, 4><<<grid, 256, 0, st>>>(a); break;
+        case 4: k_conv3x3_f16s<4, 4><<<grid, 256, 0, st>>>(a); break;
+        case 5: k_conv3x3_f16s<5, 4><<<grid, 256, 0, st>>>(a); break;
+        case 6: k_conv3x3_f16s<6, 4><<<grid, 256, 0, st>>>(a); break;
+        case 7: k_conv3x3_f16s<7, 4><<<grid, 256, 0, st>>>(a); break;
+        default: k_conv3x3_f16s<8, 4><<<grid, 256, 0, st>>>(a); break;
+        }
+        SNK_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     // the three epilogue shapes the net wrapper uses get compile-time versions at the 21x21 tile count; everything else
     // takes the generic version
     if (!split && io16) {        // f16 activations in HBM (io16: 1 = f16 in, f32 out; 3 = f16 in and out)
@@ -555,6 +598,30 @@ extern "C" int snk_conv3x3_bn_f16s_head(const float *d_x, const void *d_wS, cons
     SNK_REQUIRE(d_x && d_wS && d_scale && d_shift && d_w1x1 && d_h1, "snk_conv3x3_bn_f16s_head: NULL argument");
     return conv_f16s_launch(d_x, d_wS, d_scale, d_shift, d_residual, d_out, d_w1x1, bn_scale, bn_shift, d_h1, n_images, height,
                             width, 1, true, stream);
+}
+
+// The training step's forward convolution: d_out = conv3x3_same(d_x, w) (no batch norm, no ReLU) and, from the same values on
+// their way out, d_sums[0..127] = sum over all pixels of (out - center), d_sums[128..255] = sum of (out - center)^2 (float64;
+// d_center: 128 floats or NULL) -- what snk_bn_train_sums_f64 would compute from d_out in a pass of its own.
+// d_partials: snk_conv3x3_stats_partials(n_images, height, width) floats.
+extern "C" long snk_conv3x3_stats_partials(int n_images, int height, int width)
+{
+    if (n_images <= 0 || height < 1 || width < 3) return -1;
+    const long T = ((long)height * width + 31) / 32;
+    return (long)n_images * T * 256 + TF_SCRATCH_FLOATS(256);              // at most one block per M tile
+}
+
+extern "C" int snk_conv3x3_f16s_stats(const float *d_x, const void *d_wS, float *d_out, const float *d_center, float *d_partials,
+                                      double *d_sums, int n_images, int height, int width, void *stream)
+{
+    SNK_REQUIRE(d_x && d_wS && d_out && d_partials && d_sums && n_images > 0, "snk_conv3x3_f16s_stats: bad argument");
+    int grid = 0;
+    const int rc = conv_f16s_launch(d_x, d_wS, nullptr, nullptr, nullptr, d_out, nullptr, 0.f, 0.f, nullptr, n_images, height, width, 0,
+                                    true, stream, 0, d_center, d_partials, &grid);
+    if (rc) return rc;
+    tf_fold<double>(d_partials, grid, 256, 256, 1.0, d_sums, (double *)(d_partials + (long)grid * 256), (hipStream_t)stream);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 // reduced precision with f16 activations in HBM (BASELINE configs[4]): d_x16 / d_residual16 are f16 [n][H][W][128]; the output

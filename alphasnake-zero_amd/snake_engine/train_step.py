@@ -7,8 +7,8 @@ Data flow of a step on ``n`` rows (h x w x 3 observations, 3 targets); every act
   forward   stem          snk_stem_conv_f32                     y0
             batch norm    snk_bn_train_sums_f64 -> (all-reduce) -> snk_bn_train_finalize -> snk_bn_train_apply    out0 (+ its
                           power-of-two range for the convolution that reads it)
-            tower layer   snk_conv3x3_prepare_weights_f16s_train + snk_conv3x3_bn_f16s (bare convolution) + batch norm
-                          (+ shortcut) + ReLU                    y_l, out_l
+            tower layer   snk_conv3x3_prepare_weights_f16s_train + snk_conv3x3_f16s_stats (bare convolution; its epilogue also takes
+                          the batch-norm sums) + batch norm (+ shortcut) + ReLU      y_l, out_l
             head          snk_head_conv1x1_sums -> finalize (1 channel) -> snk_head_dense_train_fwd      z, h, d1, q, sum (q - t)^2
   backward  head          snk_head_dense_train_bwd -> (all-reduce) -> snk_bn_train_grad_finalize -> snk_head_conv1x1_bwd
             tower layer   snk_bn_train_grad_sums_f64 -> (all-reduce) -> snk_bn_train_grad_finalize -> snk_bn_train_grad_apply,
@@ -23,12 +23,15 @@ Parameters, gradients and Adam moments are single flat buffers; every tensor of 
 the one-rank full-batch step up to float32 rounding.  A step whose learning rate is 0 (alpha_nnet.py:79-84: every step
 after the 100th) can only move the batch-norm moving averages: ``forward_only`` runs just the forward half.
 """
+import os
+
 import numpy as np
 import torch
 
 from ._lib import check, lib
 from .net import F16S_WEIGHT_BYTES
 
+_CONV_STATS = os.environ.get("SNK_TRAIN_CONV_STATS", "1") != "0"      # 0: batch-norm sums in a pass of their own (A/B runs)
 BN_EPS, BN_MOMENTUM, L2_C = 1e-3, 0.99, 1e-5
 ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-7
 C = 128
@@ -102,6 +105,7 @@ class TrainStep:
         self.sums, self.sums_local = f(2 * C, torch.float64), f(2 * C, torch.float64)
         self.partials = f(self.L.snk_bn_train_partials())
         self.wg_partials = f(int(self.L.snk_conv3x3_wgrad_partials(self.h, self.w)))
+        self.cv_partials = f(int(self.L.snk_conv3x3_stats_partials(self.max_rows, self.h, self.w)))
         self.sw_partials = f(int(self.L.snk_stem_wgrad_partials(self.max_rows, self.h, self.w)))
         # head
         self.z, self.hh, self.g1 = f(self.max_rows * self.hw), f(self.max_rows * self.hw), f(self.max_rows * self.hw)
@@ -132,10 +136,11 @@ class TrainStep:
             else:
                 self.dist.all_reduce(t)
 
-    def _bn_forward(self, l, n, count, res, relu_out, tail):
+    def _bn_forward(self, l, n, count, res, relu_out, tail, have_sums=False):
         L, st, rows, k = self.L, self._st(), n * self.hw, self._k(l)
         mm, mv = self.moving[k + 3], self.moving[k + 4]
-        check(L.snk_bn_train_sums_f64(_p(self.y[l]), rows, _p(mm), _p(self.partials), _p(self.sums), st))
+        if not have_sums:                                        # the tower's convolutions take the sums on their way out
+            check(L.snk_bn_train_sums_f64(_p(self.y[l]), rows, _p(mm), _p(self.partials), _p(self.sums), st))
         self._all_reduce(self.sums)
         check(L.snk_bn_train_finalize(_p(self.sums), float(count), _p(mm), _p(self.view[k + 1]), _p(self.view[k + 2]), _p(mm), _p(mv),
                                       BN_MOMENTUM, BN_EPS, _p(self.mean[l]), _p(self.inv[l]), _p(self.scale[l]), _p(self.shift[l]), C, st))
@@ -159,9 +164,13 @@ class TrainStep:
         for l in range(1, self.n_layers):
             k = self._k(l)
             check(L.snk_conv3x3_prepare_weights_f16s_train(_p(self.view[k]), _p(self.img_f[l]), _p(self.tail_out[l - 1]), 0, None, st))
-            self._conv(self.out[l - 1], self.img_f[l], None, self.y[l], n)
+            if _CONV_STATS:
+                check(L.snk_conv3x3_f16s_stats(_p(self.out[l - 1]), _p(self.img_f[l]), _p(self.y[l]), _p(self.moving[k + 3]),
+                                               _p(self.cv_partials), _p(self.sums), n, self.h, self.w, st))
+            else:
+                self._conv(self.out[l - 1], self.img_f[l], None, self.y[l], n)
             res = self.out[l - 2] if l % 2 == 0 else None                # a block's second layer adds the block's input
-            self._bn_forward(l, n, count, res, self.out[l], self.tail_out[l])
+            self._bn_forward(l, n, count, res, self.out[l], self.tail_out[l], have_sums=_CONV_STATS)
         kh = self._k(self.n_layers)
         mm, mv = self.moving[kh + 3], self.moving[kh + 4]
         rows = n * self.hw

@@ -373,6 +373,13 @@ int snk_bn_train_grad_apply(const float *d_dout, const float *d_out, const uint8
 int snk_conv3x3_prepare_weights_f16s_train(const float *d_w_hwio, void *d_wS, const float *d_in_tail, int input_gradient,
                                            const void *d_wS_same_kernel, void *stream);
 int snk_stem_conv_f32(const float *d_x, const float *d_w, float *d_out, int n_images, int height, int width, void *stream);
+/* The forward convolution of a tower layer under training: d_out = conv3x3_same(d_x, w), bare (the batch norm comes after), and
+ * from the same values on their way out of the kernel d_sums[0..127] = sum (out - center), [128..255] = sum (out - center)^2
+ * over all n * h * w pixels (float64; d_center: 128 floats or NULL): snk_bn_train_sums_f64(d_out) without the extra pass.
+ * d_wS: snk_conv3x3_prepare_weights_f16s_train(..., input_gradient = 0); d_partials: snk_conv3x3_stats_partials(n, h, w) floats. */
+long snk_conv3x3_stats_partials(int n_images, int height, int width);
+int snk_conv3x3_f16s_stats(const float *d_x, const void *d_wS, float *d_out, const float *d_center, float *d_partials,
+                           double *d_sums, int n_images, int height, int width, void *stream);
 long snk_stem_wgrad_partials(int n_images, int height, int width);
 int snk_stem_wgrad_f32(const float *d_x, const float *d_dy, float *d_partials, float *d_dw, int n_images, int height, int width,
                        void *stream);
