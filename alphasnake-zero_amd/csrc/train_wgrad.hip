@@ -10,8 +10,8 @@
 // outside the image) lie in LDS in the order they have in HBM, [pixel][32 channels] as f16 hi / lo images with 64-byte rows
 // and pitch P = W + 1 (the zero cell behind an image row is the next row's left border).  The MFMA fragments are taken with
 // gfx950's transposing LDS read (ds_read_b64_tr_b16: a 16-lane group reads 4 rows x 16 channels and every lane receives ITS
-// channel's four rows), so a tap (dy, dx) is simply the X image read (dy + 1) * P + dx ROWS further on; the three dx taps of
-// a dy share three reads of twelve consecutive rows and one 16-bit funnel shift (v_alignbit).  Products are hi*hi + hi*lo +
+// channel's four rows), so a tap (dy, dx) is simply the X image read (dy + 1) * P + dx ROWS further on (a transposing read may
+// start at any row: no funnel shifts), and the reads run one (k-step, dy) group ahead of the MFMAs that use them.  Products are hi*hi + hi*lo +
 // lo*hi as in the forward kernel; the operands' power-of-two scales are the ones the element-wise kernels measured.
 //
 // Round 3: the block is 8 wavefronts with two ROLES and two LDS buffers.  Wavefronts 0-3 run the MFMAs of slab t from buffer
@@ -31,13 +31,6 @@ typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
 #define WG_GX 8                      // rows in front of the X image (the dx = -1 tap of the first pixel reads one row back)
 #define WG_MAXX 9                    // (pixel, four channels) items per staging thread and slab: X, then dY
 #define WG_MAXY 8
-
-__device__ static inline wg_f16x8 wg_frag(uint4 v)
-{
-    union { uint4 u; wg_f16x8 f; } c;
-    c.u = v;
-    return c.f;
-}
 
 typedef short wg_s4 __attribute__((ext_vector_type(4)));
 #define WG_TR(byte_ptr) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s4 *)(byte_ptr))
@@ -170,33 +163,56 @@ __global__ __launch_bounds__(512) void k_wgrad_f16s(WgArgs p)
         __syncthreads();
         for (int t = 0; t < T; ++t) {
             const unsigned char *XH = smem + (t & 1) * buf_bytes, *XL = XH + p.rows_x * 64, *YH = XL + p.rows_x * 64, *YL = YH + y_rows * 64;
-            for (int ks = wv; ks < p.nk; ks += 4) {
-                const int R = 16 * ks + 8 * h;
-                const wg_f16x8 bh = wg_join(WG_TR(YH + R * 64 + lane_off), WG_TR(YH + (R + 4) * 64 + lane_off));
-                const wg_f16x8 bl = wg_join(WG_TR(YL + R * 64 + lane_off), WG_TR(YL + (R + 4) * 64 + lane_off));
-#pragma unroll
-                for (int dyi = 0; dyi < 3; ++dyi) {
-                    const int Rx = R + xoff + (dyi - 1) * P - 1;       // rows Rx .. Rx + 11 hold the three dx taps' elements
-                    union { struct { wg_s4 a, b, c; } s; unsigned d[6]; } uh, ul;
-                    uh.s.a = WG_TR(XH + Rx * 64 + lane_off); uh.s.b = WG_TR(XH + (Rx + 4) * 64 + lane_off); uh.s.c = WG_TR(XH + (Rx + 8) * 64 + lane_off);
-                    ul.s.a = WG_TR(XL + Rx * 64 + lane_off); ul.s.b = WG_TR(XL + (Rx + 4) * 64 + lane_off); ul.s.c = WG_TR(XL + (Rx + 8) * 64 + lane_off);
-#define WG_AB(hi_, lo_) __builtin_amdgcn_alignbit((hi_), (lo_), 16)
-                    const wg_f16x8 ah[3] = {wg_frag(make_uint4(uh.d[0], uh.d[1], uh.d[2], uh.d[3])),                                              // dx = -1
-                                            wg_frag(make_uint4(WG_AB(uh.d[1], uh.d[0]), WG_AB(uh.d[2], uh.d[1]), WG_AB(uh.d[3], uh.d[2]), WG_AB(uh.d[4], uh.d[3]))),
-                                            wg_frag(make_uint4(uh.d[1], uh.d[2], uh.d[3], uh.d[4]))};                                              // dx = +1
-                    const wg_f16x8 al[3] = {wg_frag(make_uint4(ul.d[0], ul.d[1], ul.d[2], ul.d[3])),
-                                            wg_frag(make_uint4(WG_AB(ul.d[1], ul.d[0]), WG_AB(ul.d[2], ul.d[1]), WG_AB(ul.d[3], ul.d[2]), WG_AB(ul.d[4], ul.d[3]))),
-                                            wg_frag(make_uint4(ul.d[1], ul.d[2], ul.d[3], ul.d[4]))};
-#undef WG_AB
-#pragma unroll
-                    for (int dxi = 0; dxi < 3; ++dxi) {
-                        const int tp = 3 * dyi + dxi;
-                        acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[dxi], bh, acc[tp], 0, 0, 0);
-                        acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[dxi], bl, acc[tp], 0, 0, 0);
-                        acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[dxi], bh, acc[tp], 0, 0, 0);
-                    }
+            // Software pipeline over (k-step, dy) groups: the twelve transposing reads of group g + 1 (plus the four dY reads of
+            // the next k-step) are issued before the nine MFMAs of group g, whose operands were read one group earlier -- this
+            // is the only MFMA wavefront of its SIMD, nothing else covers an LDS wait.  Two fragment sets P / Q alternate:
+            // dy = 0, 1, 2 of one k-step use P, Q, P and the next k-step Q, P, Q.  The fences pin that order.
+#define WG_SB() __builtin_amdgcn_sched_barrier(0)
+#define WG_LOADB1(B_, Y_, R_) B_ = wg_join(WG_TR(Y_ + (R_) * 64 + lane_off), WG_TR(Y_ + ((R_) + 4) * 64 + lane_off));
+#define WG_LOADA(AH, AL, R_, dyi_)                                                              \
+            _Pragma("unroll") for (int dxi = 0; dxi < 3; ++dxi) {                               \
+                const int Rx_ = (R_) + xoff + ((dyi_) - 1) * P + (dxi - 1);                     \
+                AH[dxi] = wg_join(WG_TR(XH + Rx_ * 64 + lane_off), WG_TR(XH + (Rx_ + 4) * 64 + lane_off)); \
+                AL[dxi] = wg_join(WG_TR(XL + Rx_ * 64 + lane_off), WG_TR(XL + (Rx_ + 4) * 64 + lane_off)); \
+            }
+#define WG_MFMA3(AH, AL, dyi_)                                                                  \
+            _Pragma("unroll") for (int dxi = 0; dxi < 3; ++dxi) {                               \
+                const int tp = 3 * (dyi_) + dxi;                                                \
+                acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[dxi], bh, acc[tp], 0, 0, 0); \
+                acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[dxi], bl, acc[tp], 0, 0, 0); \
+                acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[dxi], bh, acc[tp], 0, 0, 0); \
+            }
+// at most 14 reads are in flight behind the ones an MFMA group waits for (the LDS counter has four bits); the last k-step of
+// a slab "prefetches" itself again instead of branching
+#define WG_KSTEP(PH, PL, QH, QL)                                                                \
+            {                                                                                   \
+                const int R = 16 * ks + 8 * h;                                                  \
+                const int Rn = ks + 4 < p.nk ? R + 64 : R;                                      \
+                WG_LOADA(QH, QL, R, 1) WG_LOADB1(nbh, YH, Rn) WG_SB(); WG_MFMA3(PH, PL, 0) WG_SB(); \
+                WG_LOADA(PH, PL, R, 2) WG_LOADB1(nbl, YL, Rn) WG_SB(); WG_MFMA3(QH, QL, 1) WG_SB(); \
+                WG_LOADA(QH, QL, Rn, 0) WG_SB(); WG_MFMA3(PH, PL, 2) WG_SB();                    \
+                bh = nbh; bl = nbl;                                                             \
+            }
+            int ks = wv;
+            if (ks < p.nk) {
+                wg_f16x8 bh, bl, nbh, nbl, a0h[3], a0l[3], a1h[3], a1l[3];
+                WG_LOADB1(bh, YH, 16 * ks + 8 * h)
+                WG_LOADB1(bl, YL, 16 * ks + 8 * h)
+                WG_LOADA(a0h, a0l, 16 * ks + 8 * h, 0)
+                for (;;) {
+                    WG_KSTEP(a0h, a0l, a1h, a1l)
+                    ks += 4;
+                    if (ks >= p.nk) break;
+                    WG_KSTEP(a1h, a1l, a0h, a0l)
+                    ks += 4;
+                    if (ks >= p.nk) break;
                 }
             }
+#undef WG_KSTEP
+#undef WG_MFMA3
+#undef WG_LOADA
+#undef WG_LOADB1
+#undef WG_SB
             __syncthreads();
         }
         // the four MFMA wavefronts' accumulators are added through LDS (all slabs are done: the buffers are free)
