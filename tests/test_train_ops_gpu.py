@@ -221,9 +221,10 @@ def _net64(torch, ws, X, Y):
     return float(loss), dict(zip(pidx, grads)), pre, q.detach(), n_conv
 
 
-@pytest.mark.parametrize("n,blocks,hw", [(40, 2, 21), (23, 4, 21), (5, 1, 37), (9, 1, 13)])
+@pytest.mark.parametrize("n,blocks,hw", [(40, 2, 21), (23, 4, 21), (5, 1, 37), (9, 1, 13), (3, 10, 37)])
 def test_one_whole_step_matches_float64_with_the_same_relu_masks(torch_gpu, n, blocks, hw):
-    """hw = 37: BASELINE configs[4]'s 19 x 19 board (its weight gradient runs in slabs of five image rows), 13: a 7 x 7 board"""
+    """hw = 37: BASELINE configs[4]'s 19 x 19 board (its weight gradient runs in slabs of five image rows; the last case is that
+    config's 10-block net), 13: a 7 x 7 board"""
     torch = torch_gpu
     from snake_engine import net
     from snake_engine.train_step import TrainStep
