@@ -158,6 +158,7 @@ def test_batch_norm_kernels_match_float64(torch_gpu, with_res, n, mean, std):
     r64 = res.double().requires_grad_(True) if with_res else None
     m64, v64 = y64.mean(dim=0), y64.var(dim=0, unbiased=False)
     z = (y64 - m64) / torch.sqrt(v64 + 1e-3) * g64 + b64
+    m64, v64 = m64.detach(), v64.detach()
     if with_res:
         z = z + r64
     o64 = torch.relu(z)
