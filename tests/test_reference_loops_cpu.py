@@ -99,3 +99,44 @@ def test_pit_script_fixture_is_self_consistent():
         want = (tag + " beats the previouse champion. score = " + str(score) + ". It is the new champion!") if score > 0.51 \
             else (tag + " failed to beat the previouse champion. score = " + str(score) + ".")
         assert lines[1 + ci] == want
+
+
+def test_ladder_arithmetic_and_line_formats_reproduce_the_reference_pit_txt():
+    """alphasnake-zero_amd/pit.py's score arithmetic and its three pit.txt line formats, fed the winner indices the reference's
+    own pit.py produced, give the reference's pit.txt byte for byte (the games themselves are replayed on the GPU,
+    tests/test_reference_loops_gpu.py)"""
+    import importlib
+    import sys
+    sys.modules.pop("pit", None)
+    pit = importlib.import_module("pit")
+    z = load_golden("pit_script.npz")
+    text = "m3 is set to be the baseline champion.\n"
+    for ci in range(int(z["n"])):
+        winners = [None if w < 0 else int(w) for w in z[f"c{ci}_winners"]]
+        score = pit.challenger_score(winners, int(z[f"c{ci}_args"][5]))
+        text += pit.verdict_line(f"m{4 + ci}", score, pit.THRESHOLD)
+    assert text.encode() == z["pit_txt"].tobytes()
+    assert (pit.PIT_GAMES, pit.HEIGHT, pit.WIDTH, pit.SNAKE_CNT) == tuple(int(v) for v in z["c0_args"][[4, 0, 1, 2]])
+
+
+def test_log_csv_row_format_of_the_mirror_trainer_is_the_reference_text(tmp_path, monkeypatch):
+    """utils.alpha_snake_zero_trainer._log_row / the header written by train(): fed the six averages of a recorded generation
+    they write the reference's log.csv bytes (trainer.py:35-41, 56-61)"""
+    import utils.alpha_snake_zero_trainer as T
+    z = load_golden("trainer.npz")
+    lines = z["gen0_log_csv"].tobytes().decode().splitlines()
+    monkeypatch.chdir(tmp_path)
+
+    class Runner:
+        game_cnt = 48
+    r = Runner()
+    vals = [float(v) for v in lines[2].split(", ")[1:]]
+    for k, v in zip(T.LOG_FIELDS, vals):
+        setattr(r, k, v)
+    tr = T.AlphaSnakeZeroTrainer(48, 4, 8, 2e-4, 0.9)
+    with open("log.csv", "a") as f:                      # what train() writes before the first generation
+        f.write("new model g\n")
+        f.write("iteration, wall_collision, body_collision, head_collision, starvation, food_eaten, game_length\n")
+    tr._log_row(r, 0)
+    assert open("log.csv").read().splitlines() == lines[:3]
+    assert [T.AlphaSnakeZeroTrainer.health_dec_for(i) for i in (0, 8, 9, 32, 33, 100)] == [9, 9, 3, 3, 1, 1]
