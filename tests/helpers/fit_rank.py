@@ -19,10 +19,10 @@ from snake_engine import net
 from utils import trainer_torch
 
 rs = np.random.RandomState(3)
-X = rs.rand(192, 21, 21, 3).astype(np.float32)
-Y = np.tanh(rs.randn(192, 3)).astype(np.float32)
+X = rs.rand(201, 21, 21, 3).astype(np.float32)          # three batches of 67 rows: two ranks get 34 and 33 of each
+Y = np.tanh(rs.randn(201, 3)).astype(np.float32)
 ws = net.glorot_uniform_weights((21, 21, 3), blocks=2, seed=5)
-got = trainer_torch.fit(ws, (21, 21, 3), X, Y, 2, 64, ([3, 5], [1e-3, 2.5e-4, 0.0]), seed=11, verbose=False)
+got = trainer_torch.fit(ws, (21, 21, 3), X, Y, 2, 67, ([3, 5], [1e-3, 2.5e-4, 0.0]), seed=11, verbose=False)
 assert trainer_torch.fit.last_mode == "kernels"
 q = trainer_torch._Net(got, torch.device("cuda")).forward(torch.as_tensor(X[:96], device="cuda"), False).detach().cpu().numpy()
 np.savez(os.path.join(out, f"fit_w{world}_r{rank}.npz"), *got, hist=np.array(trainer_torch.fit.last_history), q=q)
