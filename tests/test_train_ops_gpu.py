@@ -167,7 +167,7 @@ def test_batch_norm_kernels_match_float64(torch_gpu, with_res, n, mean, std):
     grads64 = torch.autograd.grad(z, ins64, dout.double() * (out > 0).double())
     assert float((m_.double() - m64).abs().max()) < 1e-6 * max(1.0, abs(mean))
     assert float(((1.0 / inv.double() ** 2 - 1e-3) - v64).abs().max() / v64.max()) < 2e-5
-    assert float((out.double() - o64).abs().max()) < 3e-5 * max(1.0, abs(mean) / std / 20)
+    assert float((out.double() - o64.detach()).abs().max()) < 3e-5 * max(1.0, abs(mean) / std / 20)
     tol = 2e-5 * max(1.0, abs(mean) / std / 20)            # xhat = (y - mean) inv in float32: the mean's rounding error counts in units of std
     assert rel(dx, grads64[0]) < tol and rel(dg, grads64[1]) < tol and rel(db, grads64[2]) < tol
     if with_res:
