@@ -13,7 +13,7 @@
 //
 // The reductions are two-stage and deterministic: every block writes its 256 partial sums, one block adds them in
 // float64 in a fixed order (a run repeats bit for bit; ranks all-reduce the 256 numbers between the two kernels of each
-// direction, utils/trainer_torch.py).  Everything here is HBM-bound: the PyTorch expressions these kernels replace made ten to
+// direction, snake_engine/train_step.py).  Everything here is HBM-bound: the PyTorch expressions these kernels replace made ten to
 // fifteen passes over the activation per layer and direction.
 #include "common.h"
 #include "train_fold.h"
