@@ -12,6 +12,18 @@ import torch
 from snake_engine.net import QNet, glorot_uniform_weights, n_blocks_of
 
 
+def lr_schedule(learning_rate=0.0001):
+    """alpha_nnet.py:79-84: PiecewiseConstantDecay([20, 40, 60, 80, 100], [lr, lr/4, lr/16, lr/64, lr/256, 0.0]) of the
+    optimizer's step count -- (boundaries, values); the products are formed exactly as the reference forms them"""
+    boundaries = [20, 40, 60, 80, 100]
+    values = [0.0] * (len(boundaries) + 1)
+    n = learning_rate
+    for i in range(len(boundaries)):
+        values[i] = n
+        n *= 0.25
+    return boundaries, values
+
+
 class _VNet:
     """the slice of the Keras Model object the reference's scripts touch (test_model.py:12, test_weights.py:7)"""
 
@@ -96,15 +108,9 @@ class AlphaNNet:
     def copy_and_compile(self, learning_rate=0.0001, TPU=None):
         """alpha_nnet.py:78-106: a copy with Adam + PiecewiseConstantDecay([20,40,60,80,100] steps,
         [lr, lr/4, lr/16, lr/64, lr/256, 0.0])"""
-        boundaries = [20, 40, 60, 80, 100]
-        values = [0.0] * (len(boundaries) + 1)
-        n = learning_rate
-        for i in range(len(boundaries)):
-            values[i] = n
-            n *= 0.25
         cp = AlphaNNet(input_shape=self.input_shape, _weights=self._qnet.get_weights())
         cp.learning_rate = learning_rate
-        cp.lr_schedule = (boundaries, values)
+        cp.lr_schedule = lr_schedule(learning_rate)
         return cp
 
     def save(self, name):

@@ -23,6 +23,10 @@ What is recorded:
                    start boards, spawn tape, moves, winner indices
   replay.npz       the replay.rep text one-game MPGameRunner.run writes (Game.draw, two
                    boards per tick) with the start board, moves and spawn tape behind it
+  trainer.npz      AlphaSnakeZeroTrainer.train (the reference's own module) for 3 x 2 generations
+  pit_script.npz   pit.py (the reference's own script) over three generations of stub nets
+  net_graph.npz    what AlphaNNet.__init__ / copy_and_compile / train / save build and call
+                   (layers, arguments, wiring, optimizer, schedule, loss), as JSON
 
 Only the RNG *bindings* inside the imported modules are wrapped (utils.game.random /
 choice / sample and utils.agent.choice are plain ``from x import y`` names,
@@ -1045,9 +1049,124 @@ def record_pit_script():
     print(text.decode())
     np.savez_compressed(os.path.join(HERE, "pit_script.npz"), **flat)
 
+
+def record_net_graph():
+    """AlphaNNet.__init__ / copy_and_compile / train / save (alpha_nnet.py:10-56, 58-59, 78-109), the reference's own code, run
+    against RECORDING stand-ins for the Keras names it imports (TensorFlow is absent): which layers it builds with which
+    arguments and how it wires them, which optimizer / schedule / loss it compiles with, what it passes to fit and save.
+    This pins the STRUCTURE of the net and of the training call to the reference; the arithmetic behind the names stays
+    Keras' (unpinned)."""
+    import json
+    import types
+    log = []
+    counter = [0]
+
+    class T:                                    # a symbolic tensor: just an id
+        def __init__(self):
+            counter[0] += 1
+            self.id = counter[0]
+
+    def enc(v):
+        if isinstance(v, T):
+            return {"tensor": v.id}
+        if isinstance(v, (list, tuple)):
+            return [enc(x) for x in v]
+        if isinstance(v, Rec):
+            return {"obj": v.kind, "args": enc(v.args), "kwargs": {k: enc(x) for k, x in v.kwargs.items()}}
+        return v
+
+    class Rec:
+        kind = "?"
+
+        def __init__(self, *args, **kwargs):
+            self.args, self.kwargs = args, kwargs
+
+        def __call__(self, x):
+            out = T()
+            log.append({"layer": self.kind, "args": enc(self.args), "kwargs": {k: enc(v) for k, v in self.kwargs.items()},
+                        "in": enc(x), "out": out.id})
+            return out
+
+    def layer(name):
+        return type(name, (Rec,), {"kind": name})
+
+    def Input(shape):
+        t = T()
+        log.append({"layer": "Input", "args": [list(shape)], "kwargs": {}, "in": None, "out": t.id})
+        return t
+
+    class Model:
+        def __init__(self, inputs=None, outputs=None):
+            self.inputs, self.outputs = inputs, outputs
+            self.layers = [types.SimpleNamespace(input_shape=(None, 21, 21, 3))]
+            self.calls = []
+            log.append({"layer": "Model", "args": [], "kwargs": {"inputs": enc(inputs), "outputs": enc(outputs)}, "in": None, "out": None})
+
+        def get_weights(self):
+            return ["w"]
+
+        def set_weights(self, w):
+            self.calls.append(["set_weights", w])
+
+        def build(self, shape):
+            self.calls.append(["build", list(shape)])
+
+        def compile(self, **kw):
+            self.calls.append(["compile", {k: enc(v) for k, v in kw.items()}])
+
+        def fit(self, X, Y, **kw):
+            self.calls.append(["fit", [list(np.shape(X)), str(np.asarray(X).dtype), list(np.shape(Y))], kw])
+
+        def save(self, path):
+            self.calls.append(["save", path])
+
+    def clone_model(m):
+        c = Model.__new__(Model)
+        c.inputs, c.outputs, c.layers, c.calls = m.inputs, m.outputs, m.layers, [["cloned"]]
+        return c
+    names = ["tensorflow", "tensorflow.keras", "tensorflow.keras.layers", "tensorflow.keras.optimizers",
+             "tensorflow.keras.regularizers", "tensorflow.keras.models"]
+    mods = {n: types.ModuleType(n) for n in names}
+    mods["tensorflow"].keras = mods["tensorflow.keras"]
+    for n in names[2:]:
+        setattr(mods["tensorflow.keras"], n.rsplit(".", 1)[1], mods[n])
+    L = mods["tensorflow.keras.layers"]
+    L.Input = Input
+    for nm in ("Conv2D", "BatchNormalization", "Activation", "Add", "Flatten", "Dense"):
+        setattr(L, nm, layer(nm))
+    O = mods["tensorflow.keras.optimizers"]
+    O.Adam = layer("Adam")
+    O.schedules = types.SimpleNamespace(PiecewiseConstantDecay=layer("PiecewiseConstantDecay"))
+    mods["tensorflow.keras.regularizers"].l2 = layer("l2")
+    M = mods["tensorflow.keras.models"]
+    M.Model, M.clone_model, M.load_model = Model, clone_model, lambda path: (_ for _ in ()).throw(OSError(path))
+    sys.modules.update(mods)
+    sys.modules.pop("utils.alpha_nnet", None)
+    import utils.alpha_nnet as NN                 # the reference's module, as it is
+    net = NN.AlphaNNet(input_shape=(21, 21, 3))
+    graph = list(log)
+    compiled = []
+    for lr in (0.0001, 9.8e-05, 0.0003, 1e-4 * 0.98 ** 40):
+        c = net.copy_and_compile(lr)
+        compiled.append({"learning_rate": lr, "calls": c.v_net.calls})
+    default = net.copy_and_compile()
+    X = [np.zeros((21, 21, 3), np.float32)] * 5
+    Y = [np.zeros(3, np.float32)] * 5
+    default.train(X, Y, batch_size=4)
+    default.train(X, Y)
+    default.save("g7")
+    out = {"graph": graph, "compiled": compiled, "default_compile_and_calls": default.v_net.calls,
+           "is_obstacle": [[v, bool(net.is_obstacle(np.float32(v)))] for v in (0.0, 0.02, 0.04, 0.06, 1.0)]}
+    text = json.dumps(out, sort_keys=True)
+    np.savez_compressed(os.path.join(HERE, "net_graph.npz"), json=np.frombuffer(text.encode(), np.uint8))
+    convs = [g for g in graph if g["layer"] == "Conv2D"]
+    print(f"[net_graph] {len(graph)} graph entries: {len(convs)} Conv2D, {sum(g['layer'] == 'BatchNormalization' for g in graph)} BN, "
+          f"{sum(g['layer'] == 'Add' for g in graph)} Add, {sum(g['layer'] == 'Dense' for g in graph)} Dense; {len(text)} bytes of json")
+    sys.modules.pop("utils.alpha_nnet", None)
+
 if __name__ == "__main__":
     os.chdir("/tmp")
-    which = set(sys.argv[1:]) or {"tic", "tic_more", "corner", "tables", "mcts", "mcts_more", "runner", "pit", "replay", "trainer", "pit_script"}
+    which = set(sys.argv[1:]) or {"tic", "tic_more", "corner", "tables", "mcts", "mcts_more", "runner", "pit", "replay", "trainer", "pit_script", "net_graph"}
     if "tic" in which:
         record_trajectories("11x11x4", 11, 11, 4, 1, 40, seed=1, p_legal=0.92, max_ticks=400, raw_every=23)
         record_trajectories("11x11x4_dec9", 11, 11, 4, 9, 10, seed=2, p_legal=0.97, max_ticks=400, raw_every=29)
@@ -1079,3 +1198,5 @@ if __name__ == "__main__":
         record_trainer()
     if "pit_script" in which:
         record_pit_script()
+    if "net_graph" in which:
+        record_net_graph()
