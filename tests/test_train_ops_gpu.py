@@ -391,5 +391,6 @@ def test_two_rank_fit_on_the_kernels_equals_the_one_rank_fit(torch_gpu, tmp_path
           f"weights {max(float(np.abs(a[k] - one[k]).max()) for k in keys):.2e}")
     assert dq.max() < 5e-2 and dq.mean() < 1e-2, (dq.max(), dq.mean())              # measured: 1.2e-2 / 2.6e-3
     assert max(float(np.abs(a[k] - one[k]).max()) for k in keys) < 2e-2              # measured: 4e-3
-    moved = max(float(np.abs(one[k] - w).max()) for k, w in zip(keys, __import__("snake_engine.net", fromlist=["x"]).glorot_uniform_weights((21, 21, 3), blocks=2, seed=5)))
-    assert moved > 1e-3                                                               # it trained
+    from snake_engine.net import glorot_uniform_weights
+    start = glorot_uniform_weights((21, 21, 3), blocks=2, seed=5)
+    assert max(float(np.abs(one[k] - w).max()) for k, w in zip(keys, start)) > 1e-3  # it trained
