@@ -10,9 +10,10 @@ import numpy as np
 from .mcts_oracle import argmaxs
 
 
-def pit_run(games, net_a, net_b, alice_snake_cnt=None, spawn_tape=None):
-    """games: list of oracle Game objects (index = game id); spawn_tape(turn) -> spawn cell per game id (-1 none).
-    Returns (winners list with None for draws, per-game number of ticks played)."""
+def pit_run(games, net_a, net_b, alice_snake_cnt=None, spawn_tape=None, draws=None, spawn_log=None):
+    """games: list of oracle Game objects (index = game id); spawn_tape(turn) -> spawn cell per game id (-1 none), or
+    draws(turn, game id) -> the two uniforms Game.tic would draw (game.py:131-133), the cell chosen then appended to
+    spawn_log[turn - 1][game id].  Returns (winners list with None for draws, per-game number of ticks played)."""
     S = games[0].g.S
     if alice_snake_cnt is None:
         alice_snake_cnt = S // 2                                            # pit_mp_game_runner.py:17-18
@@ -37,8 +38,15 @@ def pit_run(games, net_a, net_b, alice_snake_cnt=None, spawn_tape=None):
             dense[g][s] = m
         nxt = []
         tape = spawn_tape(turn) if spawn_tape is not None else None
+        if spawn_log is not None:
+            spawn_log.append(np.full(len(games), -2, np.int16))
         for g in live:
-            done = games[g].tic(dense[g], spawn_cell=int(tape[g]) if tape is not None else -1)
+            if draws is not None:
+                done = games[g].tic(dense[g], draws=draws(turn, g))
+                if spawn_log is not None:
+                    spawn_log[-1][g] = games[g].last_spawn
+            else:
+                done = games[g].tic(dense[g], spawn_cell=int(tape[g]) if tape is not None else -1)
             lengths[g] += 1
             if done:                                                        # :43-47
                 for i, r in enumerate(games[g].rewards):
