@@ -536,3 +536,22 @@ def test_small_self_play_runs_on_graphs_with_the_real_net(env, monkeypatch):
     assert st["net_evals"] > 24 * 20 and 80 <= len(alice.records) <= 96
     v = np.array(alice.values[:80])
     assert np.isfinite(v).all() and (np.abs(v) <= 1).all()
+
+
+def test_sequential_mode_tracks_the_c_restatement_on_unrecorded_configurations():
+    """beyond the five recorded reference runs: 40 random configurations (7x7 .. 13x13, 2-4 snakes, three health decrements,
+    breadth 8-24, depth 4-8, four softmax bases, fresh uniform tapes) played on the device in sequential mode and on
+    oracle/mcts_cpu.c (itself pinned to the reference's recorded runs) with the same draws: ids, moves, net-evaluation counts,
+    draws consumed and final boards identical turn by turn, root Q within 1e-5 (tools/fuzz_mcts.py; 600 more seeds:
+    profiles/r3_fuzz_mcts.log)"""
+    import os
+    import re
+    import subprocess
+    import sys
+    from conftest import REPO
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "fuzz_mcts.py"), "1000", "40"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m = re.search(r"fuzz done: (\d+) of 40 runs identical .* worst root \|dQ\| ([0-9.e+-]+)", r.stdout)
+    assert m, r.stdout[-1000:]
+    assert int(m.group(1)) >= 39, r.stdout[-1500:]             # a uniform within 1e-6 of a cdf edge may part the two libms: at most one run
+    assert float(m.group(2)) <= 1e-5

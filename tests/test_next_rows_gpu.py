@@ -47,6 +47,17 @@ def test_pit_winners_match_the_reference_bit_exact(ci):
     assert len(gr.games) == 0
 
 
+def test_pit_pair_tracks_the_oracle_on_unrecorded_setups():
+    """beyond the four recorded reference runs: 30 random setups (7x7 .. 19x19, 2-6 snakes, any team split, three stub nets);
+    the oracle's pit loop plays first, the device replays with the oracle's food spawns: every winner index identical
+    (tools/fuzz_pit.py; 400 more setups: profiles/r3_fuzz_pit.log)"""
+    import subprocess
+    import sys
+    from conftest import REPO
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "fuzz_pit.py"), "2000", "30"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "fuzz ok: 30 pit runs" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 def test_pit_agent_device_path_equals_host_path(oracle):
     """pit_agent.Agent.make_moves on a device tensor of planes (the engine-backed runner's form) and on the reference's
     list of arrays give the same greedy moves"""
