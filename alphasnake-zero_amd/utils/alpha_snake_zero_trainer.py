@@ -99,7 +99,10 @@ class AlphaSnakeZeroTrainer:
         if dist is None:
             wanted, batch_size, _ = sample_plan(n, 1)
             picked = sample(range(n), wanted)
-            X = [alice.records[i] for i in picked]
+            if hasattr(alice.records, "fetch"):        # the engine-backed records: one observe launch for all sampled rows
+                X = list(alice.records.fetch(picked)) if wanted else []
+            else:
+                X = [alice.records[i] for i in picked]
             V = [alice.values[i] for i in picked]
         else:                                  # every rank contributes its share of the rows, all ranks get all rows
             import torch
