@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsnake_engine.so")
+LIB_PATH = os.environ.get("SNK_LIB_PATH") or os.path.join(_HERE, "libsnake_engine.so")      # SNK_LIB_PATH: a variant build (A/B runs)
 
 MAX_SNAKES, MAX_CELLS, MAX_NODES = 8, 361, 384
 
