@@ -63,6 +63,10 @@ struct ConvHsArgs {
     int n_img_grouped;         // images (a multiple of 8) that use the XCD-aware block order
     const float *center;       // MODE 4 (training forward): per-channel centre of the batch-norm sums (or NULL = 0)
     float *stat_part;          // MODE 4: [gridDim.x][2][128] sums of (out - center) and (out - center)^2 over the block's pixels
+    // sub-rectangle form (k_conv3x3_f16s_rect): one descriptor per block, written on the device by k_rect_plan
+    const uint4 *desc;         // { image, y0 | x0 << 8 | h << 16 | w << 24, tile0 | ntile << 8 | part << 16 | parts << 24, fill rectangle }
+    const int *n_desc;         // number of descriptors (blocks past it leave at once)
+    const float *bg_out;       // [Hd][Wd][128]: this layer's output on an all-background image, copied into fill \ rectangle
 };
 
 #ifdef HS_STAMPS       // development build only (tools/conv_stamps.py): s_memtime at the phase boundaries of every block
@@ -90,8 +94,13 @@ extern "C" int snk_dbg_conv_stamps(unsigned long long *h_out, int n_blocks)
 //   is written as f16.  The activations of BASELINE configs[4]'s tower then cost 2 bytes in HBM instead of 4 (the f16 form
 //   with float32 activations is HBM-bound), staging is a plain copy (the values are f16 already: no scale, no clamp, no
 //   conversion) and the range guard has nothing to watch.
-template <int NI, int MODE, bool SPLIT = true, int IO16 = 0>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
+// RECT: the block's "image" is a sub-rectangle (ry0, rx0, rh, rw) of the Hd x Wd canvas (see k_rect_plan below): GEMM rows are
+//   the rectangle's pixels in row-major order, the LDS rows are pitched rw + 2 with the halo columns taken from the canvas
+//   (zero outside it), global rows stay pitched Wd.
+template <int NI, int MODE, bool SPLIT, int IO16, bool RECT>
+__device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *smem, const int img, const int tile0, const int ntile,
+                                         const int ry0, const int rx0, const int rh, const int rw, const unsigned fill,
+                                         const int part, const int parts)
 {
     static_assert(IO16 == 0 || !SPLIT, "f16 activations only exist in the reduced-precision form");
     constexpr bool IN16 = (IO16 & 1) != 0, OUT16 = (IO16 & 2) != 0;
@@ -100,30 +109,28 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
     const bool has_head = MODE == 0 ? p.w1x1 != nullptr : MODE == 3;
     const bool has_out = MODE == 0 ? p.out != nullptr : MODE != 3;
     const float relu_floor = ((MODE != 0 && MODE != 4) || (MODE == 0 && p.relu)) ? 0.f : -__builtin_inff();
-    __shared__ __align__(16) unsigned char smem[HS_SMEM];
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;        // wave wn owns outputs 32 wn .. 32 wn + 31
     const int h = lane >> 5, l31 = lane & 31;
-    // XCD-aware block -> (image, part) map: workgroups go round-robin to the 8 XCDs, each with its own L2, and the parts of
-    // an image share halo rows; parts of one image are therefore 8 workgroups apart (same XCD, dispatched back to back)
-    int img, blk;
-    {
-        const int b = blockIdx.x, per = 8 * p.n_blk;
-        if (b < p.n_img_grouped * p.n_blk) { const int r = b % per; img = (b / per) * 8 + (r & 7); blk = r >> 3; }
-        else { img = b / p.n_blk; blk = b - img * p.n_blk; }
-    }
-    const int HW = p.Hd * p.Wd;
-    const int tile0 = blk * p.tiles_base + min(blk, p.tiles_rem), ntile = p.tiles_base + (blk < p.tiles_rem ? 1 : 0);
+    const int Wr = RECT ? rw : p.Wd;                       // width of the GEMM's image
+    const int cy0 = RECT ? ry0 : 0, cx0 = RECT ? rx0 : 0;  // its origin on the canvas
+    const int HW = RECT ? rh * rw : p.Hd * p.Wd;           // its pixels = GEMM rows
+    const int HWc = p.Hd * p.Wd;                           // the canvas: what the tensors in HBM are pitched by
     const int m0 = 32 * tile0, m1 = min(32 * (tile0 + ntile), HW);      // the block's GEMM rows = pixels m0 .. m1 - 1 of the image
-    const int P = p.Wd + 1;                                // padded pitch
-    const float invW = 1.0f / (float)p.Wd;
+    const int P = RECT ? Wr + 2 : Wr + 1;                  // padded pitch
+    const float invW = 1.0f / (float)Wr;
     const int y_first = (int)(((float)m0 + 0.5f) * invW), y_last = (int)(((float)(m1 - 1) + 0.5f) * invW);
-    // LDS row r holds image row y_first - 1 + r (zero when outside the image), LDS column x + 1 image column x
+    // LDS row r holds image row y_first - 1 + r (zero when outside the canvas), LDS column x + 1 image column x
 
-    // ---- staging role: item k of this thread = pixel (tid / 4 + 64 k) of the rows the strip needs, float4 (tid % 4) of the chunk
-    const int ry_lo = y_first == 0 ? 1 : 0, ry_hi = min(y_last + 1, p.Hd - 1) - (y_first - 1);   // LDS rows that exist in the image
-    const int npx = (ry_hi - ry_lo + 1) * p.Wd;
-    const float *xrow = p.x + ((long)img * p.Hd + (y_first - 1 + ry_lo)) * p.Wd * HS_C + 4 * (tid & 3);
-    const _Float16 *xrow16 = (const _Float16 *)p.x + ((long)img * p.Hd + (y_first - 1 + ry_lo)) * p.Wd * HS_C + 4 * (tid & 3);
+    // ---- staging role: item k of this thread = pixel (tid / 4 + 64 k) of the strip (the rows and columns of the canvas the
+    //      block's taps reach), float4 (tid % 4) of the chunk
+    const int ya = max(cy0 + y_first - 1, 0), yb = min(cy0 + y_last + 1, p.Hd - 1);          // canvas rows of the strip
+    const int xa = RECT ? max(cx0 - 1, 0) : 0, xb = RECT ? min(cx0 + Wr, p.Wd - 1) : p.Wd - 1;   // its canvas columns
+    const int ry_lo = ya - (cy0 + y_first - 1), cx_lo = RECT ? xa - (cx0 - 1) : 1;             // LDS row / column of (ya, xa)
+    const int ws = xb - xa + 1;
+    const int npx = (yb - ya + 1) * ws;
+    const float invWs = RECT ? 1.0f / (float)ws : invW;
+    const float *xrow = p.x + (((long)img * p.Hd + ya) * p.Wd + xa) * HS_C + 4 * (tid & 3);
+    const _Float16 *xrow16 = (const _Float16 *)p.x + (((long)img * p.Hd + ya) * p.Wd + xa) * HS_C + 4 * (tid & 3);
     const int pix0 = tid >> 2;
     const float xs = p.wscale_inv[2];                      // activations are multiplied by this power of two before the split
     unsigned ldo[HS_NST];                                  // LDS byte offset (inside a buffer) of the thread's items
@@ -132,9 +139,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
 #pragma unroll
     for (int k = 0; k < HS_NST; ++k) {
         const int pix_ = min(pix0 + 64 * k, npx - 1);
-        const int r_ = (int)(((float)pix_ + 0.5f) * invW), x_ = pix_ - r_ * p.Wd;
-        ldo[k] = ((ry_lo + r_) * P + x_ + 1) * HS_LDP + (tid & 3) * 8;
-        gof[k] = pix_ * HS_C;
+        const int r_ = (int)(((float)pix_ + 0.5f) * invWs), x_ = pix_ - r_ * ws;
+        ldo[k] = ((ry_lo + r_) * P + cx_lo + x_) * HS_LDP + (tid & 3) * 8;
+        gof[k] = (r_ * p.Wd + x_) * HS_C;
     }
     float4 st[HS_NST];
     f16x4 st16[HS_NST];
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int m_ = min(m0 + 32 * i + l31, HW - 1);     // rows past the image repeat its last pixel (computed, never stored)
-        const int y_ = (int)(((float)m_ + 0.5f) * invW), x_ = m_ - y_ * p.Wd;
+        const int y_ = (int)(((float)m_ + 0.5f) * invW), x_ = m_ - y_ * Wr;
         la[i] = (unsigned)((y_ - (y_first - 1)) * P + x_ + 1) * HS_LDP + 16 * h;
     }
 #define HS_LDS(off) (*(const f16x8 *)(smem + (off)))
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
     float4 cen4 = make_float4(0.f, 0.f, 0.f, 0.f), st_s = cen4, st_q = cen4;
     if (STATS && p.center) cen4 = *(const float4 *)(p.center + 4 * cq);
     float *Ms = (float *)smem;                                      // [2][64 rows][HS_MLD]
-    const long obase = (long)img * HW * HS_C + 4 * cq;
+    const long obase = (long)img * HWc * HS_C + 4 * cq;
     float4 wh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (has_head) wh = *(const float4 *)(p.w1x1 + 4 * cq);
     constexpr int NPASS = (NI + 1) / 2;
@@ -295,7 +302,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
     {                                                                                           \
         _Pragma("unroll") for (int j = 0; j < HS_ROWS(pass) / 8; ++j) {                         \
             const int m_ = m0 + 64 * (pass) + rr0 + 8 * j;                                      \
-            off[(pass) & 1][j] = m_ < m1 ? m_ * HS_C : -1;                                      \
+            if (RECT) {                                                                         \
+                const int y_ = (int)(((float)m_ + 0.5f) * invW), x_ = m_ - y_ * Wr;             \
+                off[(pass) & 1][j] = m_ < m1 ? ((cy0 + y_) * p.Wd + cx0 + x_) * HS_C : -1;      \
+            } else off[(pass) & 1][j] = m_ < m1 ? m_ * HS_C : -1;                               \
         }                                                                                       \
         if (has_res) {                                                                          \
             _Pragma("unroll") for (int j = 0; j < HS_ROWS(pass) / 8; ++j) {                     \
@@ -351,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
                 d_ += hs_dpp(d_, 0xB1); d_ += hs_dpp(d_, 0x4E); d_ += hs_dpp(d_, 0x141); d_ += hs_dpp(d_, 0x140);
                 d_ += __shfl_xor(d_, 16, 64);
                 if (cq == 0 && off[pass & 1][j] >= 0)
-                    p.h1[(long)img * HW + off[pass & 1][j] / HS_C] = fmaxf(__builtin_fmaf(d_, p.s1, p.b1), 0.f);
+                    p.h1[(long)img * HWc + off[pass & 1][j] / HS_C] = fmaxf(__builtin_fmaf(d_, p.s1, p.b1), 0.f);
             }
         }
     }
@@ -370,7 +380,56 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
             *(float4 *)(p.stat_part + (size_t)blockIdx.x * 256 + rr0 * 128 + 4 * cq) = t;
         }
     }
+    if (RECT && p.bg_out) {
+        // the layers that read this output reach beyond the rectangle: the pixels of the fill rectangle outside it take the
+        // layer's state-independent background values; the image's parts share the pixels, 32 lanes per pixel
+        const int fy0 = fill & 255, fx0 = (fill >> 8) & 255, fh = (fill >> 16) & 255, fw = fill >> 24;
+        const float invF = 1.0f / (float)fw;
+        for (int q = part * 8 + rr0; q < fh * fw; q += 8 * parts) {
+            const int fy = (int)(((float)q + 0.5f) * invF), y_ = fy0 + fy, x_ = fx0 + q - fy * fw;
+            if (y_ >= cy0 && y_ < cy0 + rh && x_ >= cx0 && x_ < cx0 + rw) continue;
+            const int o_ = (y_ * p.Wd + x_) * HS_C + 4 * cq;
+            *(float4 *)(p.out + (long)img * HWc * HS_C + o_) = *(const float4 *)(p.bg_out + o_);
+        }
+    }
     HS_STAMP(4)
+}
+
+template <int NI, int MODE, bool SPLIT = true, int IO16 = 0>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
+{
+    __shared__ __align__(16) unsigned char smem[HS_SMEM];
+    // XCD-aware block -> (image, part) map: workgroups go round-robin to the 8 XCDs, each with its own L2, and the parts of
+    // an image share halo rows; parts of one image are therefore 8 workgroups apart (same XCD, dispatched back to back)
+    int img, blk;
+    {
+        const int b = blockIdx.x, per = 8 * p.n_blk;
+        if (b < p.n_img_grouped * p.n_blk) { const int r = b % per; img = (b / per) * 8 + (r & 7); blk = r >> 3; }
+        else { img = b / p.n_blk; blk = b - img * p.n_blk; }
+    }
+    const int tile0 = blk * p.tiles_base + min(blk, p.tiles_rem), ntile = p.tiles_base + (blk < p.tiles_rem ? 1 : 0);
+    hs_block<NI, MODE, SPLIT, IO16, false>(p, smem, img, tile0, ntile, 0, 0, 0, 0, 0u, 0, 1);
+}
+
+// The sub-rectangle form.  The reference's observation (game.py:215-257) is one background pixel (0, WALL, 0) everywhere
+// outside the board window, so the output of the tower's k-th 3x3 layer is the same for every state outside the window
+// grown by k + 1 pixels: only that rectangle is computed per image, everything else is a per-layer constant
+// (QNet._backgrounds).  Blocks take (image, rectangle, tile range) from descriptors; the M-tile count of a block selects
+// the body at run time (wave-uniform), so one launch covers every rectangle shape of the batch.
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_f16s_rect(ConvHsArgs p)
+{
+    __shared__ __align__(16) unsigned char smem[HS_SMEM];
+    if ((int)blockIdx.x >= *p.n_desc) return;
+    const uint4 d = p.desc[blockIdx.x];
+    const int img = (int)d.x, ry0 = d.y & 255, rx0 = (d.y >> 8) & 255, rh = (d.y >> 16) & 255, rw = d.y >> 24;
+    const int tile0 = d.z & 255, ntile = (d.z >> 8) & 255, part = (d.z >> 16) & 255, parts = d.z >> 24;
+#define HS_RECT_CASE(NI_) case NI_: hs_block<NI_, MODE, true, 0, true>(p, smem, img, tile0, ntile, ry0, rx0, rh, rw, d.w, part, parts); break;
+    switch (ntile) {
+        HS_RECT_CASE(1) HS_RECT_CASE(2) HS_RECT_CASE(3) HS_RECT_CASE(4) HS_RECT_CASE(5) HS_RECT_CASE(6) HS_RECT_CASE(7)
+    default: hs_block<8, MODE, true, 0, true>(p, smem, img, tile0, ntile, ry0, rx0, rh, rw, d.w, part, parts); break;
+    }
+#undef HS_RECT_CASE
 }
 
 // max |w| of the layer -> k with 256 <= max * 2^k < 512; writes {2^-k, 2^k, x_scale, 1 / x_scale, range flag = 0} behind the fragment image
@@ -499,7 +558,7 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
     SNK_REQUIRE((long)n_images * n_blk < (1l << 31) && (long)HW * HS_C < (1l << 31), "snk_conv3x3_bn_f16s: batch too large");
     ConvHsArgs a = {d_x, (const f16x8 *)d_wS, (const float *)((const _Float16 *)d_wS + HS_WS_ELEMS), d_scale, d_shift,
                     d_residual, d_out, d_w1x1, d_h1, s1, b1, height, width, n_blk, tiles_base, tiles_rem, relu, (n_images / 8) * 8,
-                    d_center, d_stat_part};
+                    d_center, d_stat_part, nullptr, nullptr, nullptr};
     const int n_mt = tiles_max, grid = n_images * n_blk;
     hipStream_t st = (hipStream_t)stream;
     if (grid_out) *grid_out = grid;
@@ -569,6 +628,175 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
         break;
     }
 #undef HS_LAUNCH_MODES
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- planning of the sub-rectangle form ------------------------------------------------------------------------------
+// parts (blocks) a rectangle of hr x wr pixels is cut into and the M tiles of its largest part: the fewest parts of at most
+// 8 tiles whose strip (their rows, one above, one below, halo columns) fits the LDS buffer and the staging items
+__host__ __device__ static inline int hs_rect_parts(int hr, int wr, int Hd, int Wd, int *tiles_max)
+{
+    const int T = (hr * wr + 31) / 32;
+    for (int parts = (T + 7) / 8;; ++parts) {
+        const int tm = (T + parts - 1) / parts;
+        int rows_out = (tm * 32 + wr - 2) / wr + 1;                       // worst alignment of 32 tm pixels
+        if (rows_out > hr) rows_out = hr;
+        const int rows_in = rows_out + 2 < Hd ? rows_out + 2 : Hd, cols_in = wr + 2 < Wd ? wr + 2 : Wd;
+        const bool fits = (rows_out + 2) * (wr + 2) <= HS_NPB && rows_in * cols_in <= 64 * HS_NST;
+        if (fits || tm == 1) { *tiles_max = tm; return fits ? parts : -1; }
+    }
+}
+
+// bounding box of the pixels of an observation [H][W][3] that differ from the background pixel (b0, b1, b2): one wavefront
+// per observation; an observation without such a pixel gets the centre pixel
+__global__ __launch_bounds__(256) void k_obs_bbox(const float *__restrict__ planes, int n, int Hd, int Wd, float b0, float b1, float b2,
+                                                  unsigned *__restrict__ bbox)
+{
+    const int img = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (img >= n) return;
+    const float *x = planes + (long)img * Hd * Wd * 3;
+    const float invW = 1.0f / (float)Wd;
+    int y0 = 255, x0 = 255, y1 = -1, x1 = -1;
+    for (int q = lane; q < Hd * Wd; q += 64) {
+        const float v0 = x[3 * q], v1 = x[3 * q + 1], v2 = x[3 * q + 2];
+        if (!(v0 == b0 && v1 == b1 && v2 == b2)) {
+            const int y_ = (int)(((float)q + 0.5f) * invW), x_ = q - y_ * Wd;
+            y0 = min(y0, y_); y1 = max(y1, y_); x0 = min(x0, x_); x1 = max(x1, x_);
+        }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        y0 = min(y0, __shfl_xor(y0, s, 64)); x0 = min(x0, __shfl_xor(x0, s, 64));
+        y1 = max(y1, __shfl_xor(y1, s, 64)); x1 = max(x1, __shfl_xor(x1, s, 64));
+    }
+    if (lane == 0) {
+        if (y1 < 0) { y0 = y1 = Hd / 2; x0 = x1 = Wd / 2; }
+        bbox[img] = (unsigned)y0 | (unsigned)x0 << 8 | (unsigned)y1 << 16 | (unsigned)x1 << 24;
+    }
+}
+
+#define HS_RECT_MAX_LAYERS 24
+struct RectPlanArgs {
+    int n_layers;
+    int grow[HS_RECT_MAX_LAYERS];          // the layer's rectangle = bounding box grown by this many pixels, cut to the canvas
+    int fill[HS_RECT_MAX_LAYERS];          // its fill rectangle = the rectangle grown by this many more (< 0: the whole canvas)
+    uint4 *desc;                           // [n_layers][max_blocks]
+    long max_blocks;
+    int *counts;                           // [n_layers][2]: descriptors written, M tiles they cover
+};
+
+// One workgroup per layer: every image's rectangle -> its parts -> block descriptors, largest blocks first (bins by the
+// image's largest part; the order inside a bin is whatever the atomics give -- no result depends on it)
+__global__ __launch_bounds__(1024) void k_rect_plan(const unsigned *__restrict__ bbox, int n, int Hd, int Wd, RectPlanArgs a)
+{
+    __shared__ int cnt[9], cur[9], tiles_sum;
+    const int L = blockIdx.x, g = a.grow[L], fg = a.fill[L], tid = threadIdx.x;
+    if (tid < 9) cnt[tid] = 0;
+    if (tid == 0) tiles_sum = 0;
+    __syncthreads();
+    int tiles = 0;
+    for (int img = tid; img < n; img += 1024) {
+        const unsigned b = bbox[img];
+        const int y0 = max((int)(b & 255) - g, 0), x0 = max((int)((b >> 8) & 255) - g, 0);
+        const int y1 = min((int)((b >> 16) & 255) + g, Hd - 1), x1 = min((int)(b >> 24) + g, Wd - 1);
+        int tm;
+        const int parts = hs_rect_parts(y1 - y0 + 1, x1 - x0 + 1, Hd, Wd, &tm);
+        atomicAdd(&cnt[tm], parts);
+        tiles += ((y1 - y0 + 1) * (x1 - x0 + 1) + 31) / 32;
+    }
+    atomicAdd(&tiles_sum, tiles);
+    __syncthreads();
+    if (tid == 0) {
+        int o = 0;
+        for (int tm = 8; tm >= 1; --tm) { cur[tm] = o; o += cnt[tm]; }
+        a.counts[2 * L] = o;
+        a.counts[2 * L + 1] = tiles_sum;
+    }
+    __syncthreads();
+    uint4 *desc = a.desc + (long)L * a.max_blocks;
+    for (int img = tid; img < n; img += 1024) {
+        const unsigned b = bbox[img];
+        const int y0 = max((int)(b & 255) - g, 0), x0 = max((int)((b >> 8) & 255) - g, 0);
+        const int y1 = min((int)((b >> 16) & 255) + g, Hd - 1), x1 = min((int)(b >> 24) + g, Wd - 1);
+        const int hr = y1 - y0 + 1, wr = x1 - x0 + 1;
+        int tm;
+        const int parts = hs_rect_parts(hr, wr, Hd, Wd, &tm);
+        const int T = (hr * wr + 31) / 32, base = T / parts, rem = T % parts;
+        int fy0 = 0, fx0 = 0, fy1 = Hd - 1, fx1 = Wd - 1;
+        if (fg >= 0) { fy0 = max(y0 - fg, 0); fx0 = max(x0 - fg, 0); fy1 = min(y1 + fg, Hd - 1); fx1 = min(x1 + fg, Wd - 1); }
+        const unsigned rect = (unsigned)y0 | (unsigned)x0 << 8 | (unsigned)hr << 16 | (unsigned)wr << 24;
+        const unsigned fill = (unsigned)fy0 | (unsigned)fx0 << 8 | (unsigned)(fy1 - fy0 + 1) << 16 | (unsigned)(fx1 - fx0 + 1) << 24;
+        const int slot = atomicAdd(&cur[tm], parts);
+        for (int k = 0; k < parts; ++k) {
+            const int tile0 = k * base + min(k, rem), ntile = base + (k < rem ? 1 : 0);
+            desc[slot + k] = make_uint4((unsigned)img, rect, (unsigned)tile0 | (unsigned)ntile << 8 | (unsigned)k << 16 | (unsigned)parts << 24, fill);
+        }
+    }
+}
+
+static int rect_max_parts(int height, int width)
+{
+    static int cache_h = 0, cache_w = 0, cache_v = 0;
+    if (cache_h == height && cache_w == width) return cache_v;
+    int worst = 1;
+    for (int hr = 1; hr <= height; ++hr)
+        for (int wr = 1; wr <= width; ++wr) {
+            int tm;
+            const int parts = hs_rect_parts(hr, wr, height, width, &tm);
+            if (parts < 0) return -1;
+            if (parts > worst) worst = parts;
+        }
+    cache_h = height; cache_w = width; cache_v = worst;
+    return worst;
+}
+
+extern "C" long snk_conv_rect_max_blocks(int n_images, int height, int width)
+{
+    if (n_images < 0 || height < 3 || width < 3 || height > 80 || width > 80) return -1;
+    const int mp = rect_max_parts(height, width);
+    return mp < 0 ? -1 : (long)n_images * mp;
+}
+
+extern "C" int snk_conv_rect_plan(const float *d_planes, float b0, float b1, float b2, int n_images, int height, int width,
+                                  int n_layers, const int *grow, const int *fill_grow, void *d_bbox, void *d_desc, int *d_counts,
+                                  void *stream)
+{
+    SNK_REQUIRE(d_planes && grow && fill_grow && d_bbox && d_desc && d_counts, "snk_conv_rect_plan: NULL argument");
+    SNK_REQUIRE(n_layers >= 1 && n_layers <= HS_RECT_MAX_LAYERS, "snk_conv_rect_plan: %d layers (at most %d)", n_layers, HS_RECT_MAX_LAYERS);
+    const long mb = snk_conv_rect_max_blocks(n_images, height, width);
+    SNK_REQUIRE(mb >= 0 && mb < (1l << 31), "snk_conv_rect_plan: bad shape %d x %d x %d", n_images, height, width);
+    if (n_images == 0) return 0;
+    RectPlanArgs a;
+    a.n_layers = n_layers;
+    for (int i = 0; i < n_layers; ++i) {
+        SNK_REQUIRE(grow[i] >= 0 && grow[i] < 128, "snk_conv_rect_plan: grow[%d] = %d", i, grow[i]);
+        a.grow[i] = grow[i];
+        a.fill[i] = fill_grow[i] > 127 ? 127 : fill_grow[i];
+    }
+    a.desc = (uint4 *)d_desc; a.max_blocks = mb; a.counts = d_counts;
+    hipStream_t st = (hipStream_t)stream;
+    k_obs_bbox<<<(n_images + 3) / 4, 256, 0, st>>>(d_planes, n_images, height, width, b0, b1, b2, (unsigned *)d_bbox);
+    k_rect_plan<<<n_layers, 1024, 0, st>>>((const unsigned *)d_bbox, n_images, height, width, a);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int snk_conv3x3_bn_f16s_rect(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
+                                        const float *d_residual, float *d_out, const void *d_desc, const int *d_count,
+                                        const float *d_bg_out, int n_images, int height, int width, void *stream)
+{
+    SNK_REQUIRE(d_x && d_wS && d_scale && d_shift && d_out && d_desc && d_count, "snk_conv3x3_bn_f16s_rect: NULL argument");
+    SNK_REQUIRE(d_out != d_x, "snk_conv3x3_bn_f16s_rect: in-place convolution is not possible");
+    const long mb = snk_conv_rect_max_blocks(n_images, height, width);
+    SNK_REQUIRE(mb >= 0 && mb < (1l << 31) && (long)height * width * HS_C < (1l << 31), "snk_conv3x3_bn_f16s_rect: bad shape %d x %d x %d",
+                n_images, height, width);
+    if (n_images == 0) return 0;
+    ConvHsArgs a = {d_x, (const f16x8 *)d_wS, (const float *)((const _Float16 *)d_wS + HS_WS_ELEMS), d_scale, d_shift,
+                    d_residual, d_out, nullptr, nullptr, 0.f, 0.f, height, width, 1, 0, 0, 1, 0, nullptr, nullptr,
+                    (const uint4 *)d_desc, d_count, d_bg_out};
+    if (d_residual) k_conv3x3_f16s_rect<2><<<(int)mb, 256, 0, (hipStream_t)stream>>>(a);
+    else k_conv3x3_f16s_rect<1><<<(int)mb, 256, 0, (hipStream_t)stream>>>(a);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -92,6 +92,26 @@ def n_blocks_of(weights):
     return (len(weights) - 14) // 10
 
 
+BACKGROUND_PIXEL = (0.0, 1.0, 0.0)      # game.py:218: every pixel of an observation outside the board window is [0, WALL, 0]
+
+
+def rect_layer_count(h, w, n_layers, threshold=0.93):
+    """How many of the tower's first layers run in the sub-rectangle form by default: tower layer i needs the board window
+    (B x B, B = (h + 1) / 2, somewhere on the canvas with the head in the centre) grown by i + 2 pixels; the form pays while
+    the grown window, averaged over the head positions, stays below `threshold` of the canvas.  The last layer always
+    runs in full (its epilogue feeds the head)."""
+    bh, bw = (h + 1) // 2, (w + 1) // 2
+    count = 0
+    for i in range(max(n_layers - 1, 0)):
+        g = i + 2
+        ly = [min(h - 1, s + bh - 1 + g) - max(0, s - g) + 1 for s in range(h - bh + 1)]
+        lx = [min(w - 1, s + bw - 1 + g) - max(0, s - g) + 1 for s in range(w - bw + 1)]
+        if (sum(ly) / len(ly)) * (sum(lx) / len(lx)) >= threshold * h * w:
+            break
+        count += 1
+    return count
+
+
 class QNet:
     def __init__(self, weights, input_shape, device=None, max_chunk=4096):
         if not torch.cuda.is_available():
@@ -113,6 +133,12 @@ class QNet:
         # activations is HBM-bound): the fastest reduced-precision option, for BASELINE configs[4]
         if self.conv_algo not in ("f16s", "winograd", "direct", "bf16", "f16", "f16a"):
             raise EngineError(f"SNK_CONV_ALGO={self.conv_algo!r}: expected f16s, winograd, direct, f16, f16a or bf16")
+        # sub-rectangle form of the first tower layers (snk_conv3x3_bn_f16s_rect): SNK_CONV_RECT=0 switches it off,
+        # SNK_CONV_RECT_LAYERS=n fixes the number of layers that use it
+        self.rect = self.conv_algo == "f16s" and os.environ.get("SNK_CONV_RECT", "1") != "0"
+        self.background = BACKGROUND_PIXEL
+        self.rect_tiles = None       # set to [] to collect every chunk's (images, per-layer GEMM tiles) device tensors
+        self._bg = None
         self.n_streams = int(os.environ.get("SNK_NET_STREAMS", "1"))   # 2: chunks alternate between two streams (+0.8 % end to end,
         #    but per-launch HIP-event timings then overlap, so bench.py keeps the single-stream default)
         self._side = None
@@ -159,6 +185,15 @@ class QNet:
         self.fc1_w, self.fc1_b = t[base + 5].contiguous(), t[base + 6].contiguous()
         self.fc2_w, self.fc2_b = t[base + 7].contiguous(), t[base + 8].contiguous()
         self.calibrated = False                 # new weights: the next caller with observations at hand calibrates
+        self._bg = None
+        n_layers = 2 * self.blocks
+        self.n_rect = rect_layer_count(self.h, self.w, n_layers) if self.rect else 0
+        if self.rect and "SNK_CONV_RECT_LAYERS" in os.environ:
+            self.n_rect = max(0, min(int(os.environ["SNK_CONV_RECT_LAYERS"]), n_layers - 1))
+        # the output of tower layer i is read by layer i + 1 and, when it closes a residual block, by layer i + 2 as the
+        # shortcut: a sub-rectangle layer fills 2 pixels around its rectangle for sub-rectangle readers, the whole canvas
+        # when a full layer reads it
+        self.rect_fill = [-1 if (i + 1 >= self.n_rect or (i % 2 == 1 and i + 2 >= self.n_rect)) else 2 for i in range(self.n_rect)]
         torch.cuda.current_stream().synchronize()
 
     def get_weights(self):
@@ -176,6 +211,7 @@ class QNet:
         t = self._tail(i, torch.float32)
         t[2] = float(scale)
         t[3] = 1.0 / float(scale)
+        self._bg = None                         # the backgrounds are kept bit-identical to what the full layers give
 
     def range_flags(self, clear=True):
         """per tower layer: 1 when a launch since the last call clamped an input (one small device-to-host copy)"""
@@ -325,9 +361,10 @@ class QNet:
         cur, t1, t2 = a, b, c
         # the last layer's epilogue also does the head's 1x1 stage (snk_head_dense_f32 keeps 16 states' h1 in 64 KB of LDS)
         fused_head = self.conv_algo == "f16s" and self.blocks > 0 and 16 * (h * w + 128) * 4 <= 64 * 1024
+        plan = self._rect_plan(x, m, k, st) if self.n_rect > 0 else None
         for blk in range(self.blocks):
             i0, i1 = 2 * blk, 2 * blk + 1
-            self._conv(i0, cur, None, t1, m, st)
+            self._conv(i0, cur, None, t1, m, st, plan=plan)
             if fused_head and blk == self.blocks - 1:
                 h1 = self._h1_workspace(m, k)
                 self._conv(i1, t1, cur, None, m, st, h1=h1)
@@ -336,7 +373,7 @@ class QNet:
                                            self.fc2_b.data_ptr(), 0 if mk is None else mk.data_ptr(), out[s0:s0 + m].data_ptr(),
                                            m, h, w, st))
                 return
-            self._conv(i1, t1, cur, t2, m, st)
+            self._conv(i1, t1, cur, t2, m, st, plan=plan)
             cur, t2 = t2, cur
         mk = None if mask is None else mask[s0:s0 + m]
         check(L.snk_head_f32(cur.data_ptr(), self.head_w.data_ptr(), self.head_s, self.head_b,
@@ -351,11 +388,78 @@ class QNet:
             self._ws[key] = torch.empty((n, self.h * self.w), dtype=torch.float32, device=self.device)
         return self._ws[key]
 
-    def _conv(self, i, x, res, out, m, st, h1=None):
+    # ---- sub-rectangle form ----------------------------------------------------------------------
+    def backgrounds(self):
+        """[n_rect][h][w][128]: the outputs of the first tower layers on an all-background observation, computed with the
+        full kernels themselves (so that a pixel the sub-rectangle form fills equals the pixel the full form computes,
+        bit for bit); made again when the weights or an activation scale change."""
+        if self._bg is None:
+            m, st = 1, torch.cuda.current_stream().cuda_stream
+            blank = torch.tensor(self.background, dtype=torch.float32, device=self.device).repeat(1, self.h, self.w, 1).contiguous()
+            bufs = [torch.empty((1, self.h, self.w, 128), dtype=torch.float32, device=self.device) for _ in range(3)]
+            check(self.L.snk_stem_conv_bn_relu_f32(blank.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(),
+                                                   self.stem_sh.data_ptr(), bufs[0].data_ptr(), m, self.h, self.w, st))
+            bg = torch.empty((self.n_rect, self.h, self.w, 128), dtype=torch.float32, device=self.device)
+            cur, t1, t2 = bufs
+            tm, self.conv_timing = self.conv_timing, None
+            for i in range(self.n_rect):
+                if i % 2 == 0:
+                    self._conv(i, cur, None, t1, m, st)
+                    bg[i].copy_(t1[0])
+                else:
+                    self._conv(i, t1, cur, t2, m, st)
+                    bg[i].copy_(t2[0])
+                    cur, t2 = t2, cur
+            self.conv_timing = tm
+            self._bg = bg
+        return self._bg
+
+    def _rect_plan(self, x, m, k, st):
+        """descriptors of this chunk's sub-rectangle layers: (descriptor tensor [n_rect][max_blocks][4], counts [n_rect][2])"""
+        bg = self.backgrounds()
+        mb = int(self.L.snk_conv_rect_max_blocks(m, self.h, self.w))
+        if mb < 0:
+            raise EngineError(f"sub-rectangle convolution: shape {m} x {self.h} x {self.w} not supported")
+        key = ("rect", k)
+        capturing = torch.cuda.is_current_stream_capturing()
+        ws = None if capturing or self._ws is None else self._ws.get(key)
+        if ws is None or ws[0].shape[1] < mb or ws[2].shape[0] < m:
+            ws = (torch.empty((self.n_rect, mb, 4), dtype=torch.int32, device=self.device),
+                  torch.zeros((self.n_rect, 2), dtype=torch.int32, device=self.device),
+                  torch.empty((m,), dtype=torch.int32, device=self.device))
+            if not capturing:
+                if self._ws is None:
+                    self._ws = {}
+                self._ws[key] = ws
+        desc, counts, bbox = ws
+        if self.rect_tiles is not None:          # bench.py: what the launches really executed
+            counts = torch.zeros((self.n_rect, 2), dtype=torch.int32, device=self.device)
+            self.rect_tiles.append((m, counts))
+        import ctypes as C
+        grow = (C.c_int * self.n_rect)(*[i + 2 for i in range(self.n_rect)])
+        fill = (C.c_int * self.n_rect)(*self.rect_fill)
+        # the descriptor array of layer l starts at l * max_blocks(m): the tensor may be wider (an earlier, larger chunk)
+        desc_m = desc if desc.shape[1] == mb else desc.view(-1)[:self.n_rect * mb * 4].view(self.n_rect, mb, 4)
+        b0, b1, b2 = self.background
+        check(self.L.snk_conv_rect_plan(x.data_ptr(), b0, b1, b2, m, self.h, self.w, self.n_rect, grow, fill,
+                                        bbox.data_ptr(), desc_m.data_ptr(), counts.data_ptr(), st))
+        return desc_m, counts, bg
+
+    def _conv(self, i, x, res, out, m, st, h1=None, plan=None):
         tm = self.conv_timing
         if tm is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream())
+        if plan is not None and i < self.n_rect and h1 is None:
+            desc, counts, bg = plan
+            check(self.L.snk_conv3x3_bn_f16s_rect(x.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
+                                                  self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),
+                                                  out.data_ptr(), desc[i].data_ptr(), counts[i].data_ptr(), bg[i].data_ptr(),
+                                                  m, self.h, self.w, st))
+            if tm is not None:
+                e1.record(torch.cuda.current_stream())
+                tm.append((e0, e1, 2.0 * m * self.h * self.w * 9 * 128 * 128))
+            return
         if h1 is not None:
             check(self.L.snk_conv3x3_bn_f16s_head(x.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
                                                   self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),

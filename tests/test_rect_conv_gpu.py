@@ -1,0 +1,262 @@
+"""GPU tests of the sub-rectangle form of the tower's 3x3 layers (csrc/conv_split.hip: k_obs_bbox, k_rect_plan,
+k_conv3x3_f16s_rect; snake_engine/net.py: QNet.backgrounds / _rect_plan).
+
+The reference's observation (game.py:215-257) is [0, WALL, 0] outside the board window, so a layer's output outside the
+window grown by one pixel per layer is state-independent.  The form computes the grown window only and copies the rest
+from a per-layer constant; it has to give the SAME BITS as the full convolution (each output pixel is the same chain of
+MFMAs on the same operands), which is what these tests assert -- the 1e-5 parity of the net against the CPU restatement
+(tests/test_net_gpu.py) runs through this form too, since it is the default."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available()
+    import snake_engine
+    from snake_engine import net
+    return torch, snake_engine, net
+
+
+def _randomised_bn(ws, seed):
+    rng = np.random.RandomState(seed)
+    out = [w.copy() for w in ws]
+    k = 0
+    while k < len(out):
+        if out[k].ndim == 4:
+            n = out[k].shape[3]
+            out[k + 1] = (1.0 + 0.2 * rng.randn(n)).astype(np.float32)
+            out[k + 2] = (0.1 * rng.randn(n)).astype(np.float32)
+            out[k + 3] = (0.05 * rng.randn(n)).astype(np.float32)
+            out[k + 4] = (0.5 + rng.rand(n)).astype(np.float32)
+            k += 5
+        else:
+            k += 1
+    return out
+
+
+def _mid_game_planes(se, torch, n, board, snakes, ticks, seed):
+    eng = se.Engine(n, board, board, snakes, 1, 0.15, seed=seed)
+    eng.reset()
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    for _ in range(ticks):
+        pairs = torch.nonzero(eng.alive()).to(torch.int32).contiguous()
+        _, mask, _ = eng.observe_all(pairs, want_planes=False, want_key=False)
+        pick = torch.multinomial((mask == 0).to(torch.float32) + 1e-3, 1, generator=g).squeeze(1).to(torch.uint8)
+        mv = torch.ones((n, snakes), dtype=torch.uint8, device="cuda")
+        mv[pairs[:, 0].long(), pairs[:, 1].long()] = pick
+        eng.step(mv)
+    pairs = torch.nonzero(eng.alive()).to(torch.int32).contiguous()
+    planes, mask, _ = eng.observe_all(pairs)
+    return planes, mask
+
+
+def _special_observations(torch, h, w):
+    """observations the engine never produces: all background, one foreign pixel in a corner / on an edge / in the
+    centre, no background at all, a window touching two canvas edges"""
+    bgp = torch.tensor([0.0, 1.0, 0.0])
+    obs = []
+    x = bgp.repeat(h, w, 1); obs.append(x.clone())
+    for (y, xx) in ((0, 0), (h - 1, w - 1), (0, w // 2), (h // 2, 0), (h // 2, w // 2), (h - 1, 0)):
+        t = x.clone(); t[y, xx] = torch.tensor([0.3, 0.2, 0.1]); obs.append(t)
+    g = torch.Generator().manual_seed(9)
+    obs.append(torch.rand(h, w, 3, generator=g))
+    t = x.clone(); t[:h // 2 + 1, w // 2:] = torch.rand(h // 2 + 1, w - w // 2, 3, generator=g); obs.append(t)
+    t = x.clone(); t[3, 5] = torch.tensor([float("nan"), 1.0, 0.0]); obs.append(t)        # NaN is not the background
+    return torch.stack(obs).contiguous()
+
+
+def _parts(hr, wr, H, W):
+    """csrc/conv_split.hip hs_rect_parts: the fewest parts of at most 8 tiles whose strip fits the LDS buffer (352 pixels)
+    and the staging items (320 pixels)"""
+    T = (hr * wr + 31) // 32
+    parts = (T + 7) // 8
+    while True:
+        tm = (T + parts - 1) // parts
+        rows_out = min((tm * 32 + wr - 2) // wr + 1, hr)
+        if (rows_out + 2) * (wr + 2) <= 352 and min(rows_out + 2, H) * min(wr + 2, W) <= 320:
+            return parts
+        assert tm > 1
+        parts += 1
+
+
+def test_plan_matches_a_numpy_model(env):
+    """bounding boxes, rectangles, parts and fill rectangles of the plan against a NumPy restatement; every image's tiles
+    are covered exactly once, blocks come largest first"""
+    torch, se, net = env
+    from snake_engine._lib import lib, check
+    L = lib()
+    h = w = 21
+    s = load_golden("states_11x11x4.npz")
+    planes = torch.cat([torch.as_tensor(s["raw"]), _special_observations(torch, h, w)]).cuda().contiguous()
+    n = planes.shape[0]
+    grow, fill = [2, 3, 4, 7], [2, 2, -1, -1]
+    mb = L.snk_conv_rect_max_blocks(n, h, w)
+    assert mb == n * max(_parts(a, b, h, w) for a in range(1, h + 1) for b in range(1, w + 1))
+    desc = torch.full((len(grow), mb, 4), -1, dtype=torch.int32, device="cuda")
+    counts = torch.zeros((len(grow), 2), dtype=torch.int32, device="cuda")
+    bbox = torch.zeros(n, dtype=torch.int32, device="cuda")
+    check(L.snk_conv_rect_plan(planes.data_ptr(), 0.0, 1.0, 0.0, n, h, w, len(grow), (C.c_int * 4)(*grow), (C.c_int * 4)(*fill),
+                               bbox.data_ptr(), desc.data_ptr(), counts.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    ph = planes.cpu().numpy()
+    bb = bbox.cpu().numpy().view(np.uint32)
+    boxes = []
+    for i in range(n):
+        nz = np.argwhere(~((ph[i, :, :, 0] == 0.0) & (ph[i, :, :, 1] == 1.0) & (ph[i, :, :, 2] == 0.0)))
+        if len(nz) == 0:
+            y0 = y1 = h // 2; x0 = x1 = w // 2
+        else:
+            (y0, x0), (y1, x1) = nz.min(0), nz.max(0)
+        boxes.append((y0, x0, y1, x1))
+        assert (bb[i] & 255, (bb[i] >> 8) & 255, (bb[i] >> 16) & 255, bb[i] >> 24) == (y0, x0, y1, x1), i
+    # the golden observations' boxes are the 11 x 11 board window (the observer's head at the canvas centre)
+    assert all(b[2] - b[0] == 10 and b[3] - b[1] == 10 and b[0] <= 10 <= b[2] for b in boxes[:230])
+    dh, ch = desc.cpu().numpy().view(np.uint32), counts.cpu().numpy()
+    for l, (g, fg) in enumerate(zip(grow, fill)):
+        nd = int(ch[l, 0])
+        d = dh[l, :nd]
+        assert (dh[l, nd:] == 0xFFFFFFFF).all()                          # nothing written past the count
+        ntile = (d[:, 2] >> 8) & 255
+        assert (ntile >= 1).all() and (ntile <= 8).all()
+        seen = {}
+        for img, rect, tl, fl in d:
+            seen.setdefault(int(img), []).append((int(rect), int(tl), int(fl)))
+        assert sorted(seen) == list(range(n))
+        tiles_total = 0
+        order = []
+        for img, rect, tl, fl in d:
+            if ((tl >> 16) & 255) == 0:
+                order.append(int(img))
+        for i in range(n):
+            y0, x0, y1, x1 = boxes[i]
+            ry0, rx0, ry1, rx1 = max(y0 - g, 0), max(x0 - g, 0), min(y1 + g, h - 1), min(x1 + g, w - 1)
+            hr, wr = ry1 - ry0 + 1, rx1 - rx0 + 1
+            T = (hr * wr + 31) // 32
+            tiles_total += T
+            parts = seen[i]
+            assert all(p[0] == (ry0 | rx0 << 8 | hr << 16 | wr << 24) for p in parts), (l, i)
+            assert len(parts) == _parts(hr, wr, h, w) and all((p[1] >> 24) == len(parts) for p in parts)
+            cover = sorted((p[1] & 255, (p[1] >> 8) & 255, (p[1] >> 16) & 255) for p in parts)
+            nxt = 0
+            for k, (t0, nt, part) in enumerate(cover):
+                assert t0 == nxt and part == k
+                nxt += nt
+            assert nxt == T
+            if fg < 0:
+                f = (0, 0, h, w)
+            else:
+                f = (max(ry0 - fg, 0), max(rx0 - fg, 0), min(ry1 + fg, h - 1) - max(ry0 - fg, 0) + 1,
+                     min(rx1 + fg, w - 1) - max(rx0 - fg, 0) + 1)
+            assert all(p[2] == (f[0] | f[1] << 8 | f[2] << 16 | f[3] << 24) for p in parts)
+        assert int(ch[l, 1]) == tiles_total
+        # largest first: the largest part of the images in descriptor order never grows
+        biggest = {i: max((p[1] >> 8) & 255 for p in seen[i]) for i in range(n)}
+        seq = [biggest[i] for i in order]
+        assert seq == sorted(seq, reverse=True)
+
+
+@pytest.mark.parametrize("board,snakes,blocks,n_games,n_rect", [(11, 4, 4, 160, None), (7, 2, 4, 64, None), (11, 4, 4, 64, 7),
+                                                                  (19, 8, 10, 6, None), (5, 2, 2, 32, 3)])
+def test_rect_form_gives_the_same_bits_as_the_full_form(env, board, snakes, blocks, n_games, n_rect, monkeypatch):
+    """whole net: Q of mid-game observations (and of hand-made ones: blank, single foreign pixels on edges and corners, no
+    background at all) through the sub-rectangle layers == through the full layers, bit for bit; and every sub-rectangle
+    layer's output on its fill rectangle == the full layer's output there"""
+    torch, se, net = env
+    h = w = 2 * board - 1
+    ws = _randomised_bn(net.glorot_uniform_weights((h, w, 3), blocks=blocks, seed=board), 5)
+    planes, mask = _mid_game_planes(se, torch, n_games, board, snakes, 12, seed=100 + board)
+    planes = torch.cat([planes, _special_observations(torch, h, w).cuda()]).contiguous()
+    planes = torch.nan_to_num(planes, nan=3.0)
+    m = planes.shape[0]
+    monkeypatch.setenv("SNK_CONV_RECT", "0")
+    full = net.QNet(ws, (h, w, 3), max_chunk=8192)
+    assert full.n_rect == 0
+    monkeypatch.setenv("SNK_CONV_RECT", "1")
+    if n_rect is not None:
+        monkeypatch.setenv("SNK_CONV_RECT_LAYERS", str(n_rect))
+    rect = net.QNet(ws, (h, w, 3), max_chunk=8192)
+    assert rect.n_rect == (n_rect if n_rect is not None else net.rect_layer_count(h, w, 2 * blocks)) and rect.n_rect >= 1
+    q_full = full.forward(planes)
+    q_rect = rect.forward(planes)
+    assert torch.isfinite(q_full).all()
+    assert torch.equal(q_full, q_rect), (q_full - q_rect).abs().max().item()
+    # ragged chunks take the same route
+    rect.max_chunk = 37
+    assert torch.equal(rect.forward(planes), q_full)
+    rect.max_chunk = 8192
+
+    # layer by layer
+    st = torch.cuda.current_stream().cuda_stream
+    from snake_engine._lib import check
+
+    def tower(qn, use_plan):
+        bufs = [torch.full((m, h, w, 128), float("nan"), device="cuda") for _ in range(3)]
+        check(qn.L.snk_stem_conv_bn_relu_f32(planes.data_ptr(), qn.stem_w.data_ptr(), qn.stem_sc.data_ptr(), qn.stem_sh.data_ptr(),
+                                             bufs[0].data_ptr(), m, h, w, st))
+        plan = qn._rect_plan(planes, m, 0, st) if use_plan else None
+        outs, (cur, t1, t2) = [], bufs
+        for i in range(rect.n_rect):
+            if i % 2 == 0:
+                qn._conv(i, cur, None, t1, m, st, plan=plan); outs.append(t1.clone())
+            else:
+                qn._conv(i, t1, cur, t2, m, st, plan=plan); outs.append(t2.clone())
+                cur, t2 = t2, cur
+        return outs, plan
+    o_full, _ = tower(full, False)
+    o_rect, plan = tower(rect, True)
+    desc = plan[0].cpu().numpy().view(np.uint32)
+    counts = plan[1].cpu().numpy()
+    saved = 0
+    for i in range(rect.n_rect):
+        valid = torch.zeros((m, h, w), dtype=torch.bool)
+        for img, _, _, fl in desc[i, :counts[i, 0]]:
+            fy, fx, fh, fw = fl & 255, (fl >> 8) & 255, (fl >> 16) & 255, fl >> 24
+            valid[int(img), fy:fy + fh, fx:fx + fw] = True
+        assert valid.view(m, -1).any(1).all()
+        v = valid.cuda()
+        a, b = o_full[i][v], o_rect[i][v]
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b), (i, (a - b).abs().max().item())
+        if rect.rect_fill[i] < 0:
+            assert v.all()
+        saved += m * ((h * w + 31) // 32) - int(counts[i, 1])
+    assert saved > 0
+
+
+def test_backgrounds_follow_the_weights_and_scales(env):
+    """the per-layer constants are made again after set_weights and after a change of an activation scale (they are kept
+    bit-identical to what the full layers compute)"""
+    torch, se, net = env
+    ws = net.glorot_uniform_weights((21, 21, 3), blocks=4, seed=2)
+    qn = net.QNet(ws, (21, 21, 3))
+    bg0 = qn.backgrounds().clone()
+    assert bg0.shape == (6, 21, 21, 128) and torch.isfinite(bg0).all()
+    # far from the canvas edge the background of a layer is one pixel value (nothing there sees the zero padding)
+    assert torch.equal(bg0[0, 5, 5], bg0[0, 12, 9]) and not torch.equal(bg0[0, 0, 0], bg0[0, 5, 5])
+    qn.set_x_scale(2, qn.conv_x_scale[2] / 4)
+    assert qn._bg is None
+    qn.set_weights(_randomised_bn(ws, 8))
+    assert qn._bg is None and not torch.equal(qn.backgrounds(), bg0)
+
+
+def test_rect_entry_points_refuse_bad_arguments(env):
+    torch, se, net = env
+    from snake_engine._lib import lib
+    L = lib()
+    assert L.snk_conv_rect_max_blocks(4, 2, 21) < 0 and L.snk_conv_rect_max_blocks(4, 21, 81) < 0
+    assert L.snk_conv_rect_max_blocks(0, 21, 21) == 0
+    x = torch.zeros(8, device="cuda")
+    g = (C.c_int * 1)(2)
+    assert L.snk_conv_rect_plan(None, 0.0, 1.0, 0.0, 1, 21, 21, 1, g, g, x.data_ptr(), x.data_ptr(), x.data_ptr(), None) < 0
+    assert L.snk_conv_rect_plan(x.data_ptr(), 0.0, 1.0, 0.0, 1, 21, 21, 25, g, g, x.data_ptr(), x.data_ptr(), x.data_ptr(), None) < 0
+    assert b"layers" in L.snk_last_error()
+    assert L.snk_conv3x3_bn_f16s_rect(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), None, x.data_ptr(), x.data_ptr(),
+                                      x.data_ptr(), None, 1, 21, 21, None) < 0           # in place
