@@ -420,8 +420,9 @@ template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s_rect(ConvHsArgs p)
 {
     __shared__ __align__(16) unsigned char smem[HS_SMEM];
-    if ((int)blockIdx.x >= *p.n_desc) return;
-    const uint4 d = p.desc[blockIdx.x];
+    const int nd = *p.n_desc;
+    const uint4 d = p.desc[blockIdx.x];                    // both loads in flight together: the grid never exceeds the array
+    if ((int)blockIdx.x >= nd) return;
     const int img = (int)d.x, ry0 = d.y & 255, rx0 = (d.y >> 8) & 255, rh = (d.y >> 16) & 255, rw = d.y >> 24;
     const int tile0 = d.z & 255, ntile = (d.z >> 8) & 255, part = (d.z >> 16) & 255, parts = d.z >> 24;
 #define HS_RECT_CASE(NI_) case NI_: hs_block<NI_, MODE, true, 0, true>(p, smem, img, tile0, ntile, ry0, rx0, rh, rw, d.w, part, parts); break;

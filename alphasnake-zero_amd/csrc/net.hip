@@ -588,6 +588,8 @@ struct StemArgs {
     float *out;          // [M][128]
     int M, Hd, Wd;
     int raw;             // != 0 (k_stem_conv_mfma only): the bare convolution -- no scale / shift (both may be NULL), no ReLU
+    const unsigned *bbox; // k_stem_conv_mfma only, or NULL: per image y0 | x0 << 8 | y1 << 16 | x1 << 24 (k_obs_bbox, conv_split.hip);
+    int grow;            //   only the pixels of that box grown by `grow` (cut to the canvas) are computed and written
 };
 
 // 256 pixels per block; thread (pg = tid / 32, cq = tid % 32) computes outputs 4 cq .. 4 cq + 3 of pixels pg + 8 k with its
@@ -791,9 +793,20 @@ __global__ __launch_bounds__(256) void k_stem_conv_mfma(StemArgs p)
         //                                                        buffer was measured: no change, the loads are not what it waits for)
         float *out = p.out + (long)img * HW * CV_C;
         _Float16 *out16 = (_Float16 *)p.out + (long)img * HW * CV_C;
-        for (int t = wv; t < T; t += 4) {
-            const int pix = min(32 * t + l31, HW - 1);         // rows past the image repeat its last pixel (computed, never stored)
-            const int y = pix / Wd, x = pix - y * Wd;
+        // the GEMM rows are the pixels of a rectangle of the image (all of it without a bounding box)
+        int ry0 = 0, rx0 = 0, wr = Wd, HWr = HW, Tr = T;
+        if (p.bbox) {
+            const unsigned bb = p.bbox[img];
+            ry0 = max((int)(bb & 255) - p.grow, 0); rx0 = max((int)((bb >> 8) & 255) - p.grow, 0);
+            wr = min((int)(bb >> 24) + p.grow, Wd - 1) - rx0 + 1;
+            HWr = (min((int)((bb >> 16) & 255) + p.grow, Hd - 1) - ry0 + 1) * wr;
+            Tr = (HWr + 31) / 32;
+        }
+        const float inv_wr = 1.0f / (float)wr;
+        for (int t = wv; t < Tr; t += 4) {
+            const int pix = min(32 * t + l31, HWr - 1);        // rows past the image repeat its last pixel (computed, never stored)
+            const int yr = (int)(((float)pix + 0.5f) * inv_wr);
+            const int y = ry0 + yr, x = rx0 + pix - yr * wr;
             const float *b = st_img + y * P3 + x * 3;
             sm_f16x8 Ah[2], Al[2];
 #pragma unroll
@@ -823,8 +836,10 @@ __global__ __launch_bounds__(256) void k_stem_conv_mfma(StemArgs p)
             // float4 stores through an LDS patch, one N tile at a time (same time) or whole 512-byte rows (slower: 476 vs 372 us)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < HW) {
+                const int rr = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (rr < HWr) {
+                    const int yr = (int)(((float)rr + 0.5f) * inv_wr);
+                    const int row = (ry0 + yr) * Wd + rx0 + rr - yr * wr;
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
                         const float v = fmaxf(__builtin_fmaf(acc[nt][r], scl[nt], shf[nt]), floor_);
@@ -1049,6 +1064,24 @@ extern "C" int snk_stem_conv_bn_relu_f32(const float *d_x, const float *d_w, con
     if (lds <= 64 * 1024 && !stem_valu) k_stem_conv_mfma<false><<<min(n_images, stem_grid), 256, lds, (hipStream_t)stream>>>(a);
     else if (lds <= 64 * 1024) k_stem_conv_img<false><<<min(n_images, 768), 256, lds, (hipStream_t)stream>>>(a);
     else k_stem_conv<<<(int)((M + ST_PX - 1) / ST_PX), 256, 0, (hipStream_t)stream>>>(a);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// the stem on the bounding box of every observation's non-background pixels grown by `grow` pixels (d_bbox: what
+// snk_conv_rect_plan wrote); pixels of d_out outside that rectangle are left untouched
+extern "C" int snk_stem_conv_bn_relu_f32_rect(const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,
+                                              float *d_out, const void *d_bbox, int grow, int n_images, int height, int width,
+                                              void *stream)
+{
+    SNK_REQUIRE(d_x && d_w && d_scale && d_shift && d_out && d_bbox && grow >= 1 && grow < 128, "snk_stem_conv_bn_relu_f32_rect: bad argument");
+    if (n_images <= 0) return 0;
+    const long M = (long)n_images * height * width;
+    SNK_REQUIRE(M < (1l << 31), "snk_stem_conv_bn_relu_f32_rect: batch too large");
+    const size_t lds = (size_t)(height + 2) * (width + 2) * 3 * sizeof(float);
+    SNK_REQUIRE(lds <= 64 * 1024 && height <= 255 && width <= 255, "snk_stem_conv_bn_relu_f32_rect: observation %d x %d too large", height, width);
+    StemArgs a = {d_x, d_w, d_scale, d_shift, d_out, (int)M, height, width, 0, (const unsigned *)d_bbox, grow};
+    k_stem_conv_mfma<false><<<min(n_images, 512), 256, lds, (hipStream_t)stream>>>(a);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }

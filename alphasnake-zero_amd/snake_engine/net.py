@@ -356,12 +356,16 @@ class QNet:
         L, h, w = self.L, self.h, self.w
         a, b, c = self._workspace(m, k)
         x = planes[s0:s0 + m]
-        check(L.snk_stem_conv_bn_relu_f32(x.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(),
-                                          self.stem_sh.data_ptr(), a.data_ptr(), m, h, w, st))
+        plan = self._rect_plan(x, m, k, st) if self.n_rect > 0 else None
+        if self.n_rect >= 2:         # layer 0 and layer 1's shortcut read the stem's output on the box grown by 3 pixels only
+            check(L.snk_stem_conv_bn_relu_f32_rect(x.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(),
+                                                   self.stem_sh.data_ptr(), a.data_ptr(), plan[3].data_ptr(), 3, m, h, w, st))
+        else:
+            check(L.snk_stem_conv_bn_relu_f32(x.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(),
+                                              self.stem_sh.data_ptr(), a.data_ptr(), m, h, w, st))
         cur, t1, t2 = a, b, c
         # the last layer's epilogue also does the head's 1x1 stage (snk_head_dense_f32 keeps 16 states' h1 in 64 KB of LDS)
         fused_head = self.conv_algo == "f16s" and self.blocks > 0 and 16 * (h * w + 128) * 4 <= 64 * 1024
-        plan = self._rect_plan(x, m, k, st) if self.n_rect > 0 else None
         for blk in range(self.blocks):
             i0, i1 = 2 * blk, 2 * blk + 1
             self._conv(i0, cur, None, t1, m, st, plan=plan)
@@ -443,7 +447,7 @@ class QNet:
         b0, b1, b2 = self.background
         check(self.L.snk_conv_rect_plan(x.data_ptr(), b0, b1, b2, m, self.h, self.w, self.n_rect, grow, fill,
                                         bbox.data_ptr(), desc_m.data_ptr(), counts.data_ptr(), st))
-        return desc_m, counts, bg
+        return desc_m, counts, bg, bbox
 
     def _conv(self, i, x, res, out, m, st, h1=None, plan=None):
         tm = self.conv_timing
@@ -451,7 +455,7 @@ class QNet:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream())
         if plan is not None and i < self.n_rect and h1 is None:
-            desc, counts, bg = plan
+            desc, counts, bg = plan[:3]
             check(self.L.snk_conv3x3_bn_f16s_rect(x.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
                                                   self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),
                                                   out.data_ptr(), desc[i].data_ptr(), counts[i].data_ptr(), bg[i].data_ptr(),

@@ -333,6 +333,7 @@ def main():
     m = alice._mcts
     ev0, sim0 = (m.stats["net_evals"], m.stats["sim_steps"]) if m is not None else (0, 0)     # --warmup 0: nothing ran yet
     nnet._qnet.conv_timing = None if args.no_conv_timing else []
+    nnet._qnet.rect_tiles = None if args.no_conv_timing or not nnet._qnet.n_rect else []      # GEMM tiles the sub-rectangle layers execute
     probe = net.ClockProbe(torch.device("cuda", dev_index)) if rank == 0 else None
     nnet._qnet.clock_probe = probe
     coll_dev = "cuda" if backend == "nccl" else "cpu"
@@ -399,6 +400,24 @@ def main():
         peak = 2500.0 if algo in ("bf16", "f16s", "f16", "f16a") else 157.3      # dense MFMA peaks (bf16 / f16, f32), MI355X_MICROARCH.md
         # MFMA flops the kernel executes per algorithmic (direct-convolution) flop
         executed = {"f16s": 3.0 * 448 / 441, "f16": 448 / 441.0, "f16a": 448 / 441.0, "winograd": 16 * 121 / (441 * 9.0)}.get(algo, 1.0)
+        qn = nnet._qnet
+        rect = None
+        if qn.rect_tiles:
+            # sub-rectangle form: the first n_rect layers convolve the board window grown by one pixel per layer only; what
+            # the launches executed = the 32-row GEMM tiles the device-side plans counted + the full layers' tiles
+            T_full, n_layers = (OBS * OBS + 31) // 32, 2 * qn.blocks
+            imgs = sum(mm for mm, _ in qn.rect_tiles)
+            per_layer = torch.stack([c[:, 1] for _, c in qn.rect_tiles]).to(torch.float64).sum(dim=0).cpu().numpy()
+            tiles = float(per_layer.sum()) + float(imgs) * T_full * (n_layers - qn.n_rect)
+            executed = 3.0 * tiles * 32 / (float(imgs) * n_layers * OBS * OBS)
+            rect = {"layers": qn.n_rect, "of": n_layers,
+                    "tiles_executed_vs_full_per_layer": [float(v) / (imgs * T_full) for v in per_layer],
+                    "tiles_executed_vs_full": tiles / (float(imgs) * T_full * n_layers),
+                    "what": "tower layer i < layers convolves only the bounding box of an observation's non-background pixels (the "
+                            "board window, game.py:215-257) grown by i + 2 pixels; the rest of its output is a per-layer constant "
+                            "(bit-identical to the full convolution, tests/test_rect_conv_gpu.py); `achieved` still counts the "
+                            "reference's full direct convolution"}
+            qn.rect_tiles = None
         traffic = None      # HBM bytes per average launch, from the committed rocprofv3 --pmc passes (profiles/)
         tfile = os.path.join(REPO, "profiles", {"f16s": "r3_conv_f16s_traffic.json", "winograd": "r1_conv_traffic.json"}.get(algo, "none"))
         if os.path.exists(tfile) and tm:
@@ -424,7 +443,8 @@ def main():
                        "net_evals_per_s_rank0": evals / dt, "sample_rows_gathered": int(Xg.shape[0]),
                        "graph_replays": m.stats.get("graph_replays", 0)},
             "roofline": {"bound": "mfma",
-                         "kernel": {"winograd": "k_conv3x3_wino_f32", "bf16": "k_conv3x3_bf16", "f16s": "k_conv3x3_f16s",
+                         "kernel": {"winograd": "k_conv3x3_wino_f32", "bf16": "k_conv3x3_bf16",
+                                    "f16s": "k_conv3x3_f16s" + (" + k_conv3x3_f16s_rect (the same body on sub-rectangles)" if rect else ""),
                                     "f16": "k_conv3x3_f16s<SPLIT = false>",
                                     "f16a": "k_conv3x3_f16s<SPLIT = false, IO16>"}.get(algo, "k_conv3x3_f32"),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
@@ -436,12 +456,13 @@ def main():
                                        "bf16": "implicit GEMM on v_mfma_f32_32x32x16_bf16",
                                        "f16": "implicit GEMM on v_mfma_f32_32x32x16_f16, f16-rounded operands (reduced precision)",
                                        "f16a": "implicit GEMM on v_mfma_f32_32x32x16_f16, f16 operands, f16 activations in HBM (reduced precision)",
-                                       "f16s": "implicit GEMM on v_mfma_f32_32x32x16_f16 with split operands: executes 3 (hi*hi, hi*lo, lo*hi) "
-                                               "x 448/441 (M-tile padding) = 3.05 MFMA flops per algorithmic flop; peak = dense f16 MFMA "
-                                               "at 2.4 GHz, the chip holds ~1.55 GHz in this loop on random data (DESIGN.md section 4)"}.get(
+                                       "f16s": "implicit GEMM on v_mfma_f32_32x32x16_f16 with split operands: 3 MFMAs (hi*hi, hi*lo, lo*hi) per "
+                                               "product over the GEMM tiles actually launched (executed_frac; the full form pads 441 rows to "
+                                               "448, the sub-rectangle form computes fewer rows, see sub_rectangles); peak = dense f16 MFMA "
+                                               "at 2.4 GHz, the chip holds less in this loop (clock_mhz)"}.get(
                                                    algo, "implicit GEMM on v_mfma_f32_32x32x2_f32"),
                          "avg_launch_ms": conv_s / max(1, len(tm)) * 1e3,
-                         "share_of_step_time": conv_s / dt},
+                         "share_of_step_time": conv_s / dt, "sub_rectangles": rect},
             # what a non-linear scaling curve is made of: one row per rank (rank r = GPU r of the node)
             "ranks": [{"rank": r, "env_steps": int(v[0]), "self_play_s": v[1], "sample_rows_s": v[2], "all_gather_s": v[3],
                        "all_reduce_s": v[4], "wall_s": v[5], "env_steps_per_s": v[0] / v[5], "net_evals": int(v[6]),

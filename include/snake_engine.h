@@ -213,11 +213,16 @@ int snk_conv3x3_bn_f16(const float *d_x, const void *d_wS, const float *d_scale,
  *   next sub-rectangle layers read: 2); < 0: into the whole canvas (the next reader is a full layer).
  * snk_conv3x3_bn_f16s_rect: layer l's launch: d_desc / d_count point at layer l's descriptors and count; d_bg_out:
  *   [height][width][128] = the layer's output on the all-background observation (or NULL: no fill).  d_x and d_residual
- *   must be valid on the rectangle grown by 1 / on the rectangle; pixels of d_out outside the fill rectangle are untouched. */
+ *   must be valid on the rectangle grown by 1 / on the rectangle; pixels of d_out outside the fill rectangle are untouched.
+ * snk_stem_conv_bn_relu_f32_rect: snk_stem_conv_bn_relu_f32 (alpha_nnet.py:21-22) on the bounding boxes (d_bbox as
+ *   snk_conv_rect_plan wrote it) grown by `grow` pixels: what the first sub-rectangle layers read of the stem's output. */
 long snk_conv_rect_max_blocks(int n_images, int height, int width);
 int snk_conv_rect_plan(const float *d_planes, float b0, float b1, float b2, int n_images, int height, int width,
                        int n_layers, const int *grow, const int *fill_grow, void *d_bbox, void *d_desc, int *d_counts,
                        void *stream);
+int snk_stem_conv_bn_relu_f32_rect(const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,
+                                   float *d_out, const void *d_bbox, int grow, int n_images, int height, int width,
+                                   void *stream);
 int snk_conv3x3_bn_f16s_rect(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
                              const float *d_residual, float *d_out, const void *d_desc, const int *d_count,
                              const float *d_bg_out, int n_images, int height, int width, void *stream);

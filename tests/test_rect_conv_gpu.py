@@ -185,6 +185,8 @@ def test_rect_form_gives_the_same_bits_as_the_full_form(env, board, snakes, bloc
     rect = net.QNet(ws, (h, w, 3), max_chunk=8192)
     assert rect.n_rect == (n_rect if n_rect is not None else net.rect_layer_count(h, w, 2 * blocks)) and rect.n_rect >= 1
     q_full = full.forward(planes)
+    for t in rect._workspace(m, 0):                 # whatever the form leaves unwritten must never be read
+        t.fill_(float("nan"))
     q_rect = rect.forward(planes)
     assert torch.isfinite(q_full).all()
     assert torch.equal(q_full, q_rect), (q_full - q_rect).abs().max().item()
