@@ -389,7 +389,8 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
             const int fy = (int)(((float)q + 0.5f) * invF), y_ = fy0 + fy, x_ = fx0 + q - fy * fw;
             if (y_ >= cy0 && y_ < cy0 + rh && x_ >= cx0 && x_ < cx0 + rw) continue;
             const int o_ = (y_ * p.Wd + x_) * HS_C + 4 * cq;
-            *(float4 *)(p.out + (long)img * HWc * HS_C + o_) = *(const float4 *)(p.bg_out + o_);
+            if (OUT16) *(f16x4 *)((_Float16 *)p.out + (long)img * HWc * HS_C + o_) = *(const f16x4 *)((const _Float16 *)p.bg_out + o_);
+            else *(float4 *)(p.out + (long)img * HWc * HS_C + o_) = *(const float4 *)(p.bg_out + o_);
         }
     }
     HS_STAMP(4)
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
 // grown by k + 1 pixels: only that rectangle is computed per image, everything else is a per-layer constant
 // (QNet._backgrounds).  Blocks take (image, rectangle, tile range) from descriptors; the M-tile count of a block selects
 // the body at run time (wave-uniform), so one launch covers every rectangle shape of the batch.
-template <int MODE>
+template <int MODE, bool SPLIT = true, int IO16 = 0>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s_rect(ConvHsArgs p)
 {
     __shared__ __align__(16) unsigned char smem[HS_SMEM];
@@ -425,10 +426,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s_rect(ConvHsArgs p)
     if ((int)blockIdx.x >= nd) return;
     const int img = (int)d.x, ry0 = d.y & 255, rx0 = (d.y >> 8) & 255, rh = (d.y >> 16) & 255, rw = d.y >> 24;
     const int tile0 = d.z & 255, ntile = (d.z >> 8) & 255, part = (d.z >> 16) & 255, parts = d.z >> 24;
-#define HS_RECT_CASE(NI_) case NI_: hs_block<NI_, MODE, true, 0, true>(p, smem, img, tile0, ntile, ry0, rx0, rh, rw, d.w, part, parts); break;
+#define HS_RECT_CASE(NI_) case NI_: hs_block<NI_, MODE, SPLIT, IO16, true>(p, smem, img, tile0, ntile, ry0, rx0, rh, rw, d.w, part, parts); break;
     switch (ntile) {
         HS_RECT_CASE(1) HS_RECT_CASE(2) HS_RECT_CASE(3) HS_RECT_CASE(4) HS_RECT_CASE(5) HS_RECT_CASE(6) HS_RECT_CASE(7)
-    default: hs_block<8, MODE, true, 0, true>(p, smem, img, tile0, ntile, ry0, rx0, rh, rw, d.w, part, parts); break;
+    default: hs_block<8, MODE, SPLIT, IO16, true>(p, smem, img, tile0, ntile, ry0, rx0, rh, rw, d.w, part, parts); break;
     }
 #undef HS_RECT_CASE
 }
@@ -783,9 +784,9 @@ extern "C" int snk_conv_rect_plan(const float *d_planes, float b0, float b1, flo
     return 0;
 }
 
-extern "C" int snk_conv3x3_bn_f16s_rect(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
-                                        const float *d_residual, float *d_out, const void *d_desc, const int *d_count,
-                                        const float *d_bg_out, int n_images, int height, int width, void *stream)
+static int conv_f16s_rect_launch(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
+                                 const float *d_residual, float *d_out, const void *d_desc, const int *d_count,
+                                 const float *d_bg_out, int n_images, int height, int width, bool act16, void *stream)
 {
     SNK_REQUIRE(d_x && d_wS && d_scale && d_shift && d_out && d_desc && d_count, "snk_conv3x3_bn_f16s_rect: NULL argument");
     SNK_REQUIRE(d_out != d_x, "snk_conv3x3_bn_f16s_rect: in-place convolution is not possible");
@@ -796,10 +797,30 @@ extern "C" int snk_conv3x3_bn_f16s_rect(const float *d_x, const void *d_wS, cons
     ConvHsArgs a = {d_x, (const f16x8 *)d_wS, (const float *)((const _Float16 *)d_wS + HS_WS_ELEMS), d_scale, d_shift,
                     d_residual, d_out, nullptr, nullptr, 0.f, 0.f, height, width, 1, 0, 0, 1, 0, nullptr, nullptr,
                     (const uint4 *)d_desc, d_count, d_bg_out};
-    if (d_residual) k_conv3x3_f16s_rect<2><<<(int)mb, 256, 0, (hipStream_t)stream>>>(a);
+    if (act16) {
+        if (d_residual) k_conv3x3_f16s_rect<2, false, 3><<<(int)mb, 256, 0, (hipStream_t)stream>>>(a);
+        else k_conv3x3_f16s_rect<1, false, 3><<<(int)mb, 256, 0, (hipStream_t)stream>>>(a);
+    } else if (d_residual) k_conv3x3_f16s_rect<2><<<(int)mb, 256, 0, (hipStream_t)stream>>>(a);
     else k_conv3x3_f16s_rect<1><<<(int)mb, 256, 0, (hipStream_t)stream>>>(a);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int snk_conv3x3_bn_f16s_rect(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
+                                        const float *d_residual, float *d_out, const void *d_desc, const int *d_count,
+                                        const float *d_bg_out, int n_images, int height, int width, void *stream)
+{
+    return conv_f16s_rect_launch(d_x, d_wS, d_scale, d_shift, d_residual, d_out, d_desc, d_count, d_bg_out, n_images, height, width,
+                                 false, stream);
+}
+
+// the sub-rectangle form of snk_conv3x3_bn_f16_act16 (f16 activations in and out, relu = 1; d_bg_out16: f16 [height][width][128])
+extern "C" int snk_conv3x3_bn_f16_act16_rect(const void *d_x16, const void *d_wS, const float *d_scale, const float *d_shift,
+                                             const void *d_residual16, void *d_out16, const void *d_desc, const int *d_count,
+                                             const void *d_bg_out16, int n_images, int height, int width, void *stream)
+{
+    return conv_f16s_rect_launch((const float *)d_x16, d_wS, d_scale, d_shift, (const float *)d_residual16, (float *)d_out16, d_desc,
+                                 d_count, (const float *)d_bg_out16, n_images, height, width, true, stream);
 }
 
 extern "C" int snk_conv3x3_bn_f16s(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,

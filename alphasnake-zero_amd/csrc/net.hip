@@ -1086,6 +1086,23 @@ extern "C" int snk_stem_conv_bn_relu_f32_rect(const float *d_x, const float *d_w
     return 0;
 }
 
+// the same with the output written as f16 (the f16-activation tower, snk_conv3x3_bn_f16_act16_rect)
+extern "C" int snk_stem_conv_bn_relu_f16out_rect(const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,
+                                                 void *d_out16, const void *d_bbox, int grow, int n_images, int height, int width,
+                                                 void *stream)
+{
+    SNK_REQUIRE(d_x && d_w && d_scale && d_shift && d_out16 && d_bbox && grow >= 1 && grow < 128, "snk_stem_conv_bn_relu_f16out_rect: bad argument");
+    if (n_images <= 0) return 0;
+    const long M = (long)n_images * height * width;
+    SNK_REQUIRE(M < (1l << 31), "snk_stem_conv_bn_relu_f16out_rect: batch too large");
+    const size_t lds = (size_t)(height + 2) * (width + 2) * 3 * sizeof(float);
+    SNK_REQUIRE(lds <= 64 * 1024 && height <= 255 && width <= 255, "snk_stem_conv_bn_relu_f16out_rect: observation %d x %d too large", height, width);
+    StemArgs a = {d_x, d_w, d_scale, d_shift, (float *)d_out16, (int)M, height, width, 0, (const unsigned *)d_bbox, grow};
+    k_stem_conv_mfma<true><<<min(n_images, 512), 256, lds, (hipStream_t)stream>>>(a);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // the bare stem convolution (training step: the batch statistics of its output come first, train.hip)
 extern "C" int snk_stem_conv_f32(const float *d_x, const float *d_w, float *d_out, int n_images, int height, int width, void *stream)
 {

@@ -135,7 +135,7 @@ class QNet:
             raise EngineError(f"SNK_CONV_ALGO={self.conv_algo!r}: expected f16s, winograd, direct, f16, f16a or bf16")
         # sub-rectangle form of the first tower layers (snk_conv3x3_bn_f16s_rect): SNK_CONV_RECT=0 switches it off,
         # SNK_CONV_RECT_LAYERS=n fixes the number of layers that use it
-        self.rect = self.conv_algo == "f16s" and os.environ.get("SNK_CONV_RECT", "1") != "0"
+        self.rect = self.conv_algo in ("f16s", "f16a") and os.environ.get("SNK_CONV_RECT", "1") != "0"
         self.background = BACKGROUND_PIXEL
         self.rect_tiles = None       # set to [] to collect every chunk's (images, per-layer GEMM tiles) device tensors
         self._bg = None
@@ -320,8 +320,13 @@ class QNet:
             bufs = self._ws[key]
         a, b, c, last = bufs
         x = planes[s0:s0 + m]
-        check(L.snk_stem_conv_bn_relu_f16out(x.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(),
-                                             self.stem_sh.data_ptr(), a.data_ptr(), m, h, w, st))
+        plan = self._rect_plan(x, m, k, st) if self.n_rect > 0 else None
+        if self.n_rect >= 2:
+            check(L.snk_stem_conv_bn_relu_f16out_rect(x.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(),
+                                                      self.stem_sh.data_ptr(), a.data_ptr(), plan[3].data_ptr(), 3, m, h, w, st))
+        else:
+            check(L.snk_stem_conv_bn_relu_f16out(x.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(),
+                                                 self.stem_sh.data_ptr(), a.data_ptr(), m, h, w, st))
         cur, t1, t2 = a, b, c
         tm = self.conv_timing
 
@@ -329,9 +334,15 @@ class QNet:
             if tm is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(torch.cuda.current_stream())
-            check(L.snk_conv3x3_bn_f16_act16(xin.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
-                                             self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),
-                                             dst.data_ptr(), int(out_f16), m, h, w, 1, st))
+            if plan is not None and i < self.n_rect:       # a sub-rectangle layer is never the last one: f16 output
+                check(L.snk_conv3x3_bn_f16_act16_rect(xin.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
+                                                      self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),
+                                                      dst.data_ptr(), plan[0][i].data_ptr(), plan[1][i].data_ptr(),
+                                                      plan[2][i].data_ptr(), m, h, w, st))
+            else:
+                check(L.snk_conv3x3_bn_f16_act16(xin.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
+                                                 self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),
+                                                 dst.data_ptr(), int(out_f16), m, h, w, 1, st))
             if tm is not None:
                 e1.record(torch.cuda.current_stream())
                 tm.append((e0, e1, 2.0 * m * h * w * 9 * 128 * 128))
@@ -399,19 +410,30 @@ class QNet:
         bit for bit); made again when the weights or an activation scale change."""
         if self._bg is None:
             m, st = 1, torch.cuda.current_stream().cuda_stream
+            a16 = self.conv_algo == "f16a"
+            dt = torch.float16 if a16 else torch.float32
             blank = torch.tensor(self.background, dtype=torch.float32, device=self.device).repeat(1, self.h, self.w, 1).contiguous()
-            bufs = [torch.empty((1, self.h, self.w, 128), dtype=torch.float32, device=self.device) for _ in range(3)]
-            check(self.L.snk_stem_conv_bn_relu_f32(blank.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(),
-                                                   self.stem_sh.data_ptr(), bufs[0].data_ptr(), m, self.h, self.w, st))
-            bg = torch.empty((self.n_rect, self.h, self.w, 128), dtype=torch.float32, device=self.device)
+            bufs = [torch.empty((1, self.h, self.w, 128), dtype=dt, device=self.device) for _ in range(3)]
+            stem = self.L.snk_stem_conv_bn_relu_f16out if a16 else self.L.snk_stem_conv_bn_relu_f32
+            check(stem(blank.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(), self.stem_sh.data_ptr(),
+                       bufs[0].data_ptr(), m, self.h, self.w, st))
+            bg = torch.empty((self.n_rect, self.h, self.w, 128), dtype=dt, device=self.device)
             cur, t1, t2 = bufs
             tm, self.conv_timing = self.conv_timing, None
+
+            def conv(i, x, res, out):
+                if a16:
+                    check(self.L.snk_conv3x3_bn_f16_act16(x.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
+                                                          self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),
+                                                          out.data_ptr(), 1, m, self.h, self.w, 1, st))
+                else:
+                    self._conv(i, x, res, out, m, st)
             for i in range(self.n_rect):
                 if i % 2 == 0:
-                    self._conv(i, cur, None, t1, m, st)
+                    conv(i, cur, None, t1)
                     bg[i].copy_(t1[0])
                 else:
-                    self._conv(i, t1, cur, t2, m, st)
+                    conv(i, t1, cur, t2)
                     bg[i].copy_(t2[0])
                     cur, t2 = t2, cur
             self.conv_timing = tm

@@ -223,6 +223,14 @@ int snk_conv_rect_plan(const float *d_planes, float b0, float b1, float b2, int 
 int snk_stem_conv_bn_relu_f32_rect(const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,
                                    float *d_out, const void *d_bbox, int grow, int n_images, int height, int width,
                                    void *stream);
+/* the same two for the reduced-precision tower with f16 activations (snk_stem_conv_bn_relu_f16out, snk_conv3x3_bn_f16_act16 with
+ * relu = 1 and f16 output; d_bg_out16: f16 [height][width][128]) */
+int snk_stem_conv_bn_relu_f16out_rect(const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,
+                                      void *d_out16, const void *d_bbox, int grow, int n_images, int height, int width,
+                                      void *stream);
+int snk_conv3x3_bn_f16_act16_rect(const void *d_x16, const void *d_wS, const float *d_scale, const float *d_shift,
+                                  const void *d_residual16, void *d_out16, const void *d_desc, const int *d_count,
+                                  const void *d_bg_out16, int n_images, int height, int width, void *stream);
 int snk_conv3x3_bn_f16s_rect(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
                              const float *d_residual, float *d_out, const void *d_desc, const int *d_count,
                              const float *d_bg_out, int n_images, int height, int width, void *stream);

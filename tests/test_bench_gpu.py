@@ -27,8 +27,13 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert d["dtype"].startswith("f32") and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 0 and abs(d["value"] - 2 * 16 / (d["ms_per_step"] * 2e-3)) / d["value"] < 0.05
     r = d["roofline"]
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and r["kernel"] == "k_conv3x3_f16s" and r["achieved"] > 0
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and r["kernel"].startswith("k_conv3x3_f16s") and r["achieved"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
+    sr = r["sub_rectangles"]                                        # the first six tower layers convolve the grown board window only
+    assert sr["layers"] == 6 and sr["of"] == 8 and len(sr["tiles_executed_vs_full_per_layer"]) == 6
+    assert all(0.3 < v <= 1.0 for v in sr["tiles_executed_vs_full_per_layer"]) and 0.5 < sr["tiles_executed_vs_full"] < 1.0
+    assert sr["tiles_executed_vs_full_per_layer"] == sorted(sr["tiles_executed_vs_full_per_layer"])
+    assert abs(r["executed_frac"] - r["frac"] * 3.0 * 448 / 441 * sr["tiles_executed_vs_full"]) < 1e-6
     clk = r["clock_mhz"]                                            # the clock the chip held beside the measured kernels
     assert clk["samples"] >= 1 and 500.0 < clk["p10"] <= clk["median"] <= clk["p90"] < 2700.0
     assert len(d["ranks"]) == 1 and d["ranks"][0]["env_steps"] == 32 and d["exchange"]["dist_backend"] is None

@@ -233,6 +233,30 @@ def test_rect_form_gives_the_same_bits_as_the_full_form(env, board, snakes, bloc
     assert saved > 0
 
 
+@pytest.mark.parametrize("board,snakes,blocks,n_games", [(11, 4, 4, 96), (19, 8, 10, 6)])
+def test_f16_activation_tower_rect_form_gives_the_same_bits(env, board, snakes, blocks, n_games, monkeypatch):
+    """the reduced-precision tower with f16 activations (SNK_CONV_ALGO=f16a, BASELINE configs[4]) through its
+    sub-rectangle layers == through its full layers, bit for bit"""
+    torch, se, net = env
+    monkeypatch.setenv("SNK_CONV_ALGO", "f16a")
+    h = w = 2 * board - 1
+    ws = _randomised_bn(net.glorot_uniform_weights((h, w, 3), blocks=blocks, seed=board), 6)
+    planes, _ = _mid_game_planes(se, torch, n_games, board, snakes, 10, seed=200 + board)
+    planes = torch.nan_to_num(torch.cat([planes, _special_observations(torch, h, w).cuda()]), nan=3.0).contiguous()
+    monkeypatch.setenv("SNK_CONV_RECT", "0")
+    full = net.QNet(ws, (h, w, 3), max_chunk=8192)
+    monkeypatch.setenv("SNK_CONV_RECT", "1")
+    rect = net.QNet(ws, (h, w, 3), max_chunk=8192)
+    assert full.n_rect == 0 and rect.n_rect >= 2 and rect.backgrounds().dtype == torch.float16
+    q_full = full.forward(planes)
+    for t in rect._ws.get(("a16", 0), []) if rect._ws else []:
+        t.fill_(float("nan"))
+    q_rect = rect.forward(planes)
+    for t in rect._ws[("a16", 0)][:3]:
+        t.fill_(float("nan"))
+    assert torch.isfinite(q_full).all() and torch.equal(q_full, q_rect) and torch.equal(rect.forward(planes), q_full)
+
+
 def test_backgrounds_follow_the_weights_and_scales(env):
     """the per-layer constants are made again after set_weights and after a change of an activation scale (they are kept
     bit-identical to what the full layers compute)"""
