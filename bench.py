@@ -419,7 +419,8 @@ def main():
                             "reference's full direct convolution"}
             qn.rect_tiles = None
         traffic = None      # HBM bytes per average launch, from the committed rocprofv3 --pmc passes (profiles/)
-        tfile = os.path.join(REPO, "profiles", {"f16s": "r3_conv_f16s_traffic.json", "winograd": "r1_conv_traffic.json"}.get(algo, "none"))
+        tfile = os.path.join(REPO, "profiles", {"f16s": "r3b_conv_rect_traffic.json" if nnet._qnet.n_rect == 6 else "r3_conv_f16s_traffic.json",
+                                                "winograd": "r1_conv_traffic.json"}.get(algo, "none"))
         if os.path.exists(tfile) and tm:
             per_state_layer = json.load(open(tfile))["hbm_bytes_per_state_layer"]
             traffic = per_state_layer * (conv_flops / len(tm)) / (2.0 * 441 * 9 * 128 * 128) if judged else None
