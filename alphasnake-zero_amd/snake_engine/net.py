@@ -65,6 +65,14 @@ def activation_scales(weights, target_log2=9):
     return scales
 
 
+def rect_fill_plan(n_rect):
+    """fill_grow of every sub-rectangle layer: the output of tower layer i is read by layer i + 1 (on that layer's rectangle
+    grown by one pixel) and, when it closes a residual block (odd i), by layer i + 2 as the shortcut (on that layer's
+    rectangle): a sub-rectangle layer fills 2 pixels of background around its rectangle for sub-rectangle readers, the whole
+    canvas (-1) when a full layer reads it"""
+    return [-1 if (i + 1 >= n_rect or (i % 2 == 1 and i + 2 >= n_rect)) else 2 for i in range(n_rect)]
+
+
 class ClockProbe:
     """Samples of the shader clock while other streams work (csrc/probe.hip): every `launch` puts one wavefront on a
     stream of its own that sits on a compute unit for `microseconds` and records shader cycles against the constant
@@ -139,6 +147,10 @@ class QNet:
         self.background = BACKGROUND_PIXEL
         self.rect_tiles = None       # set to [] to collect every chunk's (images, per-layer GEMM tiles) device tensors
         self._bg = None
+        # chunks below this many observations take the full form: a launch that small is bound by one block's duration (the
+        # full form then cuts the images into one-tile blocks, conv_split.hip `fine_max`), and the plan's two launches
+        # cost as much as a layer (BASELINE configs[0]: 8 games)
+        self.rect_min = int(os.environ.get("SNK_CONV_RECT_MIN", "48"))
         self.n_streams = int(os.environ.get("SNK_NET_STREAMS", "1"))   # 2: chunks alternate between two streams (+0.8 % end to end,
         #    but per-launch HIP-event timings then overlap, so bench.py keeps the single-stream default)
         self._side = None
@@ -190,10 +202,7 @@ class QNet:
         self.n_rect = rect_layer_count(self.h, self.w, n_layers) if self.rect else 0
         if self.rect and "SNK_CONV_RECT_LAYERS" in os.environ:
             self.n_rect = max(0, min(int(os.environ["SNK_CONV_RECT_LAYERS"]), n_layers - 1))
-        # the output of tower layer i is read by layer i + 1 and, when it closes a residual block, by layer i + 2 as the
-        # shortcut: a sub-rectangle layer fills 2 pixels around its rectangle for sub-rectangle readers, the whole canvas
-        # when a full layer reads it
-        self.rect_fill = [-1 if (i + 1 >= self.n_rect or (i % 2 == 1 and i + 2 >= self.n_rect)) else 2 for i in range(self.n_rect)]
+        self.rect_fill = rect_fill_plan(self.n_rect)
         torch.cuda.current_stream().synchronize()
 
     def get_weights(self):
@@ -320,8 +329,8 @@ class QNet:
             bufs = self._ws[key]
         a, b, c, last = bufs
         x = planes[s0:s0 + m]
-        plan = self._rect_plan(x, m, k, st) if self.n_rect > 0 else None
-        if self.n_rect >= 2:
+        plan = self._rect_plan(x, m, k, st) if self.n_rect > 0 and m >= self.rect_min else None
+        if plan is not None and self.n_rect >= 2:
             check(L.snk_stem_conv_bn_relu_f16out_rect(x.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(),
                                                       self.stem_sh.data_ptr(), a.data_ptr(), plan[3].data_ptr(), 3, m, h, w, st))
         else:
@@ -367,8 +376,8 @@ class QNet:
         L, h, w = self.L, self.h, self.w
         a, b, c = self._workspace(m, k)
         x = planes[s0:s0 + m]
-        plan = self._rect_plan(x, m, k, st) if self.n_rect > 0 else None
-        if self.n_rect >= 2:         # layer 0 and layer 1's shortcut read the stem's output on the box grown by 3 pixels only
+        plan = self._rect_plan(x, m, k, st) if self.n_rect > 0 and m >= self.rect_min else None
+        if plan is not None and self.n_rect >= 2:         # layer 0 and layer 1's shortcut read the stem's output on the box grown by 3 pixels only
             check(L.snk_stem_conv_bn_relu_f32_rect(x.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(),
                                                    self.stem_sh.data_ptr(), a.data_ptr(), plan[3].data_ptr(), 3, m, h, w, st))
         else:

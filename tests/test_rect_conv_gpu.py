@@ -183,6 +183,7 @@ def test_rect_form_gives_the_same_bits_as_the_full_form(env, board, snakes, bloc
     if n_rect is not None:
         monkeypatch.setenv("SNK_CONV_RECT_LAYERS", str(n_rect))
     rect = net.QNet(ws, (h, w, 3), max_chunk=8192)
+    rect.rect_min = 1                       # (chunks below 48 observations take the full form by default)
     assert rect.n_rect == (n_rect if n_rect is not None else net.rect_layer_count(h, w, 2 * blocks)) and rect.n_rect >= 1
     q_full = full.forward(planes)
     for t in rect._workspace(m, 0):                 # whatever the form leaves unwritten must never be read
@@ -194,6 +195,13 @@ def test_rect_form_gives_the_same_bits_as_the_full_form(env, board, snakes, bloc
     rect.max_chunk = 37
     assert torch.equal(rect.forward(planes), q_full)
     rect.max_chunk = 8192
+    if board == 11 and n_rect is None:      # and the form is within the 1e-5 contract of the CPU restatement (oracle/net_ref.py)
+        from oracle import net_ref
+        ref = net_ref.forward(ws, planes[:48].cpu().numpy(), apply_mask=False)
+        assert np.abs(q_rect[:48].cpu().numpy() - ref).max() <= 1e-5
+        rect.rect_min = 48                  # the default: a chunk of 47 observations takes the full form, 48 the sub-rectangles
+        assert torch.equal(rect.forward(planes[:47]), q_full[:47]) and torch.equal(rect.forward(planes[:48]), q_full[:48])
+        rect.rect_min = 1
 
     # layer by layer
     st = torch.cuda.current_stream().cuda_stream
@@ -247,6 +255,7 @@ def test_f16_activation_tower_rect_form_gives_the_same_bits(env, board, snakes, 
     full = net.QNet(ws, (h, w, 3), max_chunk=8192)
     monkeypatch.setenv("SNK_CONV_RECT", "1")
     rect = net.QNet(ws, (h, w, 3), max_chunk=8192)
+    rect.rect_min = 1
     assert full.n_rect == 0 and rect.n_rect >= 2 and rect.backgrounds().dtype == torch.float16
     q_full = full.forward(planes)
     for t in rect._ws.get(("a16", 0), []) if rect._ws else []:
