@@ -64,9 +64,13 @@ struct ConvHsArgs {
     const float *center;       // MODE 4 (training forward): per-channel centre of the batch-norm sums (or NULL = 0)
     float *stat_part;          // MODE 4: [gridDim.x][2][128] sums of (out - center) and (out - center)^2 over the block's pixels
     // sub-rectangle form (k_conv3x3_f16s_rect): one descriptor per block, written on the device by k_rect_plan
-    const uint4 *desc;         // { image, y0 | x0 << 8 | h << 16 | w << 24, tile0 | ntile << 8 | part << 16 | parts << 24, fill rectangle }
+    const uint4 *desc;         // { image, y0 | x0 << 8 | h << 16 | w << 24, tile0 | ntile << 8 | part << 16 | parts << 24, bounding box }
     const int *n_desc;         // number of descriptors (blocks past it leave at once)
-    const float *bg_out;       // [Hd][Wd][128]: this layer's output on an all-background image, copied into fill \ rectangle
+    const float *bg_out;       // or NULL; [Hd][Wd][128]: this layer's output on an all-background image, copied into every pixel
+                               //   of the canvas outside the rectangle (the layer's readers are full layers)
+    const float *bg_in;        // or NULL; the input's background image: x is valid on the bounding box grown by grow_in (cut to the
+    const float *bg_res;       //   canvas) and stale outside, where the producing layer's constant is read instead; the same for res
+    int grow_in, grow_res;
 };
 
 #ifdef HS_STAMPS       // development build only (tools/conv_stamps.py): s_memtime at the phase boundaries of every block
@@ -99,7 +103,7 @@ extern "C" int snk_dbg_conv_stamps(unsigned long long *h_out, int n_blocks)
 //   (zero outside it), global rows stay pitched Wd.
 template <int NI, int MODE, bool SPLIT, int IO16, bool RECT>
 __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *smem, const int img, const int tile0, const int ntile,
-                                         const int ry0, const int rx0, const int rh, const int rw, const unsigned fill,
+                                         const int ry0, const int rx0, const int rh, const int rw, const unsigned bbox,
                                          const int part, const int parts)
 {
     static_assert(IO16 == 0 || !SPLIT, "f16 activations only exist in the reduced-precision form");
@@ -135,6 +139,10 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     const float xs = p.wscale_inv[2];                      // activations are multiplied by this power of two before the split
     unsigned ldo[HS_NST];                                  // LDS byte offset (inside a buffer) of the thread's items
     unsigned gof[HS_NST];                                  // element offset of the items in x (chunk 0)
+    const float *gp[HS_NST];                               // RECT: the items' addresses (chunk 0): in x where the producing layer wrote
+    const _Float16 *gp16[HS_NST];                          //   (bounding box grown by grow_in), else in that layer's background image
+    const int by0 = bbox & 255, bx0 = (bbox >> 8) & 255, by1 = (bbox >> 16) & 255, bx1 = bbox >> 24;
+    const bool sel_in = RECT && p.bg_in != nullptr;
     // items past the strip's last pixel repeat it (same value to the same LDS address): no predication, no branches
 #pragma unroll
     for (int k = 0; k < HS_NST; ++k) {
@@ -142,6 +150,13 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
         const int r_ = (int)(((float)pix_ + 0.5f) * invWs), x_ = pix_ - r_ * ws;
         ldo[k] = ((ry_lo + r_) * P + cx_lo + x_) * HS_LDP + (tid & 3) * 8;
         gof[k] = (r_ * p.Wd + x_) * HS_C;
+        if (RECT) {
+            const int Y = ya + r_, X = xa + x_;
+            const bool stale = sel_in && (Y < by0 - p.grow_in || Y > by1 + p.grow_in || X < bx0 - p.grow_in || X > bx1 + p.grow_in);
+            const long o_ = (long)(Y * p.Wd + X) * HS_C + 4 * (tid & 3);
+            gp[k] = (stale ? p.bg_in : p.x + (long)img * HWc * HS_C) + o_;
+            gp16[k] = (stale ? (const _Float16 *)p.bg_in : (const _Float16 *)p.x + (long)img * HWc * HS_C) + o_;
+        }
     }
     float4 st[HS_NST];
     f16x4 st16[HS_NST];
@@ -149,8 +164,8 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     float4 d_t;
     float amax = 0.f;                                      // largest |scaled input| this thread staged: 65504 = something was clamped
 #define HS_LOAD(c) _Pragma("unroll") for (int k_ = 0; k_ < HS_NST; ++k_) {                      \
-        if (IN16) st16[k_] = *(const f16x4 *)(xrow16 + gof[k_] + HS_KC * (c));                  \
-        else st[k_] = *(const float4 *)(xrow + gof[k_] + HS_KC * (c)); }
+        if (IN16) st16[k_] = *(const f16x4 *)((RECT ? gp16[k_] : xrow16 + gof[k_]) + HS_KC * (c)); \
+        else st[k_] = *(const float4 *)((RECT ? gp[k_] : xrow + gof[k_]) + HS_KC * (c)); }
 // split of one staged float4 in two halves that sit in different MFMA regions (a region hides about 15 VALU instructions):
 //   A: clamp to the f16 range, hi = f16(v), d = v - hi;   B: lo = f16(d), both written to LDS
 #define HS_SPLIT_A(kk)                                                                          \
@@ -297,6 +312,8 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     constexpr int NPASS = (NI + 1) / 2;
     float4 rv[2][8];
     int off[2][8];
+    bool res_stale[8];
+    const bool sel_res = RECT && p.bg_res != nullptr;
 #define HS_ROWS(pass) (((pass) + 1 < NPASS ? 2 : NI - 2 * (NPASS - 1)) * 32)
 #define HS_EPI_PREP(pass)                 /* element offsets of this thread's rows (-1: past the block's pixels) + residual loads */ \
     {                                                                                           \
@@ -305,14 +322,20 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
             if (RECT) {                                                                         \
                 const int y_ = (int)(((float)m_ + 0.5f) * invW), x_ = m_ - y_ * Wr;             \
                 off[(pass) & 1][j] = m_ < m1 ? ((cy0 + y_) * p.Wd + cx0 + x_) * HS_C : -1;      \
+                res_stale[j] = sel_res && (cy0 + y_ < by0 - p.grow_res || cy0 + y_ > by1 + p.grow_res || \
+                                           cx0 + x_ < bx0 - p.grow_res || cx0 + x_ > bx1 + p.grow_res); \
             } else off[(pass) & 1][j] = m_ < m1 ? m_ * HS_C : -1;                               \
         }                                                                                       \
         if (has_res) {                                                                          \
             _Pragma("unroll") for (int j = 0; j < HS_ROWS(pass) / 8; ++j) {                     \
                 if (IN16) {                                                                     \
-                    const f16x4 r16_ = *(const f16x4 *)((const _Float16 *)p.res + obase + max(off[(pass) & 1][j], 0)); \
+                    const _Float16 *rb_ = (RECT && res_stale[j]) ? (const _Float16 *)p.bg_res + 4 * cq : (const _Float16 *)p.res + obase; \
+                    const f16x4 r16_ = *(const f16x4 *)(rb_ + max(off[(pass) & 1][j], 0));      \
                     rv[(pass) & 1][j] = make_float4((float)r16_[0], (float)r16_[1], (float)r16_[2], (float)r16_[3]); \
-                } else rv[(pass) & 1][j] = *(const float4 *)(p.res + obase + max(off[(pass) & 1][j], 0)); \
+                } else {                                                                        \
+                    const float *rb_ = (RECT && res_stale[j]) ? p.bg_res + 4 * cq : p.res + obase; \
+                    rv[(pass) & 1][j] = *(const float4 *)(rb_ + max(off[(pass) & 1][j], 0));    \
+                }                                                                               \
             }                                                                                   \
         }                                                                                       \
     }
@@ -381,12 +404,11 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
         }
     }
     if (RECT && p.bg_out) {
-        // the layers that read this output reach beyond the rectangle: the pixels of the fill rectangle outside it take the
-        // layer's state-independent background values; the image's parts share the pixels, 32 lanes per pixel
-        const int fy0 = fill & 255, fx0 = (fill >> 8) & 255, fh = (fill >> 16) & 255, fw = fill >> 24;
-        const float invF = 1.0f / (float)fw;
-        for (int q = part * 8 + rr0; q < fh * fw; q += 8 * parts) {
-            const int fy = (int)(((float)q + 0.5f) * invF), y_ = fy0 + fy, x_ = fx0 + q - fy * fw;
+        // the layers that read this output are full layers: every pixel of the canvas outside the rectangle takes the layer's
+        // state-independent background value; the image's parts share the pixels, 32 lanes per pixel
+        const float invF = 1.0f / (float)p.Wd;
+        for (int q = part * 8 + rr0; q < HWc; q += 8 * parts) {
+            const int y_ = (int)(((float)q + 0.5f) * invF), x_ = q - y_ * p.Wd;
             if (y_ >= cy0 && y_ < cy0 + rh && x_ >= cx0 && x_ < cx0 + rw) continue;
             const int o_ = (y_ * p.Wd + x_) * HS_C + 4 * cq;
             if (OUT16) *(f16x4 *)((_Float16 *)p.out + (long)img * HWc * HS_C + o_) = *(const f16x4 *)((const _Float16 *)p.bg_out + o_);
@@ -560,7 +582,7 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
     SNK_REQUIRE((long)n_images * n_blk < (1l << 31) && (long)HW * HS_C < (1l << 31), "snk_conv3x3_bn_f16s: batch too large");
     ConvHsArgs a = {d_x, (const f16x8 *)d_wS, (const float *)((const _Float16 *)d_wS + HS_WS_ELEMS), d_scale, d_shift,
                     d_residual, d_out, d_w1x1, d_h1, s1, b1, height, width, n_blk, tiles_base, tiles_rem, relu, (n_images / 8) * 8,
-                    d_center, d_stat_part, nullptr, nullptr, nullptr};
+                    d_center, d_stat_part, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
     const int n_mt = tiles_max, grid = n_images * n_blk;
     hipStream_t st = (hipStream_t)stream;
     if (grid_out) *grid_out = grid;
@@ -682,7 +704,6 @@ __global__ __launch_bounds__(256) void k_obs_bbox(const float *__restrict__ plan
 struct RectPlanArgs {
     int n_layers;
     int grow[HS_RECT_MAX_LAYERS];          // the layer's rectangle = bounding box grown by this many pixels, cut to the canvas
-    int fill[HS_RECT_MAX_LAYERS];          // its fill rectangle = the rectangle grown by this many more (< 0: the whole canvas)
     uint4 *desc;                           // [n_layers][max_blocks]
     long max_blocks;
     int *counts;                           // [n_layers][2]: descriptors written, M tiles they cover
@@ -693,7 +714,7 @@ struct RectPlanArgs {
 __global__ __launch_bounds__(1024) void k_rect_plan(const unsigned *__restrict__ bbox, int n, int Hd, int Wd, RectPlanArgs a)
 {
     __shared__ int cnt[9], cur[9], tiles_sum;
-    const int L = blockIdx.x, g = a.grow[L], fg = a.fill[L], tid = threadIdx.x;
+    const int L = blockIdx.x, g = a.grow[L], tid = threadIdx.x;
     if (tid < 9) cnt[tid] = 0;
     if (tid == 0) tiles_sum = 0;
     __syncthreads();
@@ -725,14 +746,11 @@ __global__ __launch_bounds__(1024) void k_rect_plan(const unsigned *__restrict__
         int tm;
         const int parts = hs_rect_parts(hr, wr, Hd, Wd, &tm);
         const int T = (hr * wr + 31) / 32, base = T / parts, rem = T % parts;
-        int fy0 = 0, fx0 = 0, fy1 = Hd - 1, fx1 = Wd - 1;
-        if (fg >= 0) { fy0 = max(y0 - fg, 0); fx0 = max(x0 - fg, 0); fy1 = min(y1 + fg, Hd - 1); fx1 = min(x1 + fg, Wd - 1); }
         const unsigned rect = (unsigned)y0 | (unsigned)x0 << 8 | (unsigned)hr << 16 | (unsigned)wr << 24;
-        const unsigned fill = (unsigned)fy0 | (unsigned)fx0 << 8 | (unsigned)(fy1 - fy0 + 1) << 16 | (unsigned)(fx1 - fx0 + 1) << 24;
         const int slot = atomicAdd(&cur[tm], parts);
         for (int k = 0; k < parts; ++k) {
             const int tile0 = k * base + min(k, rem), ntile = base + (k < rem ? 1 : 0);
-            desc[slot + k] = make_uint4((unsigned)img, rect, (unsigned)tile0 | (unsigned)ntile << 8 | (unsigned)k << 16 | (unsigned)parts << 24, fill);
+            desc[slot + k] = make_uint4((unsigned)img, rect, (unsigned)tile0 | (unsigned)ntile << 8 | (unsigned)k << 16 | (unsigned)parts << 24, b);
         }
     }
 }
@@ -761,10 +779,9 @@ extern "C" long snk_conv_rect_max_blocks(int n_images, int height, int width)
 }
 
 extern "C" int snk_conv_rect_plan(const float *d_planes, float b0, float b1, float b2, int n_images, int height, int width,
-                                  int n_layers, const int *grow, const int *fill_grow, void *d_bbox, void *d_desc, int *d_counts,
-                                  void *stream)
+                                  int n_layers, const int *grow, void *d_bbox, void *d_desc, int *d_counts, void *stream)
 {
-    SNK_REQUIRE(d_planes && grow && fill_grow && d_bbox && d_desc && d_counts, "snk_conv_rect_plan: NULL argument");
+    SNK_REQUIRE(d_planes && grow && d_bbox && d_desc && d_counts, "snk_conv_rect_plan: NULL argument");
     SNK_REQUIRE(n_layers >= 1 && n_layers <= HS_RECT_MAX_LAYERS, "snk_conv_rect_plan: %d layers (at most %d)", n_layers, HS_RECT_MAX_LAYERS);
     const long mb = snk_conv_rect_max_blocks(n_images, height, width);
     SNK_REQUIRE(mb >= 0 && mb < (1l << 31), "snk_conv_rect_plan: bad shape %d x %d x %d", n_images, height, width);
@@ -774,7 +791,6 @@ extern "C" int snk_conv_rect_plan(const float *d_planes, float b0, float b1, flo
     for (int i = 0; i < n_layers; ++i) {
         SNK_REQUIRE(grow[i] >= 0 && grow[i] < 128, "snk_conv_rect_plan: grow[%d] = %d", i, grow[i]);
         a.grow[i] = grow[i];
-        a.fill[i] = fill_grow[i] > 127 ? 127 : fill_grow[i];
     }
     a.desc = (uint4 *)d_desc; a.max_blocks = mb; a.counts = d_counts;
     hipStream_t st = (hipStream_t)stream;
@@ -786,8 +802,10 @@ extern "C" int snk_conv_rect_plan(const float *d_planes, float b0, float b1, flo
 
 static int conv_f16s_rect_launch(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
                                  const float *d_residual, float *d_out, const void *d_desc, const int *d_count,
-                                 const float *d_bg_out, int n_images, int height, int width, bool act16, void *stream)
+                                 const float *d_bg_in, int grow_in, const float *d_bg_res, int grow_res, const float *d_bg_out,
+                                 int n_images, int height, int width, bool act16, void *stream)
 {
+    SNK_REQUIRE(grow_in >= 0 && grow_in < 128 && grow_res >= 0 && grow_res < 128, "snk_conv3x3_bn_f16s_rect: grow_in %d, grow_res %d", grow_in, grow_res);
     SNK_REQUIRE(d_x && d_wS && d_scale && d_shift && d_out && d_desc && d_count, "snk_conv3x3_bn_f16s_rect: NULL argument");
     SNK_REQUIRE(d_out != d_x, "snk_conv3x3_bn_f16s_rect: in-place convolution is not possible");
     const long mb = snk_conv_rect_max_blocks(n_images, height, width);
@@ -796,7 +814,7 @@ static int conv_f16s_rect_launch(const float *d_x, const void *d_wS, const float
     if (n_images == 0) return 0;
     ConvHsArgs a = {d_x, (const f16x8 *)d_wS, (const float *)((const _Float16 *)d_wS + HS_WS_ELEMS), d_scale, d_shift,
                     d_residual, d_out, nullptr, nullptr, 0.f, 0.f, height, width, 1, 0, 0, 1, 0, nullptr, nullptr,
-                    (const uint4 *)d_desc, d_count, d_bg_out};
+                    (const uint4 *)d_desc, d_count, d_bg_out, d_bg_in, d_residual ? d_bg_res : nullptr, grow_in, grow_res};
     if (act16) {
         if (d_residual) k_conv3x3_f16s_rect<2, false, 3><<<(int)mb, 256, 0, (hipStream_t)stream>>>(a);
         else k_conv3x3_f16s_rect<1, false, 3><<<(int)mb, 256, 0, (hipStream_t)stream>>>(a);
@@ -808,19 +826,23 @@ static int conv_f16s_rect_launch(const float *d_x, const void *d_wS, const float
 
 extern "C" int snk_conv3x3_bn_f16s_rect(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
                                         const float *d_residual, float *d_out, const void *d_desc, const int *d_count,
+                                        const float *d_bg_in, int grow_in, const float *d_bg_res, int grow_res,
                                         const float *d_bg_out, int n_images, int height, int width, void *stream)
 {
-    return conv_f16s_rect_launch(d_x, d_wS, d_scale, d_shift, d_residual, d_out, d_desc, d_count, d_bg_out, n_images, height, width,
-                                 false, stream);
+    return conv_f16s_rect_launch(d_x, d_wS, d_scale, d_shift, d_residual, d_out, d_desc, d_count, d_bg_in, grow_in, d_bg_res, grow_res,
+                                 d_bg_out, n_images, height, width, false, stream);
 }
 
-// the sub-rectangle form of snk_conv3x3_bn_f16_act16 (f16 activations in and out, relu = 1; d_bg_out16: f16 [height][width][128])
+// the sub-rectangle form of snk_conv3x3_bn_f16_act16 (f16 activations in and out, relu = 1; the background images are f16
+// [height][width][128])
 extern "C" int snk_conv3x3_bn_f16_act16_rect(const void *d_x16, const void *d_wS, const float *d_scale, const float *d_shift,
                                              const void *d_residual16, void *d_out16, const void *d_desc, const int *d_count,
+                                             const void *d_bg_in16, int grow_in, const void *d_bg_res16, int grow_res,
                                              const void *d_bg_out16, int n_images, int height, int width, void *stream)
 {
     return conv_f16s_rect_launch((const float *)d_x16, d_wS, d_scale, d_shift, (const float *)d_residual16, (float *)d_out16, d_desc,
-                                 d_count, (const float *)d_bg_out16, n_images, height, width, true, stream);
+                                 d_count, (const float *)d_bg_in16, grow_in, (const float *)d_bg_res16, grow_res,
+                                 (const float *)d_bg_out16, n_images, height, width, true, stream);
 }
 
 extern "C" int snk_conv3x3_bn_f16s(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,

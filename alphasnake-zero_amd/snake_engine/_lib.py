@@ -61,11 +61,11 @@ PROTOTYPES = {
     "snk_conv3x3_bn_f16s": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "snk_conv3x3_bn_f16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "snk_conv_rect_max_blocks": (C.c_long, [i32, i32, i32]),
-    "snk_conv_rect_plan": (i32, [vp, C.c_float, C.c_float, C.c_float, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), vp, vp, vp, vp]),
+    "snk_conv_rect_plan": (i32, [vp, C.c_float, C.c_float, C.c_float, i32, i32, i32, i32, C.POINTER(i32), vp, vp, vp, vp]),
     "snk_stem_conv_bn_relu_f32_rect": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "snk_stem_conv_bn_relu_f16out_rect": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
-    "snk_conv3x3_bn_f16_act16_rect": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
-    "snk_conv3x3_bn_f16s_rect": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "snk_conv3x3_bn_f16_act16_rect": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, i32, i32, i32, vp]),
+    "snk_conv3x3_bn_f16s_rect": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, i32, i32, i32, vp]),
     "snk_conv3x3_bn_f16s_head": (i32, [vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, i32, i32, i32, vp]),
     "snk_conv3x3_bn_f16_act16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "snk_stem_conv_bn_relu_f16out": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),

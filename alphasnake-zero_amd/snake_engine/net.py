@@ -66,11 +66,11 @@ def activation_scales(weights, target_log2=9):
 
 
 def rect_fill_plan(n_rect):
-    """fill_grow of every sub-rectangle layer: the output of tower layer i is read by layer i + 1 (on that layer's rectangle
-    grown by one pixel) and, when it closes a residual block (odd i), by layer i + 2 as the shortcut (on that layer's
-    rectangle): a sub-rectangle layer fills 2 pixels of background around its rectangle for sub-rectangle readers, the whole
-    canvas (-1) when a full layer reads it"""
-    return [-1 if (i + 1 >= n_rect or (i % 2 == 1 and i + 2 >= n_rect)) else 2 for i in range(n_rect)]
+    """Which sub-rectangle layers also write their background into the rest of the canvas.  The output of tower layer i is
+    read by layer i + 1 and, when it closes a residual block (odd i), by layer i + 2 as the shortcut.  A sub-rectangle reader
+    takes what lies outside its producer's rectangle from the producer's background image; a FULL reader reads the tensor
+    everywhere, so a sub-rectangle layer with a full reader fills the canvas."""
+    return [i + 1 >= n_rect or (i % 2 == 1 and i + 2 >= n_rect) for i in range(n_rect)]
 
 
 class ClockProbe:
@@ -329,10 +329,10 @@ class QNet:
             bufs = self._ws[key]
         a, b, c, last = bufs
         x = planes[s0:s0 + m]
-        plan = self._rect_plan(x, m, k, st) if self.n_rect > 0 and m >= self.rect_min else None
+        plan = self._rect_plan(x, m, k, st) if self._use_rect(m) else None
         if plan is not None and self.n_rect >= 2:
             check(L.snk_stem_conv_bn_relu_f16out_rect(x.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(),
-                                                      self.stem_sh.data_ptr(), a.data_ptr(), plan[3].data_ptr(), 3, m, h, w, st))
+                                                      self.stem_sh.data_ptr(), a.data_ptr(), plan[3].data_ptr(), 1, m, h, w, st))
         else:
             check(L.snk_stem_conv_bn_relu_f16out(x.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(),
                                                  self.stem_sh.data_ptr(), a.data_ptr(), m, h, w, st))
@@ -346,8 +346,7 @@ class QNet:
             if plan is not None and i < self.n_rect:       # a sub-rectangle layer is never the last one: f16 output
                 check(L.snk_conv3x3_bn_f16_act16_rect(xin.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
                                                       self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),
-                                                      dst.data_ptr(), plan[0][i].data_ptr(), plan[1][i].data_ptr(),
-                                                      plan[2][i].data_ptr(), m, h, w, st))
+                                                      dst.data_ptr(), *self._rect_args(i, plan, res), m, h, w, st))
             else:
                 check(L.snk_conv3x3_bn_f16_act16(xin.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
                                                  self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),
@@ -376,10 +375,10 @@ class QNet:
         L, h, w = self.L, self.h, self.w
         a, b, c = self._workspace(m, k)
         x = planes[s0:s0 + m]
-        plan = self._rect_plan(x, m, k, st) if self.n_rect > 0 and m >= self.rect_min else None
-        if plan is not None and self.n_rect >= 2:         # layer 0 and layer 1's shortcut read the stem's output on the box grown by 3 pixels only
+        plan = self._rect_plan(x, m, k, st) if self._use_rect(m) else None
+        if plan is not None and self.n_rect >= 2:         # both readers of the stem's output (layer 0, layer 1's shortcut) are sub-rectangle layers
             check(L.snk_stem_conv_bn_relu_f32_rect(x.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(),
-                                                   self.stem_sh.data_ptr(), a.data_ptr(), plan[3].data_ptr(), 3, m, h, w, st))
+                                                   self.stem_sh.data_ptr(), a.data_ptr(), plan[3].data_ptr(), 1, m, h, w, st))
         else:
             check(L.snk_stem_conv_bn_relu_f32(x.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(),
                                               self.stem_sh.data_ptr(), a.data_ptr(), m, h, w, st))
@@ -414,9 +413,10 @@ class QNet:
 
     # ---- sub-rectangle form ----------------------------------------------------------------------
     def backgrounds(self):
-        """[n_rect][h][w][128]: the outputs of the first tower layers on an all-background observation, computed with the
-        full kernels themselves (so that a pixel the sub-rectangle form fills equals the pixel the full form computes,
-        bit for bit); made again when the weights or an activation scale change."""
+        """[1 + n_rect][h][w][128]: the outputs of the stem (index 0) and of the first tower layers (index 1 + i) on an
+        all-background observation, computed with the full kernels themselves (so that a pixel the sub-rectangle form takes
+        from here equals the pixel the full form computes, bit for bit); made again when the weights or an activation
+        scale change."""
         if self._bg is None:
             m, st = 1, torch.cuda.current_stream().cuda_stream
             a16 = self.conv_algo == "f16a"
@@ -426,7 +426,8 @@ class QNet:
             stem = self.L.snk_stem_conv_bn_relu_f16out if a16 else self.L.snk_stem_conv_bn_relu_f32
             check(stem(blank.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(), self.stem_sh.data_ptr(),
                        bufs[0].data_ptr(), m, self.h, self.w, st))
-            bg = torch.empty((self.n_rect, self.h, self.w, 128), dtype=dt, device=self.device)
+            bg = torch.empty((1 + self.n_rect, self.h, self.w, 128), dtype=dt, device=self.device)
+            bg[0].copy_(bufs[0][0])
             cur, t1, t2 = bufs
             tm, self.conv_timing = self.conv_timing, None
 
@@ -440,14 +441,25 @@ class QNet:
             for i in range(self.n_rect):
                 if i % 2 == 0:
                     conv(i, cur, None, t1)
-                    bg[i].copy_(t1[0])
+                    bg[1 + i].copy_(t1[0])
                 else:
                     conv(i, t1, cur, t2)
-                    bg[i].copy_(t2[0])
+                    bg[1 + i].copy_(t2[0])
                     cur, t2 = t2, cur
             self.conv_timing = tm
             self._bg = bg
         return self._bg
+
+    def _rect_args(self, i, plan, res):
+        """the sub-rectangle arguments of tower layer i: descriptors, count, the producers' background images and the pixels
+        they computed around the bounding box (the stem 1, tower layer j: j + 2), this layer's own image when it fills"""
+        desc, counts, bg = plan[:3]
+        return (desc[i].data_ptr(), counts[i].data_ptr(), bg[i].data_ptr(), i + 1,
+                None if res is None else bg[i - 1].data_ptr(), i, bg[1 + i].data_ptr() if self.rect_fill[i] else None)
+
+    def _use_rect(self, m):
+        # not inside a HIP-graph capture: the plan's buffers and the lazily made backgrounds belong to the eager path
+        return self.n_rect > 0 and m >= self.rect_min and not torch.cuda.is_current_stream_capturing()
 
     def _rect_plan(self, x, m, k, st):
         """descriptors of this chunk's sub-rectangle layers: (descriptor tensor [n_rect][max_blocks][4], counts [n_rect][2])"""
@@ -472,11 +484,10 @@ class QNet:
             self.rect_tiles.append((m, counts))
         import ctypes as C
         grow = (C.c_int * self.n_rect)(*[i + 2 for i in range(self.n_rect)])
-        fill = (C.c_int * self.n_rect)(*self.rect_fill)
         # the descriptor array of layer l starts at l * max_blocks(m): the tensor may be wider (an earlier, larger chunk)
         desc_m = desc if desc.shape[1] == mb else desc.view(-1)[:self.n_rect * mb * 4].view(self.n_rect, mb, 4)
         b0, b1, b2 = self.background
-        check(self.L.snk_conv_rect_plan(x.data_ptr(), b0, b1, b2, m, self.h, self.w, self.n_rect, grow, fill,
+        check(self.L.snk_conv_rect_plan(x.data_ptr(), b0, b1, b2, m, self.h, self.w, self.n_rect, grow,
                                         bbox.data_ptr(), desc_m.data_ptr(), counts.data_ptr(), st))
         return desc_m, counts, bg, bbox
 
@@ -486,11 +497,9 @@ class QNet:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream())
         if plan is not None and i < self.n_rect and h1 is None:
-            desc, counts, bg = plan[:3]
             check(self.L.snk_conv3x3_bn_f16s_rect(x.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
                                                   self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),
-                                                  out.data_ptr(), desc[i].data_ptr(), counts[i].data_ptr(), bg[i].data_ptr(),
-                                                  m, self.h, self.w, st))
+                                                  out.data_ptr(), *self._rect_args(i, plan, res), m, self.h, self.w, st))
             if tm is not None:
                 e1.record(torch.cuda.current_stream())
                 tm.append((e0, e1, 2.0 * m * self.h * self.w * 9 * 128 * 128))

@@ -202,37 +202,39 @@ int snk_conv3x3_bn_f16(const float *d_x, const void *d_wS, const float *d_scale,
                        void *stream);
 /* The sub-rectangle form of snk_conv3x3_bn_f16s (relu = 1).  The reference's observation (game.py:215-257) is ONE pixel value
  * (0, WALL, 0) everywhere outside the board window, and a 3x3 'same' convolution moves information by one pixel per layer, so
- * the output of the tower's k-th layer (alpha_nnet.py:25-47) outside the window grown by k + 1 pixels does not depend on the
- * state: it is what the layer gives on an all-background observation (the zero padding at the canvas edge included).  Only
- * the grown window is computed per observation; results are bit-identical to the full convolution.
+ * the output of the stem outside the window grown by 1 pixel, and of the tower's k-th layer (alpha_nnet.py:25-47) outside the
+ * window grown by k + 2, does not depend on the state: it is what the layer gives on an all-background observation (the zero
+ * padding at the canvas edge included) -- the layer's BACKGROUND IMAGE, [height][width][128].  Only the grown window is computed
+ * and written per observation; a reader takes a pixel outside the producer's window from the producer's background image.
+ * Results are bit-identical to the full convolution.
  * snk_conv_rect_plan: finds every observation's bounding box of non-background pixels (d_planes: [n][height][width][3], the
- *   stem's input; d_bbox: n uint32 of scratch) and writes, for each of n_layers layers, the block descriptors of the
- *   rectangles box grown by grow[l] (cut to the canvas): d_desc = n_layers * snk_conv_rect_max_blocks(n, height, width)
- *   descriptors of 16 bytes, d_counts[2 l] = descriptors of layer l, d_counts[2 l + 1] = 32-row GEMM tiles they cover.
- *   fill_grow[l] >= 0: the layer also copies its background into the rectangle grown by that many further pixels (what the
- *   next sub-rectangle layers read: 2); < 0: into the whole canvas (the next reader is a full layer).
- * snk_conv3x3_bn_f16s_rect: layer l's launch: d_desc / d_count point at layer l's descriptors and count; d_bg_out:
- *   [height][width][128] = the layer's output on the all-background observation (or NULL: no fill).  d_x and d_residual
- *   must be valid on the rectangle grown by 1 / on the rectangle; pixels of d_out outside the fill rectangle are untouched.
- * snk_stem_conv_bn_relu_f32_rect: snk_stem_conv_bn_relu_f32 (alpha_nnet.py:21-22) on the bounding boxes (d_bbox as
- *   snk_conv_rect_plan wrote it) grown by `grow` pixels: what the first sub-rectangle layers read of the stem's output. */
+ *   stem's input; d_bbox: n uint32 = y0 | x0 << 8 | y1 << 16 | x1 << 24) and writes, for each of n_layers layers, the block
+ *   descriptors of the rectangles box grown by grow[l] (cut to the canvas): d_desc = n_layers *
+ *   snk_conv_rect_max_blocks(n, height, width) descriptors of 16 bytes, d_counts[2 l] = descriptors of layer l,
+ *   d_counts[2 l + 1] = 32-row GEMM tiles they cover.
+ * snk_conv3x3_bn_f16s_rect: one layer's launch: d_desc / d_count point at that layer's descriptors and count.  d_x is valid on
+ *   the box grown by grow_in (what its producer computed) and read from d_bg_in outside it (d_bg_in NULL: d_x is valid
+ *   wherever the taps reach); d_residual likewise with grow_res / d_bg_res.  d_out is written on the layer's rectangle only --
+ *   and, with d_bg_out (the layer's own background image) given, everywhere else on the canvas too (the readers are full layers).
+ * snk_stem_conv_bn_relu_f32_rect: snk_stem_conv_bn_relu_f32 (alpha_nnet.py:21-22) on the boxes grown by `grow` pixels. */
 long snk_conv_rect_max_blocks(int n_images, int height, int width);
 int snk_conv_rect_plan(const float *d_planes, float b0, float b1, float b2, int n_images, int height, int width,
-                       int n_layers, const int *grow, const int *fill_grow, void *d_bbox, void *d_desc, int *d_counts,
-                       void *stream);
+                       int n_layers, const int *grow, void *d_bbox, void *d_desc, int *d_counts, void *stream);
 int snk_stem_conv_bn_relu_f32_rect(const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,
                                    float *d_out, const void *d_bbox, int grow, int n_images, int height, int width,
                                    void *stream);
 /* the same two for the reduced-precision tower with f16 activations (snk_stem_conv_bn_relu_f16out, snk_conv3x3_bn_f16_act16 with
- * relu = 1 and f16 output; d_bg_out16: f16 [height][width][128]) */
+ * relu = 1 and f16 output; f16 background images) */
 int snk_stem_conv_bn_relu_f16out_rect(const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,
                                       void *d_out16, const void *d_bbox, int grow, int n_images, int height, int width,
                                       void *stream);
 int snk_conv3x3_bn_f16_act16_rect(const void *d_x16, const void *d_wS, const float *d_scale, const float *d_shift,
                                   const void *d_residual16, void *d_out16, const void *d_desc, const int *d_count,
+                                  const void *d_bg_in16, int grow_in, const void *d_bg_res16, int grow_res,
                                   const void *d_bg_out16, int n_images, int height, int width, void *stream);
 int snk_conv3x3_bn_f16s_rect(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
                              const float *d_residual, float *d_out, const void *d_desc, const int *d_count,
+                             const float *d_bg_in, int grow_in, const float *d_bg_res, int grow_res,
                              const float *d_bg_out, int n_images, int height, int width, void *stream);
 /* The tower's LAST layer with the head's 1x1 stage fused into its epilogue (alpha_nnet.py:46-50): besides (or, with
  * d_out NULL, instead of) the layer output it writes d_h1[n][height*width] = relu(dot(out[pixel][:], w1x1) * bn_scale

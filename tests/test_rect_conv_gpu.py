@@ -88,8 +88,8 @@ def _parts(hr, wr, H, W):
 
 
 def test_plan_matches_a_numpy_model(env):
-    """bounding boxes, rectangles, parts and fill rectangles of the plan against a NumPy restatement; every image's tiles
-    are covered exactly once, blocks come largest first"""
+    """bounding boxes, rectangles and parts of the plan against a NumPy restatement; every image's tiles are covered exactly
+    once, blocks come largest first"""
     torch, se, net = env
     from snake_engine._lib import lib, check
     L = lib()
@@ -97,14 +97,13 @@ def test_plan_matches_a_numpy_model(env):
     s = load_golden("states_11x11x4.npz")
     planes = torch.cat([torch.as_tensor(s["raw"]), _special_observations(torch, h, w)]).cuda().contiguous()
     n = planes.shape[0]
-    grow, fill = [2, 3, 4, 7], [2, 2, -1, -1]
+    grow = [2, 3, 4, 7]
     mb = L.snk_conv_rect_max_blocks(n, h, w)
     assert mb == n * max(_parts(a, b, h, w) for a in range(1, h + 1) for b in range(1, w + 1))
     desc = torch.full((len(grow), mb, 4), -1, dtype=torch.int32, device="cuda")
     counts = torch.zeros((len(grow), 2), dtype=torch.int32, device="cuda")
     bbox = torch.zeros(n, dtype=torch.int32, device="cuda")
-    check(L.snk_conv_rect_plan(planes.data_ptr(), 0.0, 1.0, 0.0, n, h, w, len(grow), (C.c_int * 4)(*grow), (C.c_int * 4)(*fill),
-                               bbox.data_ptr(), desc.data_ptr(), counts.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    check(L.snk_conv_rect_plan(planes.data_ptr(), 0.0, 1.0, 0.0, n, h, w, len(grow), (C.c_int * 4)(*grow), bbox.data_ptr(), desc.data_ptr(), counts.data_ptr(), torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     ph = planes.cpu().numpy()
     bb = bbox.cpu().numpy().view(np.uint32)
@@ -120,7 +119,7 @@ def test_plan_matches_a_numpy_model(env):
     # the golden observations' boxes are the 11 x 11 board window (the observer's head at the canvas centre)
     assert all(b[2] - b[0] == 10 and b[3] - b[1] == 10 and b[0] <= 10 <= b[2] for b in boxes[:230])
     dh, ch = desc.cpu().numpy().view(np.uint32), counts.cpu().numpy()
-    for l, (g, fg) in enumerate(zip(grow, fill)):
+    for l, g in enumerate(grow):
         nd = int(ch[l, 0])
         d = dh[l, :nd]
         assert (dh[l, nd:] == 0xFFFFFFFF).all()                          # nothing written past the count
@@ -150,12 +149,7 @@ def test_plan_matches_a_numpy_model(env):
                 assert t0 == nxt and part == k
                 nxt += nt
             assert nxt == T
-            if fg < 0:
-                f = (0, 0, h, w)
-            else:
-                f = (max(ry0 - fg, 0), max(rx0 - fg, 0), min(ry1 + fg, h - 1) - max(ry0 - fg, 0) + 1,
-                     min(rx1 + fg, w - 1) - max(rx0 - fg, 0) + 1)
-            assert all(p[2] == (f[0] | f[1] << 8 | f[2] << 16 | f[3] << 24) for p in parts)
+            assert all(p[2] == int(bb[i]) for p in parts)               # the box itself rides along (what the producers computed)
         assert int(ch[l, 1]) == tiles_total
         # largest first: the largest part of the images in descriptor order never grows
         biggest = {i: max((p[1] >> 8) & 255 for p in seen[i]) for i in range(n)}
@@ -168,7 +162,7 @@ def test_plan_matches_a_numpy_model(env):
 def test_rect_form_gives_the_same_bits_as_the_full_form(env, board, snakes, blocks, n_games, n_rect, monkeypatch):
     """whole net: Q of mid-game observations (and of hand-made ones: blank, single foreign pixels on edges and corners, no
     background at all) through the sub-rectangle layers == through the full layers, bit for bit; and every sub-rectangle
-    layer's output on its fill rectangle == the full layer's output there"""
+    layer's output on its rectangle (on the whole canvas where it fills) == the full layer's output there"""
     torch, se, net = env
     h = w = 2 * board - 1
     ws = _randomised_bn(net.glorot_uniform_weights((h, w, 3), blocks=blocks, seed=board), 5)
@@ -227,16 +221,18 @@ def test_rect_form_gives_the_same_bits_as_the_full_form(env, board, snakes, bloc
     saved = 0
     for i in range(rect.n_rect):
         valid = torch.zeros((m, h, w), dtype=torch.bool)
-        for img, _, _, fl in desc[i, :counts[i, 0]]:
-            fy, fx, fh, fw = fl & 255, (fl >> 8) & 255, (fl >> 16) & 255, fl >> 24
+        for img, rc, _, _ in desc[i, :counts[i, 0]]:
+            fy, fx, fh, fw = rc & 255, (rc >> 8) & 255, (rc >> 16) & 255, rc >> 24
             valid[int(img), fy:fy + fh, fx:fx + fw] = True
         assert valid.view(m, -1).any(1).all()
         v = valid.cuda()
+        if rect.rect_fill[i]:
+            v = torch.ones_like(v)
+        elif i < 2:                                                     # (first use of the NaN-filled buffer)
+            assert torch.isnan(o_rect[i][~v]).all()                     # nothing else is written
         a, b = o_full[i][v], o_rect[i][v]
         assert torch.isfinite(a).all()
         assert torch.equal(a, b), (i, (a - b).abs().max().item())
-        if rect.rect_fill[i] < 0:
-            assert v.all()
         saved += m * ((h * w + 31) // 32) - int(counts[i, 1])
     assert saved > 0
 
@@ -273,9 +269,10 @@ def test_backgrounds_follow_the_weights_and_scales(env):
     ws = net.glorot_uniform_weights((21, 21, 3), blocks=4, seed=2)
     qn = net.QNet(ws, (21, 21, 3))
     bg0 = qn.backgrounds().clone()
-    assert bg0.shape == (6, 21, 21, 128) and torch.isfinite(bg0).all()
+    assert bg0.shape == (7, 21, 21, 128) and torch.isfinite(bg0).all()          # the stem's and six tower layers'
     # far from the canvas edge the background of a layer is one pixel value (nothing there sees the zero padding)
-    assert torch.equal(bg0[0, 5, 5], bg0[0, 12, 9]) and not torch.equal(bg0[0, 0, 0], bg0[0, 5, 5])
+    assert torch.equal(bg0[1, 5, 5], bg0[1, 12, 9]) and not torch.equal(bg0[1, 0, 0], bg0[1, 5, 5])
+    assert torch.equal(bg0[0, 1, 1], bg0[0, 12, 9]) and not torch.equal(bg0[0, 0, 0], bg0[0, 1, 1])
     qn.set_x_scale(2, qn.conv_x_scale[2] / 4)
     assert qn._bg is None
     qn.set_weights(_randomised_bn(ws, 8))
@@ -290,8 +287,11 @@ def test_rect_entry_points_refuse_bad_arguments(env):
     assert L.snk_conv_rect_max_blocks(0, 21, 21) == 0
     x = torch.zeros(8, device="cuda")
     g = (C.c_int * 1)(2)
-    assert L.snk_conv_rect_plan(None, 0.0, 1.0, 0.0, 1, 21, 21, 1, g, g, x.data_ptr(), x.data_ptr(), x.data_ptr(), None) < 0
-    assert L.snk_conv_rect_plan(x.data_ptr(), 0.0, 1.0, 0.0, 1, 21, 21, 25, g, g, x.data_ptr(), x.data_ptr(), x.data_ptr(), None) < 0
+    assert L.snk_conv_rect_plan(None, 0.0, 1.0, 0.0, 1, 21, 21, 1, g, x.data_ptr(), x.data_ptr(), x.data_ptr(), None) < 0
+    assert L.snk_conv_rect_plan(x.data_ptr(), 0.0, 1.0, 0.0, 1, 21, 21, 25, g, x.data_ptr(), x.data_ptr(), x.data_ptr(), None) < 0
     assert b"layers" in L.snk_last_error()
     assert L.snk_conv3x3_bn_f16s_rect(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), None, x.data_ptr(), x.data_ptr(),
-                                      x.data_ptr(), None, 1, 21, 21, None) < 0           # in place
+                                      x.data_ptr(), None, 1, None, 0, None, 1, 21, 21, None) < 0           # in place
+    y = torch.zeros(8, device="cuda")
+    assert L.snk_conv3x3_bn_f16s_rect(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), None, y.data_ptr(), x.data_ptr(),
+                                      x.data_ptr(), None, 200, None, 0, None, 1, 21, 21, None) < 0 and b"grow_in" in L.snk_last_error()

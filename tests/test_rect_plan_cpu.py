@@ -27,30 +27,30 @@ def _inside(a, b):
     return a[0] >= b[0] and a[1] >= b[1] and a[2] <= b[2] and a[3] <= b[3]
 
 
-def test_every_read_rectangle_was_written():
-    """tower layer i computes box + (i + 2) and fills fill_grow[i] more (or the canvas); it reads its input on its rectangle
-    grown by one and, for odd i, the shortcut (output of layer i - 2, the stem for i = 1) on its rectangle.  The stem
-    writes box + 3 when two or more layers use the form, else the canvas."""
+def test_every_pixel_a_layer_reads_is_current():
+    """Tower layer i < n_rect computes box + (i + 2) only (the stem box + 1 when both of its readers are sub-rectangle
+    layers).  A sub-rectangle reader is told what its producer computed (QNet._rect_args: grow_in = i + 1 for the input,
+    grow_res = i for the shortcut) and takes the rest from the producer's background image -- the two numbers must be
+    exactly the producer's rectangle; a FULL reader needs the whole canvas written, which rect_fill_plan arranges."""
     rng = np.random.RandomState(0)
     for h, w, n_layers in ((21, 21, 8), (13, 13, 8), (37, 37, 20), (9, 9, 4), (21, 13, 6)):
         canvas = (0, 0, h - 1, w - 1)
         for n_rect in range(0, n_layers):
-            fill = rect_fill_plan(n_rect)
-            assert len(fill) == n_rect
-            for _ in range(40):
+            fills = rect_fill_plan(n_rect)
+            assert len(fills) == n_rect and (n_rect == 0 or fills[-1])
+            for _ in range(20):
                 y0, y1 = sorted(rng.randint(0, h, 2)); x0, x1 = sorted(rng.randint(0, w, 2))
                 box = (y0, x0, y1, x1)
-                stem = _grow(box, 3, h, w) if n_rect >= 2 else canvas
-                written = []
+                # what every producer leaves current in its output tensor: -1 = the stem
+                written = {-1: _grow(box, 1, h, w) if n_rect >= 2 else canvas}
+                computed = {-1: _grow(box, 1, h, w)}
                 for i in range(n_layers):
                     rect = _grow(box, i + 2, h, w) if i < n_rect else canvas
-                    reads_in = _grow(rect, 1, h, w)
-                    src = stem if i == 0 else written[i - 1]
-                    assert _inside(reads_in, src), (h, n_rect, i, box)
-                    if i % 2 == 1:
-                        sc = stem if i == 1 else written[i - 2]
-                        assert _inside(rect, sc), (h, n_rect, i, box)
-                    if i < n_rect:
-                        written.append(canvas if fill[i] < 0 else _grow(rect, fill[i], h, w))
-                    else:
-                        written.append(canvas)
+                    readers = [(i - 1, i + 1)] + ([(i - 2, i)] if i % 2 == 1 else [])     # (producer, grow the reader is told)
+                    for prod, told in readers:
+                        if i < n_rect:          # takes box + told from the tensor, the rest from the producer's background
+                            assert _grow(box, told, h, w) == computed[prod] and _inside(computed[prod], written[prod]), (h, n_rect, i, prod)
+                        else:                   # reads the tensor wherever its taps reach
+                            assert written[prod] == canvas, (h, n_rect, i, prod)
+                    computed[i] = rect
+                    written[i] = canvas if (i >= n_rect or fills[i]) else rect
