@@ -262,6 +262,25 @@ def test_f16_activation_tower_rect_form_gives_the_same_bits(env, board, snakes, 
     assert torch.isfinite(q_full).all() and torch.equal(q_full, q_rect) and torch.equal(rect.forward(planes), q_full)
 
 
+def test_bounded_fuzz_of_the_rect_form(env):
+    """tools/fuzz_rect.py, bounded: random canvases (square or not), depths, layer counts, chunkings and synthetic
+    observations (one-pixel boxes, boxes in corners, no box, no background) -- both forms equal bit for bit"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_rect", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_rect.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    keep = {k: os.environ.get(k) for k in ("SNK_CONV_RECT", "SNK_CONV_RECT_LAYERS")}
+    try:
+        assert fz.run(seed=11, trials=30, verbose=False) == 30
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_backgrounds_follow_the_weights_and_scales(env):
     """the per-layer constants are made again after set_weights and after a change of an activation scale (they are kept
     bit-identical to what the full layers compute)"""
