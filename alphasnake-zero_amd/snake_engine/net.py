@@ -296,6 +296,8 @@ class QNet:
             out = torch.empty((n, 3), dtype=torch.float32, device=self.device)
         if n == 0:
             return out
+        if self._use_rect(min(n, self.max_chunk)):
+            self.backgrounds()       # made on the caller's stream, before any chunk (on whatever stream) reads them
         n_chunks = (n + self.max_chunk - 1) // self.max_chunk
         if n_chunks == 1 or self.n_streams < 2:
             for s0 in range(0, n, self.max_chunk):
