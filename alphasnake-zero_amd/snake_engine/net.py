@@ -6,6 +6,7 @@ Weight list order (= Keras ``model.get_weights()`` order of the reference graph)
   for each of the 2*blocks residual convs: kernel (3,3,k,k), BN gamma/beta/mean/var,
   head kernel (1,1,k,1), head BN (4 x (1,)), dense kernel (h*w, 128), bias, dense_1 kernel (128, 3), bias.
 """
+import ctypes as C
 import math
 import os
 
@@ -484,7 +485,6 @@ class QNet:
         if self.rect_tiles is not None:          # bench.py: what the launches really executed
             counts = torch.zeros((self.n_rect, 2), dtype=torch.int32, device=self.device)
             self.rect_tiles.append((m, counts))
-        import ctypes as C
         grow = (C.c_int * self.n_rect)(*[i + 2 for i in range(self.n_rect)])
         # the descriptor array of layer l starts at l * max_blocks(m): the tensor may be wider (an earlier, larger chunk)
         desc_m = desc if desc.shape[1] == mb else desc.view(-1)[:self.n_rect * mb * 4].view(self.n_rect, mb, 4)

@@ -281,6 +281,39 @@ def test_bounded_fuzz_of_the_rect_form(env):
                 os.environ[k] = v
 
 
+def test_self_play_takes_the_same_moves_in_both_forms(env, monkeypatch):
+    """the whole path -- MPGameRunner + Agent (production-mode MCTS, Philox draws) + AlphaNNet -- with the same seeds: three
+    root turns of 96 games end on the same boards with the same recorded values and evaluation counts whether the tower's
+    first layers run on sub-rectangles or on the whole canvas (bit-identical Q values -> identical draws and moves)"""
+    torch, se, net = env
+    from utils.agent import Agent
+    from utils.alpha_nnet import AlphaNNet
+    from utils.mp_game_runner import MPGameRunner
+    import random
+    MPGameRunner.verbose = False
+    monkeypatch.setattr(MPGameRunner, "init", "device")      # start boards from the seeded device generator, as bench.py does
+    ws = _randomised_bn(net.glorot_uniform_weights((21, 21, 3), blocks=4, seed=3), 9)
+    out = {}
+    for form in ("0", "1", "1"):
+        random.seed(5); np.random.seed(5)
+        monkeypatch.setenv("SNK_CONV_RECT", form)
+        nn = AlphaNNet(input_shape=(21, 21, 3), _weights=ws)
+        assert nn._qnet.n_rect == (6 if form == "1" else 0)
+        alice = Agent(nn, 2, True, 8, 16, seed=77)
+        gr = MPGameRunner(11, 11, 4, 1, 96, seed=78)
+        gr.run(alice, max_turns=3)
+        states = gr.engine.export()
+        if form in out:                                       # the path is deterministic: the same form twice is the same run
+            again = (gr.env_steps, alice._mcts.stats["net_evals"], len(alice.records), bytes(gr.engine.export()))
+            assert again == out[form][:3] + (out[form][4],)
+            continue
+        out[form] = (gr.env_steps, alice._mcts.stats["net_evals"], len(alice.records), np.array(alice.values[:len(alice.records)]),
+                     bytes(states))
+    a, b = out["0"], out["1"]
+    assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and a[1] > 5000
+    assert np.array_equal(a[3], b[3]) and a[4] == b[4]
+
+
 def test_backgrounds_follow_the_weights_and_scales(env):
     """the per-layer constants are made again after set_weights and after a change of an activation scale (they are kept
     bit-identical to what the full layers compute)"""
