@@ -473,7 +473,7 @@ class QNet:
         key = ("rect", k)
         capturing = torch.cuda.is_current_stream_capturing()
         ws = None if capturing or self._ws is None else self._ws.get(key)
-        if ws is None or ws[0].shape[1] < mb or ws[2].shape[0] < m:
+        if ws is None or ws[0].shape[0] != self.n_rect or ws[0].shape[1] < mb or ws[2].shape[0] < m:
             ws = (torch.empty((self.n_rect, mb, 4), dtype=torch.int32, device=self.device),
                   torch.zeros((self.n_rect, 2), dtype=torch.int32, device=self.device),
                   torch.empty((m,), dtype=torch.int32, device=self.device))

@@ -329,6 +329,14 @@ def test_backgrounds_follow_the_weights_and_scales(env):
     assert qn._bg is None
     qn.set_weights(_randomised_bn(ws, 8))
     assert qn._bg is None and not torch.equal(qn.backgrounds(), bg0)
+    # weights of another depth through the same object: the plan's buffers follow the new layer count
+    x = _special_observations(torch, 21, 21).cuda().repeat(6, 1, 1, 1).nan_to_num(nan=2.0).contiguous()
+    q8 = qn.forward(x)
+    ws2 = net.glorot_uniform_weights((21, 21, 3), blocks=2, seed=4)
+    qn.set_weights(ws2)
+    assert qn.n_rect == 3 and qn.backgrounds().shape[0] == 4
+    monkey_full = net.QNet(ws2, (21, 21, 3)); monkey_full.n_rect = 0
+    assert torch.equal(qn.forward(x), monkey_full.forward(x)) and torch.isfinite(q8).all()
 
 
 def test_rect_entry_points_refuse_bad_arguments(env):
