@@ -27,6 +27,8 @@
 // pixel rows written; the residual loads of the next 64 rows are in flight meanwhile.  In the tower's last layer the
 // epilogue also reduces the head's 1x1 convolution per pixel and skips the layer output.  Workgroups map to (image,
 // part) XCD-aware: the parts of an image, which share halo rows, run on the same XCD (same L2) back to back.
+// The block body (hs_block) has two callers: k_conv3x3_f16s (whole images) and k_conv3x3_f16s_rect (the part of an image
+// that depends on the state: the first tower layers of the self-play path, see the comment above that kernel).
 #include "common.h"
 #include "train_fold.h"
 #include <stdlib.h>
@@ -435,10 +437,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
 }
 
 // The sub-rectangle form.  The reference's observation (game.py:215-257) is one background pixel (0, WALL, 0) everywhere
-// outside the board window, so the output of the tower's k-th 3x3 layer is the same for every state outside the window
-// grown by k + 1 pixels: only that rectangle is computed per image, everything else is a per-layer constant
-// (QNet._backgrounds).  Blocks take (image, rectangle, tile range) from descriptors; the M-tile count of a block selects
-// the body at run time (wave-uniform), so one launch covers every rectangle shape of the batch.
+// outside the board window, so the output of tower layer k (0-based) is the same for every state outside the window grown
+// by k + 2 pixels (the stem: 1): only that rectangle is computed and written per image; what a reader needs beyond its
+// producer's rectangle it takes from the producer's constant background image (QNet.backgrounds; p.bg_in / p.bg_res, chosen
+// per staging item and per shortcut row when the block sets up its addresses).  Blocks take (image, rectangle, tile range,
+// bounding box) from descriptors written by k_rect_plan; the M-tile count of a block selects the body at run time
+// (wave-uniform), so one launch covers every rectangle shape of the batch.
 template <int MODE, bool SPLIT = true, int IO16 = 0>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s_rect(ConvHsArgs p)
 {
