@@ -158,7 +158,7 @@ def test_plan_matches_a_numpy_model(env):
 
 
 @pytest.mark.parametrize("board,snakes,blocks,n_games,n_rect", [(11, 4, 4, 160, None), (7, 2, 4, 64, None), (11, 4, 4, 64, 7),
-                                                                  (19, 8, 10, 6, None), (5, 2, 2, 32, 3)])
+                                                                  (19, 8, 10, 6, None), (5, 2, 2, 32, 3), (11, 4, 4, 1900, None)])
 def test_rect_form_gives_the_same_bits_as_the_full_form(env, board, snakes, blocks, n_games, n_rect, monkeypatch):
     """whole net: Q of mid-game observations (and of hand-made ones: blank, single foreign pixels on edges and corners, no
     background at all) through the sub-rectangle layers == through the full layers, bit for bit; and every sub-rectangle
@@ -197,6 +197,8 @@ def test_rect_form_gives_the_same_bits_as_the_full_form(env, board, snakes, bloc
         assert torch.equal(rect.forward(planes[:47]), q_full[:47]) and torch.equal(rect.forward(planes[:48]), q_full[:48])
         rect.rect_min = 1
 
+    if m > 4000:                            # the bench's chunk size class: the whole-net comparison is the test
+        return
     # layer by layer
     st = torch.cuda.current_stream().cuda_stream
     from snake_engine._lib import check
