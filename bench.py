@@ -260,6 +260,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=8192, help="states per net forward chunk")
     ap.add_argument("--conv-algo", choices=["winograd", "direct", "bf16", "f16s", "f16", "f16a"], default=None,
                     help="default: f16s (float32-accurate split-f16 MFMA, the judged configuration); winograd, direct: f32 MFMA; bf16 = configs[4]-style bf16 MFMA, outside the 1e-5 tolerance")
+    ap.add_argument("--conv-rect", choices=["0", "1"], default=None,
+                    help="0: every tower layer convolves the whole canvas (the A/B arm of the sub-rectangle form; env SNK_CONV_RECT)")
     ap.add_argument("--board", type=int, default=11, choices=[7, 11, 19], help="board side; 19 with --snakes 8 --blocks 10 = BASELINE configs[4]")
     ap.add_argument("--snakes", type=int, default=4)
     ap.add_argument("--blocks", type=int, default=4, help="residual blocks of the Q-net")
@@ -285,6 +287,8 @@ def main():
     os.dup2(2, 1)
     if args.conv_algo:
         os.environ["SNK_CONV_ALGO"] = args.conv_algo
+    if args.conv_rect is not None:
+        os.environ["SNK_CONV_RECT"] = args.conv_rect
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
