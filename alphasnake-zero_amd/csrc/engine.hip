@@ -1028,6 +1028,22 @@ __global__ __launch_bounds__(CMP_THREADS) void k_cmp_scatter(const uint8_t *__re
     for (int q = 0; q < CMP_ITEMS; ++q) if (f[q]) out[pos++] = base + q;
 }
 
+// the same compaction in ONE launch for lists a single block walks quickly (the rollout ticks of small and medium batches are
+// bound by their launch count): every thread takes a run of consecutive flags; same output order as the three-kernel form
+#define CMP_ONE_MAX (CMP_THREADS * 64)
+__global__ __launch_bounds__(CMP_THREADS) void k_cmp_one(const uint8_t *__restrict__ flags, int n, int32_t *__restrict__ out,
+                                                         int32_t *__restrict__ count)
+{
+    __shared__ int sh[8];
+    const int per = (n + CMP_THREADS - 1) / CMP_THREADS, base = threadIdx.x * per;
+    int c = 0;
+    for (int q = 0; q < per; ++q) { const int i = base + q; if (i < n && flags[i]) ++c; }
+    int total;
+    int pos = block_exclusive_scan_256(c, &total, sh);
+    for (int q = 0; q < per; ++q) { const int i = base + q; if (i < n && flags[i]) out[pos++] = i; }
+    if (threadIdx.x == 0) *count = total;
+}
+
 // ------------------------------------------------------------------------------------------ C ABI
 // square boards of 5x5 (the eight standard start cells are distinct from there on, game.py:25-29) to 19x19 (SNK_MAX_CELLS);
 // the reference's observation is a rot90 of a (2H-1)x(2W-1) canvas, so only square boards batch (game.py:257)
@@ -1391,6 +1407,11 @@ extern "C" int snk_compact_flags(const uint8_t *d_flags, int n, int32_t *d_out, 
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) { SNK_CHECK_HIP(hipMemsetAsync(d_count, 0, sizeof(int32_t), st)); return 0; }
     SNK_REQUIRE(d_flags && d_out && d_scratch, "snk_compact_flags: NULL argument");
+    if (n <= CMP_ONE_MAX) {
+        k_cmp_one<<<1, CMP_THREADS, 0, st>>>(d_flags, n, d_out, d_count);
+        SNK_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     const int tiles = (n + CMP_TILE - 1) / CMP_TILE;
     k_cmp_count<<<tiles, CMP_THREADS, 0, st>>>(d_flags, n, d_scratch);
     k_cmp_scan<<<1, CMP_THREADS, 0, st>>>(d_scratch, tiles, d_count);

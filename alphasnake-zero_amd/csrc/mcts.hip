@@ -542,6 +542,72 @@ extern "C" int snk_mcts_backup(snk_tt *t, const uint32_t *d_entry, int m, const 
     return 0;
 }
 
+// ---- the rollout loop's bookkeeping (mp_game_runner.py:99-113), one launch each instead of a chain of tensor expressions ----
+// row (sub-game b, snake s) takes part in a tick when its snake is alive and the sub-game has not been retired
+__global__ void k_mcts_row_active(const uint8_t *__restrict__ alive_rows, const uint8_t *__restrict__ sub_active, int m, int S,
+                                  uint8_t *__restrict__ row_active)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) row_active[i] = (alive_rows[i] != 0 && sub_active[i / S] != 0) ? 1 : 0;
+}
+
+// after the tick's step: the sub-games that moved are counted (sim_steps += number of active ones), then a sub-game retires
+// when its game is over or its depth cap is reached (tick >= depth: mp_game_runner.py:108-113)
+__global__ void k_mcts_retire(uint8_t *__restrict__ sub_active, const uint8_t *__restrict__ done, const int32_t *__restrict__ sub_depth,
+                              int tick, int B, unsigned long long *__restrict__ sim_steps)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool act = i < B && sub_active[i] != 0;
+    const unsigned long long moved = __ballot(act);
+    if ((threadIdx.x & 63) == 0 && moved) atomicAdd(sim_steps, (unsigned long long)__popcll(moved));
+    if (act && (done[i] != 0 || tick >= sub_depth[i])) sub_active[i] = 0;
+}
+
+// the rows a tick has to evaluate (the compacted indices of the new keys): their (sub-game, snake) pairs and obstacle masks
+__global__ void k_mcts_gather_rows(const int32_t *__restrict__ idx, int n, const int32_t *__restrict__ pairs, const uint8_t *__restrict__ mask,
+                                   int32_t *__restrict__ out_pairs, uint8_t *__restrict__ out_mask)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = idx[i];
+    out_pairs[2 * i] = pairs[2 * r]; out_pairs[2 * i + 1] = pairs[2 * r + 1];
+    out_mask[3 * i] = mask[3 * r]; out_mask[3 * i + 1] = mask[3 * r + 1]; out_mask[3 * i + 2] = mask[3 * r + 2];
+}
+
+extern "C" int snk_mcts_gather_rows(const int32_t *d_idx, int n, const int32_t *d_pairs, const uint8_t *d_mask, int32_t *d_out_pairs,
+                                    uint8_t *d_out_mask, void *stream)
+{
+    SNK_REQUIRE(n >= 0, "snk_mcts_gather_rows: negative n");
+    if (n == 0) return 0;
+    SNK_REQUIRE(d_idx && d_pairs && d_mask && d_out_pairs && d_out_mask, "snk_mcts_gather_rows: NULL argument");
+    k_mcts_gather_rows<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(d_idx, n, d_pairs, d_mask, d_out_pairs, d_out_mask);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int snk_mcts_row_active(const uint8_t *d_alive_rows, const uint8_t *d_sub_active, int n_subgames, int n_snakes,
+                                   uint8_t *d_row_active, void *stream)
+{
+    SNK_REQUIRE(d_alive_rows && d_sub_active && d_row_active && n_snakes >= 1, "snk_mcts_row_active: bad argument");
+    const long m = (long)n_subgames * n_snakes;
+    if (m <= 0) return 0;
+    SNK_REQUIRE(m < (1l << 31), "snk_mcts_row_active: too many rows");
+    k_mcts_row_active<<<(int)((m + 255) / 256), 256, 0, (hipStream_t)stream>>>(d_alive_rows, d_sub_active, (int)m, n_snakes, d_row_active);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int snk_mcts_retire(uint8_t *d_sub_active, const uint8_t *d_done, const int32_t *d_sub_depth, int tick, int n_subgames,
+                               int64_t *d_sim_steps, void *stream)
+{
+    SNK_REQUIRE(d_sub_active && d_done && d_sub_depth && d_sim_steps, "snk_mcts_retire: NULL argument");
+    if (n_subgames <= 0) return 0;
+    k_mcts_retire<<<(n_subgames + 255) / 256, 256, 0, (hipStream_t)stream>>>(d_sub_active, d_done, d_sub_depth, tick, n_subgames,
+                                                                             (unsigned long long *)d_sim_steps);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" int snk_mcts_terminal_backup(snk_tt *t, const int8_t *d_rewards, int m, uint32_t *d_path_entry, uint8_t *d_path_move,
                                         int32_t *d_path_len, int path_depth, int sequential, void *stream)
 {

@@ -84,6 +84,9 @@ PROTOTYPES = {
     "snk_mcts_select_dctr": (i32, [vp, vp, i32, C.c_float, u64, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "snk_tt_set_priors_flagged": (i32, [vp, vp, vp, i32, vp, vp]),
     "snk_tt_lookup_insert_dnow": (i32, [vp, vp, vp, i32, vp, i32, vp, vp, vp]),
+    "snk_mcts_gather_rows": (i32, [vp, i32, vp, vp, vp, vp, vp]),
+    "snk_mcts_row_active": (i32, [vp, vp, i32, i32, vp, vp]),
+    "snk_mcts_retire": (i32, [vp, vp, vp, i32, i32, vp, vp]),
     "snk_mcts_backup": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp]),
     "snk_mcts_terminal_backup": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, vp]),
     "snk_mcts_root_moves": (i32, [vp, vp, i32, C.c_float, i32, vp, vp, C.c_int64, u64, C.c_uint32, C.c_uint32, vp, vp]),

@@ -136,6 +136,9 @@ class DeviceMCTS:
             self.path_move = torch.empty((m, D), dtype=torch.uint8, device=dev)
             self.path_len = torch.zeros((m,), dtype=torch.int32, device=dev)
             self.alive_rows = torch.empty((B, S), dtype=torch.uint8, device=dev)
+            self.row_active = torch.empty((m,), dtype=torch.uint8, device=dev)
+            self.eval_pairs = torch.empty((m, 2), dtype=torch.int32, device=dev)
+            self.eval_mask = torch.empty((m, 3), dtype=torch.uint8, device=dev)
             self.done = torch.empty((B,), dtype=torch.uint8, device=dev)
             self.rewards = torch.empty((m,), dtype=torch.int8, device=dev)
             self.cmp_idx = torch.empty((m,), dtype=torch.int32, device=dev)
@@ -228,6 +231,7 @@ class DeviceMCTS:
         n_alive = root_alive.sum(dim=1, dtype=torch.int32)
         depth = self.max_depth - 2 * (n_alive - 2)              # agent.py:45
         sub_depth = depth.repeat_interleave(par)
+        sub_depth_i32 = sub_depth.to(torch.int32).contiguous()
         n_ticks = max(1, int(depth.max().item()))
         epochs = self.max_breadth // par                        # agent.py:37
         tt = self.tt.h
@@ -267,11 +271,12 @@ class DeviceMCTS:
                     self.stats["rollout_ticks"] += 1
                 sim_steps_dev = None
             else:
-                sub_active = torch.ones((B,), dtype=torch.bool, device=self.device)
+                sub_active = torch.ones((B,), dtype=torch.uint8, device=self.device)
                 sim_steps_dev = torch.zeros((), dtype=torch.int64, device=self.device)
+                row_active = self.row_active
             for tick in (range(1, n_ticks + 1) if not fixed else ()):
                 self.roll.alive(n=B, out=self.alive_rows)
-                row_active = (self.alive_rows.bool() & sub_active[:, None]).reshape(-1).to(torch.uint8)
+                check(L.snk_mcts_row_active(_ptr(self.alive_rows), _ptr(sub_active), B, S, _ptr(row_active), st))
                 self.roll.observe(self.pairs, m, None, self.mask, self.key, legacy_mask=self.legacy_mask)
                 check(L.snk_tt_lookup_insert(tt, _ptr(self.key), _ptr(row_active), m, self.now, self.max_depth,
                                              _ptr(self.entry), _ptr(self.is_new), st))
@@ -280,10 +285,11 @@ class DeviceMCTS:
                 n_eval = int(self.cmp_cnt.item())               # the one host read-back of the tick
                 if n_eval:
                     idx = self.cmp_idx[:n_eval]
-                    eval_pairs = self.pairs.index_select(0, idx)
+                    eval_pairs, eval_mask = self.eval_pairs[:n_eval], self.eval_mask[:n_eval]
+                    check(L.snk_mcts_gather_rows(_ptr(idx), n_eval, _ptr(self.pairs), _ptr(self.mask), _ptr(eval_pairs), _ptr(eval_mask), st))
                     planes = self._planes(n_eval)
                     self.roll.observe(eval_pairs, n_eval, planes, None, None)
-                    q = self.evaluate(planes, self.mask.index_select(0, idx))   # nnet.v(all_states) (agent.py:190)
+                    q = self.evaluate(planes, eval_mask)            # nnet.v(all_states) (agent.py:190)
                     check(L.snk_tt_set_priors(tt, _ptr(self.entry), _ptr(idx), n_eval, _ptr(q.contiguous()), st))
                     self.stats["net_evals"] += n_eval
                 rank, n_rows = None, 0
@@ -299,11 +305,10 @@ class DeviceMCTS:
                                         _ptr(self.path_move), _ptr(self.path_len), D, seq, st))
                 # tic every live sub-game (mp_game_runner.py:104-106) in one launch over all B slots; sub-games retired by
                 # their depth cap must not move: their `active` flag is 0 and the kernel skips them (no host read-back)
-                act_u8 = sub_active.to(torch.uint8)
-                self.roll.step_active(act_u8, self.moves, B, done=self.done)
-                done = self.done.bool()
-                sim_steps_dev += act_u8.sum(dtype=torch.int64)
-                sub_active = sub_active & ~(done | (tick >= sub_depth))          # mp_game_runner.py:108-113
+                self.roll.step_active(sub_active, self.moves, B, done=self.done)
+                # the sub-games that moved are counted, then the finished ones and those at their depth cap retire
+                # (mp_game_runner.py:108-113): one launch (this was a chain of eight tensor expressions)
+                check(L.snk_mcts_retire(_ptr(sub_active), _ptr(self.done), _ptr(sub_depth_i32), tick, B, _ptr(sim_steps_dev), st))
                 self.stats["rollout_ticks"] += 1
             if sim_steps_dev is not None:
                 self._sim_steps_pending.append(sim_steps_dev)

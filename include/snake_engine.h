@@ -324,6 +324,19 @@ int snk_tt_set_priors_flagged(snk_tt *t, const uint32_t *d_entry, const uint8_t 
 int snk_tt_lookup_insert_dnow(snk_tt *t, const uint64_t *d_key, const uint8_t *d_active, int m,
                               const int32_t *d_now_turn, int max_age, uint32_t *d_entry, uint8_t *d_is_new,
                               void *stream);
+/* The rollout loop's bookkeeping around a tick (mp_game_runner.py:99-113), one launch each:
+ * snk_mcts_row_active: d_row_active[b * n_snakes + s] = snake s of sub-game b is alive AND the sub-game is still active
+ *   (d_alive_rows: what snk_engine_alive wrote; d_sub_active: uint8[n_subgames]).
+ * snk_mcts_retire (after snk_engine_step_active): *d_sim_steps += number of active sub-games (the ones that just moved); a
+ *   sub-game becomes inactive when its game is over (d_done, from the step) or tick >= d_sub_depth[b] (its depth cap).
+ * snk_mcts_gather_rows: out_pairs[i] = pairs[idx[i]] ((sub-game, snake), int32 x 2), out_mask[i] = mask[idx[i]] (uint8 x 3): the
+ *   rows whose observations go to the net (all_states, agent.py:172-186) out of the tick's row list. */
+int snk_mcts_gather_rows(const int32_t *d_idx, int n, const int32_t *d_pairs, const uint8_t *d_mask, int32_t *d_out_pairs,
+                         uint8_t *d_out_mask, void *stream);
+int snk_mcts_row_active(const uint8_t *d_alive_rows, const uint8_t *d_sub_active, int n_subgames, int n_snakes,
+                        uint8_t *d_row_active, void *stream);
+int snk_mcts_retire(uint8_t *d_sub_active, const uint8_t *d_done, const int32_t *d_sub_depth, int tick, int n_subgames,
+                    int64_t *d_sim_steps, void *stream);
 int snk_mcts_backup(snk_tt *t, const uint32_t *d_entry, int m, const float *d_est, const float *d_pmf,
                     uint32_t *d_path_entry, uint8_t *d_path_move, int32_t *d_path_len, int path_depth,
                     int sequential, void *stream);

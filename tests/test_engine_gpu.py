@@ -407,7 +407,7 @@ def test_compact_flags(se):
     import torch
     eng = se.Engine(1, 7, 7, 2)
     rng = np.random.RandomState(0)
-    for n in (1, 63, 2048, 2049, 70001, 1_000_003):
+    for n in (1, 63, 2048, 2049, 16383, 16384, 16385, 70001, 1_000_003):      # one launch up to 16 384 flags, three beyond
         f = (rng.rand(n) < 0.37).astype(np.uint8)
         idx, cnt = eng.compact(torch.as_tensor(f, device="cuda"))
         c = int(cnt.item())
