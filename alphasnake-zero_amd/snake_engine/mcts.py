@@ -207,6 +207,10 @@ class DeviceMCTS:
         side.wait_stream(main)
         with torch.cuda.stream(side):
             self._tick_fixed(B, m, D)
+            # nothing may be in flight when the capture begins (what torch.cuda.graph() does too): an allocation inside the
+            # capture otherwise finds cross-stream events of the eager tick still pending and queries them, which a capturing
+            # stream does not permit -- seen once, with a faster host side, as "operation not permitted when stream is capturing"
+            torch.cuda.synchronize()
             g.capture_begin()
             self._tick_fixed(B, m, D)
             g.capture_end()
