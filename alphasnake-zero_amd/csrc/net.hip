@@ -590,6 +590,7 @@ struct StemArgs {
     int raw;             // != 0 (k_stem_conv_mfma only): the bare convolution -- no scale / shift (both may be NULL), no ReLU
     const unsigned *bbox; // k_stem_conv_mfma only, or NULL: per image y0 | x0 << 8 | y1 << 16 | x1 << 24 (k_obs_bbox, conv_split.hip);
     int grow;            //   only the pixels of that box grown by `grow` (cut to the canvas) are computed and written
+    int group;           // k_stem_conv_mfma: images per iteration of a block (their padded copies sit side by side in LDS); 0 = 1
 };
 
 // 256 pixels per block; thread (pg = tid / 32, cq = tid % 32) computes outputs 4 cq .. 4 cq + 3 of pixels pg + 8 k with its
@@ -730,7 +731,7 @@ __global__ __launch_bounds__(256) void k_stem_conv_mfma(StemArgs p)
     __shared__ float s_wmax[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
     const int Hd = p.Hd, Wd = p.Wd, HW = Hd * Wd, row3 = Wd * 3, P3 = (Wd + 2) * 3;
-    const int n_img = p.M / HW, T = (HW + 31) / 32;
+    const int n_img = p.M / HW;
     // weight scale: max |w| over the 27 x 128 kernel -> 2^k with 256 <= max * 2^k < 512
     float wm = 0.f;
     for (int i = tid; i < 27 * CV_C; i += 256) wm = fmaxf(wm, fabsf(p.w[i]));
@@ -779,35 +780,54 @@ __global__ __launch_bounds__(256) void k_stem_conv_mfma(StemArgs p)
     const float floor_ = p.raw ? -__builtin_inff() : 0.f;
 
     const int n_lds = (Hd + 2) * P3;
-    for (int img = blockIdx.x; img < n_img; img += gridDim.x) {
-        const float *src = p.x + (long)img * HW * 3;
-        __syncthreads();                                       // the previous image's readers are done with the LDS image
-        for (int j = tid; j < n_lds; j += 256) {
-            const int yy = j / P3, rr = j - yy * P3;
+    // A block takes G images per iteration: one load / barrier / compute / store round per image left the wavefronts unevenly
+    // loaded (6 tiles of a 13 x 13 rectangle over 4 wavefronts) and the chain's latency exposed.  The tiles of the G images
+    // form one list; their rectangles (s_par: ry0, rx0, wr, HWr, first tile) are worked out by one thread during the load.
+    __shared__ int s_par[4][5];
+    __shared__ int s_tiles;
+    const int G = max(1, min(4, p.group));
+    for (int base = blockIdx.x * G; base < n_img; base += gridDim.x * G) {
+        const int ng = min(G, n_img - base);
+        __syncthreads();                                       // the previous images' readers are done with the LDS images
+        for (int j = tid; j < ng * n_lds; j += 256) {
+            const int g_ = j / n_lds, jj = j - g_ * n_lds;
+            const float *src = p.x + (long)(base + g_) * HW * 3;
+            const int yy = jj / P3, rr = jj - yy * P3;
             const bool inside = yy >= 1 && yy <= Hd && rr >= 3 && rr < 3 + row3;
             // observation values are bounded by construction (game.py:229-248: at most (H W + 2.5) * 0.04 = 14.6 on 19x19), so
             // 2^10 leaves 4x headroom to the f16 range; anything a caller passes beyond +-63.97 saturates instead of becoming inf
             st_img[j] = inside ? __builtin_amdgcn_fmed3f(src[(yy - 1) * row3 + rr - 3] * amul, -65504.f, 65504.f) : 0.f;
         }
+        if (tid == 0) {
+            // the GEMM rows of an image are the pixels of a rectangle of it (all of it without a bounding box)
+            int first = 0;
+            for (int g_ = 0; g_ < ng; ++g_) {
+                int ry0 = 0, rx0 = 0, wr = Wd, HWr = HW;
+                if (p.bbox) {
+                    const unsigned bb = p.bbox[base + g_];
+                    ry0 = max((int)(bb & 255) - p.grow, 0); rx0 = max((int)((bb >> 8) & 255) - p.grow, 0);
+                    wr = min((int)(bb >> 24) + p.grow, Wd - 1) - rx0 + 1;
+                    HWr = (min((int)((bb >> 16) & 255) + p.grow, Hd - 1) - ry0 + 1) * wr;
+                }
+                s_par[g_][0] = ry0; s_par[g_][1] = rx0; s_par[g_][2] = wr; s_par[g_][3] = HWr; s_par[g_][4] = first;
+                first += (HWr + 31) / 32;
+            }
+            s_tiles = first;
+        }
         __syncthreads();                                       // (prefetching the next image through registers into a second
         //                                                        buffer was measured: no change, the loads are not what it waits for)
-        float *out = p.out + (long)img * HW * CV_C;
-        _Float16 *out16 = (_Float16 *)p.out + (long)img * HW * CV_C;
-        // the GEMM rows are the pixels of a rectangle of the image (all of it without a bounding box)
-        int ry0 = 0, rx0 = 0, wr = Wd, HWr = HW, Tr = T;
-        if (p.bbox) {
-            const unsigned bb = p.bbox[img];
-            ry0 = max((int)(bb & 255) - p.grow, 0); rx0 = max((int)((bb >> 8) & 255) - p.grow, 0);
-            wr = min((int)(bb >> 24) + p.grow, Wd - 1) - rx0 + 1;
-            HWr = (min((int)((bb >> 16) & 255) + p.grow, Hd - 1) - ry0 + 1) * wr;
-            Tr = (HWr + 31) / 32;
-        }
-        const float inv_wr = 1.0f / (float)wr;
-        for (int t = wv; t < Tr; t += 4) {
+        const int n_tiles = s_tiles;
+        for (int u = wv; u < n_tiles; u += 4) {
+            int g_ = 0;
+            for (int k = 1; k < ng; ++k) if (u >= s_par[k][4]) g_ = k;
+            const int ry0 = s_par[g_][0], rx0 = s_par[g_][1], wr = s_par[g_][2], HWr = s_par[g_][3], t = u - s_par[g_][4];
+            const float inv_wr = 1.0f / (float)wr;
+            float *out = p.out + (long)(base + g_) * HW * CV_C;
+            _Float16 *out16 = (_Float16 *)p.out + (long)(base + g_) * HW * CV_C;
             const int pix = min(32 * t + l31, HWr - 1);        // rows past the image repeat its last pixel (computed, never stored)
             const int yr = (int)(((float)pix + 0.5f) * inv_wr);
             const int y = ry0 + yr, x = rx0 + pix - yr * wr;
-            const float *b = st_img + y * P3 + x * 3;
+            const float *b = st_img + g_ * n_lds + y * P3 + x * 3;
             sm_f16x8 Ah[2], Al[2];
 #pragma unroll
             for (int s_ = 0; s_ < 2; ++s_)
@@ -1049,6 +1069,18 @@ extern "C" int snk_conv3x3_bn_f32_winograd(const float *d_x, const float *d_U, c
     return 0;
 }
 
+// images a block of k_stem_conv_mfma takes per iteration (their padded float32 copies share the 64 KB of dynamic LDS), and the
+// launch that goes with it; SNK_STEM_GROUP=1 restores one image per iteration (A/B runs)
+template <bool OUT16>
+static void stem_mfma_launch(StemArgs a, int n_images, size_t lds_one, int max_grid, hipStream_t st)
+{
+    static const int group_max = getenv("SNK_STEM_GROUP") ? max(1, min(4, atoi(getenv("SNK_STEM_GROUP")))) : 4;
+    int g = (int)min((size_t)group_max, (size_t)(64 * 1024) / lds_one);
+    g = max(1, min(g, n_images));
+    a.group = g;
+    k_stem_conv_mfma<OUT16><<<min((n_images + g - 1) / g, max_grid), 256, g * lds_one, st>>>(a);
+}
+
 extern "C" int snk_stem_conv_bn_relu_f32(const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,
                                          float *d_out, int n_images, int height, int width, void *stream)
 {
@@ -1061,7 +1093,7 @@ extern "C" int snk_stem_conv_bn_relu_f32(const float *d_x, const float *d_w, con
     // default: the MFMA form on 512 persistent blocks (2 resident per CU); SNK_STEM=valu selects the packed-FMA form
     static const int stem_grid = getenv("SNK_STEM_GRID") ? atoi(getenv("SNK_STEM_GRID")) : 512;
     static const int stem_valu = getenv("SNK_STEM") ? !strcmp(getenv("SNK_STEM"), "valu") : 0;
-    if (lds <= 64 * 1024 && !stem_valu) k_stem_conv_mfma<false><<<min(n_images, stem_grid), 256, lds, (hipStream_t)stream>>>(a);
+    if (lds <= 64 * 1024 && !stem_valu) stem_mfma_launch<false>(a, n_images, lds, stem_grid, (hipStream_t)stream);
     else if (lds <= 64 * 1024) k_stem_conv_img<false><<<min(n_images, 768), 256, lds, (hipStream_t)stream>>>(a);
     else k_stem_conv<<<(int)((M + ST_PX - 1) / ST_PX), 256, 0, (hipStream_t)stream>>>(a);
     SNK_CHECK_HIP(hipGetLastError());
@@ -1081,7 +1113,7 @@ extern "C" int snk_stem_conv_bn_relu_f32_rect(const float *d_x, const float *d_w
     const size_t lds = (size_t)(height + 2) * (width + 2) * 3 * sizeof(float);
     SNK_REQUIRE(lds <= 64 * 1024 && height <= 255 && width <= 255, "snk_stem_conv_bn_relu_f32_rect: observation %d x %d too large", height, width);
     StemArgs a = {d_x, d_w, d_scale, d_shift, d_out, (int)M, height, width, 0, (const unsigned *)d_bbox, grow};
-    k_stem_conv_mfma<false><<<min(n_images, 512), 256, lds, (hipStream_t)stream>>>(a);
+    stem_mfma_launch<false>(a, n_images, lds, 512, (hipStream_t)stream);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1098,7 +1130,7 @@ extern "C" int snk_stem_conv_bn_relu_f16out_rect(const float *d_x, const float *
     const size_t lds = (size_t)(height + 2) * (width + 2) * 3 * sizeof(float);
     SNK_REQUIRE(lds <= 64 * 1024 && height <= 255 && width <= 255, "snk_stem_conv_bn_relu_f16out_rect: observation %d x %d too large", height, width);
     StemArgs a = {d_x, d_w, d_scale, d_shift, (float *)d_out16, (int)M, height, width, 0, (const unsigned *)d_bbox, grow};
-    k_stem_conv_mfma<true><<<min(n_images, 512), 256, lds, (hipStream_t)stream>>>(a);
+    stem_mfma_launch<true>(a, n_images, lds, 512, (hipStream_t)stream);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1113,7 +1145,7 @@ extern "C" int snk_stem_conv_f32(const float *d_x, const float *d_w, float *d_ou
     const size_t lds = (size_t)(height + 2) * (width + 2) * 3 * sizeof(float);
     SNK_REQUIRE(lds <= 64 * 1024, "snk_stem_conv_f32: observation %d x %d too large", height, width);
     StemArgs a = {d_x, d_w, nullptr, nullptr, d_out, (int)M, height, width, 1};
-    k_stem_conv_mfma<false><<<min(n_images, 512), 256, lds, (hipStream_t)stream>>>(a);
+    stem_mfma_launch<false>(a, n_images, lds, 512, (hipStream_t)stream);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1129,7 +1161,7 @@ extern "C" int snk_stem_conv_bn_relu_f16out(const float *d_x, const float *d_w, 
     const size_t lds = (size_t)(height + 2) * (width + 2) * 3 * sizeof(float);
     SNK_REQUIRE(lds <= 64 * 1024, "snk_stem_conv_bn_relu_f16out: observation %d x %d too large", height, width);
     StemArgs a = {d_x, d_w, d_scale, d_shift, (float *)d_out16, (int)M, height, width};
-    k_stem_conv_mfma<true><<<min(n_images, 512), 256, lds, (hipStream_t)stream>>>(a);
+    stem_mfma_launch<true>(a, n_images, lds, 512, (hipStream_t)stream);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
