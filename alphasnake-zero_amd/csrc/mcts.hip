@@ -34,12 +34,10 @@ __device__ static inline unsigned long long ld_u64(const unsigned long long *p)
 // MCTSAgent.make_moves, "get states without duplicates" (agent.py:170-186)
 // ------------------------------------------------------------------------------------------
 __global__ void k_tt_lookup_insert(snk_tt T, const unsigned long long *__restrict__ key, const uint8_t *__restrict__ active,
-                                   int m, int now, int max_age, uint32_t *__restrict__ entry, uint8_t *__restrict__ is_new,
-                                   const int *__restrict__ d_now)
+                                   int m, int now, int max_age, uint32_t *__restrict__ entry, uint8_t *__restrict__ is_new)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
-    if (d_now) now = d_now[0];            // root-turn clock kept on the device (replayed HIP graphs cannot change an argument)
     unsigned long long klo = key[2 * (size_t)i], khi = key[2 * (size_t)i + 1];
     if ((active && !active[i]) || (klo == 0ull && khi == 0ull)) { entry[i] = TT_NONE; is_new[i] = 0; return; }
     if (klo == 0ull) klo = 1ull;          // 0 is the "empty" / "unpublished" sentinel of both words
@@ -133,20 +131,6 @@ __global__ void k_tt_set_priors(snk_tt T, const uint32_t *__restrict__ entry, co
     s[3] = 1.0f; s[4] = 1.0f; s[5] = 1.0f;
 }
 
-// the same for a fixed-shape batch: row i of d_q belongs to entry[i], only rows flagged is_new are written (the graph-captured
-// small-batch tick evaluates every row and keeps the evaluations of the new keys)
-__global__ void k_tt_set_priors_flagged(snk_tt T, const uint32_t *__restrict__ entry, const uint8_t *__restrict__ is_new, int m,
-                                        const float *__restrict__ q)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m || !is_new[i]) return;
-    const uint32_t e = entry[i];
-    if (e == TT_NONE) return;
-    float *s = &T.stat[(size_t)e * 8];
-    s[0] = q[3 * (size_t)i]; s[1] = q[3 * (size_t)i + 1]; s[2] = q[3 * (size_t)i + 2];
-    s[3] = 1.0f; s[4] = 1.0f; s[5] = 1.0f;
-}
-
 // ------------------------------------------------------------------------------------------
 // Agent.softermax (agent.py:114-122) and numpy.random.choice([0,1,2], p=pmf) (agent.py:91, 205)
 // ------------------------------------------------------------------------------------------
@@ -201,11 +185,10 @@ struct PathBufs {
 __global__ void k_mcts_select(snk_tt T, const uint32_t *__restrict__ entry, int m, float base, const double *__restrict__ tape,
                               const int32_t *__restrict__ rank, long tape_base, uint32_t seed_lo, uint32_t seed_hi,
                               uint32_t ctr0, uint32_t ctr1, uint8_t *__restrict__ moves, float *__restrict__ est,
-                              float *__restrict__ pmf_out, PathBufs P, const uint32_t *__restrict__ d_ctr)
+                              float *__restrict__ pmf_out, PathBufs P)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
-    if (d_ctr) { ctr0 = d_ctr[0]; ctr1 = d_ctr[1]; }     // draw counter kept on the device (a replayed HIP graph cannot change an argument)
     const uint32_t e = entry[i];
     if (e == TT_NONE) { moves[i] = 1; if (est) est[i] = 0.f; return; }
     const float *s = &T.stat[(size_t)e * 8];
@@ -454,18 +437,7 @@ extern "C" int snk_tt_lookup_insert(snk_tt *t, const uint64_t *d_key, const uint
     SNK_REQUIRE(t && d_key && d_entry && d_is_new, "snk_tt_lookup_insert: NULL argument");
     if (m <= 0) return 0;
     k_tt_lookup_insert<<<(m + 255) / 256, 256, 0, (hipStream_t)stream>>>(*t, (const unsigned long long *)d_key, d_active, m, now_turn,
-                                                                         max_age, d_entry, d_is_new, nullptr);
-    SNK_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
-extern "C" int snk_tt_lookup_insert_dnow(snk_tt *t, const uint64_t *d_key, const uint8_t *d_active, int m, const int32_t *d_now_turn,
-                                         int max_age, uint32_t *d_entry, uint8_t *d_is_new, void *stream)
-{
-    SNK_REQUIRE(t && d_key && d_entry && d_is_new && d_now_turn, "snk_tt_lookup_insert_dnow: NULL argument");
-    if (m <= 0) return 0;
-    k_tt_lookup_insert<<<(m + 255) / 256, 256, 0, (hipStream_t)stream>>>(*t, (const unsigned long long *)d_key, d_active, m, 0,
-                                                                         max_age, d_entry, d_is_new, d_now_turn);
+                                                                         max_age, d_entry, d_is_new);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -500,30 +472,7 @@ extern "C" int snk_mcts_select(snk_tt *t, const uint32_t *d_entry, int m, float 
     PathBufs P = {d_path_entry, d_path_move, d_path_len, path_depth};
     k_mcts_select<<<(m + 255) / 256, 256, 0, (hipStream_t)stream>>>(*t, d_entry, m, softmax_base, d_tape_u, d_rank, (long)tape_base,
                                                                     (uint32_t)seed, (uint32_t)(seed >> 32), ctr0, ctr1, d_moves, d_est,
-                                                                    d_pmf, P, nullptr);
-    SNK_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
-extern "C" int snk_mcts_select_dctr(snk_tt *t, const uint32_t *d_entry, int m, float softmax_base, uint64_t seed,
-                                    const uint32_t *d_ctr, uint8_t *d_moves, float *d_est, float *d_pmf, uint32_t *d_path_entry,
-                                    uint8_t *d_path_move, int32_t *d_path_len, int path_depth, void *stream)
-{
-    SNK_REQUIRE(t && d_entry && d_moves && d_path_entry && d_path_move && d_path_len && d_ctr, "snk_mcts_select_dctr: NULL argument");
-    if (m <= 0) return 0;
-    PathBufs P = {d_path_entry, d_path_move, d_path_len, path_depth};
-    k_mcts_select<<<(m + 255) / 256, 256, 0, (hipStream_t)stream>>>(*t, d_entry, m, softmax_base, nullptr, nullptr, 0l, (uint32_t)seed,
-                                                                    (uint32_t)(seed >> 32), 0u, 0u, d_moves, d_est, d_pmf, P, d_ctr);
-    SNK_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
-extern "C" int snk_tt_set_priors_flagged(snk_tt *t, const uint32_t *d_entry, const uint8_t *d_is_new, int m, const float *d_q,
-                                         void *stream)
-{
-    SNK_REQUIRE(t && d_entry && d_is_new && d_q, "snk_tt_set_priors_flagged: NULL argument");
-    if (m <= 0) return 0;
-    k_tt_set_priors_flagged<<<(m + 255) / 256, 256, 0, (hipStream_t)stream>>>(*t, d_entry, d_is_new, m, d_q);
+                                                                    d_pmf, P);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }

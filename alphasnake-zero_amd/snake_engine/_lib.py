@@ -81,9 +81,6 @@ PROTOTYPES = {
     "snk_tt_set_priors": (i32, [vp, vp, vp, i32, vp, vp]),
     "snk_tt_read_q": (i32, [vp, vp, i32, i32, vp, vp]),
     "snk_mcts_select": (i32, [vp, vp, i32, C.c_float, vp, vp, C.c_int64, u64, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, i32, vp]),
-    "snk_mcts_select_dctr": (i32, [vp, vp, i32, C.c_float, u64, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
-    "snk_tt_set_priors_flagged": (i32, [vp, vp, vp, i32, vp, vp]),
-    "snk_tt_lookup_insert_dnow": (i32, [vp, vp, vp, i32, vp, i32, vp, vp, vp]),
     "snk_mcts_gather_rows": (i32, [vp, i32, vp, vp, vp, vp, vp]),
     "snk_mcts_row_active": (i32, [vp, vp, i32, i32, vp, vp]),
     "snk_mcts_retire": (i32, [vp, vp, vp, i32, i32, vp, vp]),

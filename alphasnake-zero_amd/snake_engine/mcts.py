@@ -5,7 +5,6 @@ for buffers, index plumbing (gather / cumsum) and the single host read-back per 
 number of cache misses, which sizes the net batch).
 """
 import ctypes as C
-import os
 from time import time
 
 import numpy as np
@@ -15,16 +14,6 @@ from ._lib import lib, check, EngineError
 from .engine import Engine, _ptr, _stream
 
 PARALLEL = 8     # agent.py:32
-# Optional fixed-shape rollout tick for batches of at most this many rows (sub-games x snakes): every row is observed and
-# evaluated (no compaction, no device-to-host count), so the tick is a fixed launch sequence that is captured once in a HIP
-# graph and replayed, with the clock, the draw counter and the active flags in device memory.  OFF by default (0): measured
-# on MI355X it loses to the compacted tick at every size tried (8 games / 256 rows: 419 vs 609 env-steps/s; 32 games / 1024
-# rows: 254 vs 570) -- the cache de-duplication leaves only 20-40 % of the rows to evaluate, and a small batch's forward is
-# bound by the duration of one convolution block per layer (~50 us), not by launches: the GPU is busy 70-85 % of the wall
-# time in the eager small run already (profiles/r2_small_config_kernel_stats.csv).  Kept as an option and as the test bed
-# of the graph-replayable entry points (snk_mcts_select_dctr, snk_tt_lookup_insert_dnow, snk_tt_set_priors_flagged).
-GRAPH_ROWS = int(os.environ.get("SNK_GRAPH_ROWS", "0"))
-
 
 def _pow2_at_least(v):
     p = 1024
@@ -71,7 +60,7 @@ class TranspositionTable:
 class DeviceMCTS:
     def __init__(self, evaluate, height, width, snake_cnt, softmax_base=100, training=False, max_depth=8,
                  max_breadth=128, seed=1234, device=None, sequential=False, tape_u=None, tt_capacity=None,
-                 legacy_mask=False, graph_ticks=None):
+                 legacy_mask=False):
         """evaluate(planes[n,h,w,3] cuda f32, mask[n,3] cuda u8) -> cuda f32 [n,3]  (= AlphaNNet.v)"""
         if not torch.cuda.is_available():
             raise EngineError("DeviceMCTS needs an MI355X; there is no CPU fallback")
@@ -95,16 +84,8 @@ class DeviceMCTS:
         self.roll = None                  # rollout engine (sub-games; food_spawn_chance 0, game.py:268)
         self._bufs_B = -1
         self.verbose = False              # print the reference's per-epoch line (agent.py:57-58)
-        # fixed-shape / graph-captured tick for small batches: needs an evaluate() made of stream-ordered device work only
-        # (AlphaNNet.v_device is; a net that goes through the host is not).  None = decide per call from `graph_safe`.
-        self.graph_ticks = graph_ticks
-        self.graph_safe = False           # set by the owner (utils.agent.Agent) when evaluate() never touches the host
-        self._graph = None                # (graph, key): the captured tick and everything its launches have baked in
-        self._side = None
-        self.stats = dict(net_evals=0, rollout_ticks=0, sim_steps=0, lookups=0, graph_replays=0, graph_captures=0)
+        self.stats = dict(net_evals=0, rollout_ticks=0, sim_steps=0, lookups=0)
         self._sim_steps_pending = []      # device counters of the sub-game tics, folded into stats at the turn's end
-        self._evals_pending = []
-        self.graph_capture = os.environ.get("SNK_GRAPH_CAPTURE", "1") != "0"     # 0: fixed-shape tick launched eagerly
 
     # ---- buffers -------------------------------------------------------------------------------
     def _ensure(self, G, health_dec):
@@ -145,15 +126,6 @@ class DeviceMCTS:
             self.cmp_cnt = torch.empty((1,), dtype=torch.int32, device=dev)
             self.cmp_scratch = torch.empty((self.L.snk_compact_scratch_elems(m),), dtype=torch.int32, device=dev)
             self.planes = None
-            # persistent state of the fixed-shape tick (a replayed graph reads and writes the same addresses)
-            self.sub_active = torch.ones((B,), dtype=torch.bool, device=dev)
-            self.sub_depth = torch.zeros((B,), dtype=torch.int32, device=dev)
-            self.tick_dev = torch.zeros((), dtype=torch.int32, device=dev)
-            self.ctr_dev = torch.zeros((1,), dtype=torch.int64, device=dev)       # Philox counter: uint32[2] to the kernel
-            self.now_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
-            self.evals_dev = torch.zeros((), dtype=torch.int64, device=dev)
-            self.sims_dev = torch.zeros((), dtype=torch.int64, device=dev)
-            self._graph = None
             self._bufs_B = B
         return par, B
 
@@ -166,56 +138,6 @@ class DeviceMCTS:
     def _next_ctr(self):
         self.draw_ctr += 1
         return self.draw_ctr & 0xFFFFFFFF, (self.draw_ctr >> 32) & 0xFFFFFFFF
-
-    # ---- the fixed-shape rollout tick (small batches) ------------------------------------------------
-    def _tick_fixed(self, B, m, D):
-        """One rollout tick (agent.py:161-223 + mp_game_runner.py:99-113) as a fixed sequence of launches over all m rows:
-        state that changes from tick to tick (active flags, tick number, draw counter, statistics) lives in device
-        tensors that are updated in place, so the same sequence can be replayed from a HIP graph."""
-        L, st, tt = self.L, _stream(), self.tt.h
-        self.roll.alive(n=B, out=self.alive_rows)
-        row_active = (self.alive_rows.bool() & self.sub_active[:, None]).reshape(-1).to(torch.uint8)
-        planes = self.planes[:m]
-        self.roll.observe(self.pairs, m, planes, self.mask, self.key, legacy_mask=self.legacy_mask)
-        check(L.snk_tt_lookup_insert_dnow(tt, _ptr(self.key), _ptr(row_active), m, _ptr(self.now_dev), self.max_depth,
-                                          _ptr(self.entry), _ptr(self.is_new), st))
-        q = self.evaluate(planes, self.mask).contiguous()            # every row; only the new keys keep their evaluation
-        check(L.snk_tt_set_priors_flagged(tt, _ptr(self.entry), _ptr(self.is_new), m, _ptr(q), st))
-        self.evals_dev += self.is_new.sum(dtype=torch.int64)
-        check(L.snk_mcts_select_dctr(tt, _ptr(self.entry), m, self.base, self.seed, _ptr(self.ctr_dev), _ptr(self.moves),
-                                     _ptr(self.est), _ptr(self.pmf), _ptr(self.path_entry), _ptr(self.path_move),
-                                     _ptr(self.path_len), D, st))
-        self.ctr_dev += 1
-        check(L.snk_mcts_backup(tt, _ptr(self.entry), m, _ptr(self.est), _ptr(self.pmf), _ptr(self.path_entry),
-                                _ptr(self.path_move), _ptr(self.path_len), D, 0, st))
-        act_u8 = self.sub_active.to(torch.uint8)
-        self.roll.step_active(act_u8, self.moves, B, done=self.done)
-        self.sims_dev += act_u8.sum(dtype=torch.int64)
-        self.tick_dev += 1
-        self.sub_active &= ~(self.done.bool() | (self.sub_depth <= self.tick_dev))      # mp_game_runner.py:108-113
-
-    def _capture_tick(self, B, m, D):
-        """captures _tick_fixed in a HIP graph (torch.cuda.CUDAGraph: every launch of the tick, ours and torch's, goes to
-        the capturing stream).  Everything that changes between ticks and between root turns is device state (clock,
-        draw counter, tick number, active flags), so the graph is replayed until the batch shape or the table's buffers
-        change.  The tick is run once eagerly on the side stream first (allocations, lazy initialisation), as capture
-        requires -- on real state: it IS a tick of the search."""
-        g = torch.cuda.CUDAGraph()
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        side, main = self._side, torch.cuda.current_stream()
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            self._tick_fixed(B, m, D)
-            # nothing may be in flight when the capture begins (what torch.cuda.graph() does too): an allocation inside the
-            # capture otherwise finds cross-stream events of the eager tick still pending and queries them, which a capturing
-            # stream does not permit -- seen once, with a faster host side, as "operation not permitted when stream is capturing"
-            torch.cuda.synchronize()
-            g.capture_begin()
-            self._tick_fixed(B, m, D)
-            g.capture_end()
-        main.wait_stream(side)
-        return g
 
     def clear(self):
         """Agent.clear (agent.py:140-147)"""
@@ -240,45 +162,14 @@ class DeviceMCTS:
         epochs = self.max_breadth // par                        # agent.py:37
         tt = self.tt.h
         seq = int(self.sequential)
-        # small batches: fixed-shape tick, captured in a HIP graph for this root turn (see GRAPH_ROWS)
-        fixed = (0 < m <= GRAPH_ROWS and self.tape is None and not self.sequential
-                 and (self.graph_safe if self.graph_ticks is None else self.graph_ticks))
-        if fixed:
-            self.sub_depth.copy_(sub_depth)
-            self.ctr_dev.fill_(self.draw_ctr + 1)               # the counter the next eager draw would use
-            self.evals_dev.zero_(); self.sims_dev.zero_()
-            self.now_dev.fill_(self.now)
-            self._planes(m)
-            n_replayed = 0
-            key = (B, id(self.tt), self.tt.generation, self.planes.data_ptr(), id(self.roll), root.health_dec, self.base)
-            graph = self._graph[0] if self._graph is not None and self._graph[1] == key else None
-            if graph is None:
-                self._graph = None
         for ep in range(epochs):
             t_epoch = time()
             root.clone_to(self.roll, src_slots=live_slots, n=G, fanout=par)       # game.subgame (agent.py:46-50)
             self.path_len.zero_()
-            if fixed:
-                self.sub_active.fill_(True)
-                self.tick_dev.zero_()
-                for tick in range(1, n_ticks + 1):
-                    if graph is not None:
-                        graph.replay()
-                        self.stats["graph_replays"] += 1
-                    elif self.graph_capture and n_ticks * epochs >= 4:
-                        graph = self._capture_tick(B, m, D)     # runs this tick eagerly (warm-up), then records the graph
-                        self._graph = (graph, key)
-                        self.stats["graph_captures"] += 1
-                    else:
-                        self._tick_fixed(B, m, D)
-                    n_replayed += 1
-                    self.stats["rollout_ticks"] += 1
-                sim_steps_dev = None
-            else:
-                sub_active = torch.ones((B,), dtype=torch.uint8, device=self.device)
-                sim_steps_dev = torch.zeros((), dtype=torch.int64, device=self.device)
-                row_active = self.row_active
-            for tick in (range(1, n_ticks + 1) if not fixed else ()):
+            sub_active = torch.ones((B,), dtype=torch.uint8, device=self.device)
+            sim_steps_dev = torch.zeros((), dtype=torch.int64, device=self.device)
+            row_active = self.row_active
+            for tick in range(1, n_ticks + 1):
                 self.roll.alive(n=B, out=self.alive_rows)
                 check(L.snk_mcts_row_active(_ptr(self.alive_rows), _ptr(sub_active), B, S, _ptr(row_active), st))
                 self.roll.observe(self.pairs, m, None, self.mask, self.key, legacy_mask=self.legacy_mask)
@@ -314,8 +205,7 @@ class DeviceMCTS:
                 # (mp_game_runner.py:108-113): one launch (this was a chain of eight tensor expressions)
                 check(L.snk_mcts_retire(_ptr(sub_active), _ptr(self.done), _ptr(sub_depth_i32), tick, B, _ptr(sim_steps_dev), st))
                 self.stats["rollout_ticks"] += 1
-            if sim_steps_dev is not None:
-                self._sim_steps_pending.append(sim_steps_dev)
+            self._sim_steps_pending.append(sim_steps_dev)
             check(L.snk_engine_rewards(self.roll.h, None, B, _ptr(self.rewards), st))
             check(L.snk_mcts_terminal_backup(tt, _ptr(self.rewards), m, _ptr(self.path_entry), _ptr(self.path_move),
                                              _ptr(self.path_len), D, seq, st))   # agent.py:60-72
@@ -330,12 +220,6 @@ class DeviceMCTS:
                 if occ * 2 > cap:
                     self.tt.rebuild(cap * 2, self.now, 1 << 30)
                     tt = self.tt.h
-                    graph, self._graph = None, None              # the captured launches point into the old table
-                    key = (B, id(self.tt), self.tt.generation, self.planes.data_ptr(), id(self.roll), root.health_dec, self.base)
-        if fixed:
-            self.draw_ctr += n_replayed                          # the draws the ticks consumed
-            self._sim_steps_pending.append(self.sims_dev.clone())
-            self._evals_pending.append(self.evals_dev.clone())
         # V[i] = cached_values[first_key] (agent.py:74-87): the root observation's entry, from clone 0 of each game
         first = self.path_entry.view(G, par, S, D)[:, 0, :, 0].contiguous().reshape(-1)
         root_rows_alive = root_alive.reshape(-1).contiguous()
@@ -362,9 +246,6 @@ class DeviceMCTS:
         if self._sim_steps_pending:
             self.stats["sim_steps"] += int(torch.stack(self._sim_steps_pending).sum().item())
             self._sim_steps_pending = []
-        if self._evals_pending:
-            self.stats["net_evals"] += int(torch.stack(self._evals_pending).sum().item())
-            self._evals_pending = []
         if ovf:
             raise EngineError("transposition table overflowed; raise tt_capacity")
         if occ * 2 > cap:

@@ -273,10 +273,6 @@ class QNet:
 
     # ---- forward -------------------------------------------------------------------------------
     def _workspace(self, n, k=0):
-        if torch.cuda.is_current_stream_capturing():
-            # inside a HIP-graph capture the activations come from the graph's own memory pool: they stay valid for as long
-            # as the graph is replayed, whatever later (larger) eager forwards do to the cached workspaces
-            return [torch.empty((n, self.h, self.w, 128), dtype=torch.float32, device=self.device) for _ in range(3)]
         if self._ws is None:
             self._ws = {}
         if k not in self._ws or self._ws[k][0].shape[0] < n:
@@ -323,13 +319,11 @@ class QNet:
         key = ("a16", k)
         if self._ws is None:
             self._ws = {}
-        if torch.cuda.is_current_stream_capturing() or key not in self._ws or self._ws[key][0].shape[0] < m:
+        if key not in self._ws or self._ws[key][0].shape[0] < m:
             bufs = [torch.empty((m, h, w, 128), dtype=torch.float16, device=self.device) for _ in range(3)]
             bufs.append(torch.empty((m, h, w, 128), dtype=torch.float32, device=self.device))
-            if not torch.cuda.is_current_stream_capturing():
-                self._ws[key] = bufs
-        else:
-            bufs = self._ws[key]
+            self._ws[key] = bufs
+        bufs = self._ws[key]
         a, b, c, last = bufs
         x = planes[s0:s0 + m]
         plan = self._rect_plan(x, m, k, st) if self._use_rect(m) else None
@@ -407,8 +401,6 @@ class QNet:
                              0 if mk is None else mk.data_ptr(), out[s0:s0 + m].data_ptr(), m, h, w, st))
 
     def _h1_workspace(self, n, k=0):
-        if torch.cuda.is_current_stream_capturing():
-            return torch.empty((n, self.h * self.w), dtype=torch.float32, device=self.device)
         key = ("h1", k)
         if key not in self._ws or self._ws[key].shape[0] < n:
             self._ws[key] = torch.empty((n, self.h * self.w), dtype=torch.float32, device=self.device)
@@ -461,8 +453,7 @@ class QNet:
                 None if res is None else bg[i - 1].data_ptr(), i, bg[1 + i].data_ptr() if self.rect_fill[i] else None)
 
     def _use_rect(self, m):
-        # not inside a HIP-graph capture: the plan's buffers and the lazily made backgrounds belong to the eager path
-        return self.n_rect > 0 and m >= self.rect_min and not torch.cuda.is_current_stream_capturing()
+        return self.n_rect > 0 and m >= self.rect_min
 
     def _rect_plan(self, x, m, k, st):
         """descriptors of this chunk's sub-rectangle layers: (descriptor tensor [n_rect][max_blocks][4], counts [n_rect][2])"""
@@ -471,16 +462,14 @@ class QNet:
         if mb < 0:
             raise EngineError(f"sub-rectangle convolution: shape {m} x {self.h} x {self.w} not supported")
         key = ("rect", k)
-        capturing = torch.cuda.is_current_stream_capturing()
-        ws = None if capturing or self._ws is None else self._ws.get(key)
+        ws = None if self._ws is None else self._ws.get(key)
         if ws is None or ws[0].shape[0] != self.n_rect or ws[0].shape[1] < mb or ws[2].shape[0] < m:
             ws = (torch.empty((self.n_rect, mb, 4), dtype=torch.int32, device=self.device),
                   torch.zeros((self.n_rect, 2), dtype=torch.int32, device=self.device),
                   torch.empty((m,), dtype=torch.int32, device=self.device))
-            if not capturing:
-                if self._ws is None:
-                    self._ws = {}
-                self._ws[key] = ws
+            if self._ws is None:
+                self._ws = {}
+            self._ws[key] = ws
         desc, counts, bbox = ws
         if self.rect_tiles is not None:          # bench.py: what the launches really executed
             counts = torch.zeros((self.n_rect, 2), dtype=torch.int32, device=self.device)

@@ -230,9 +230,6 @@ class Agent:
                                     self.max_MCTS_depth, self.max_MCTS_breadth, seed=self._seed,
                                     device=eng.device.index, sequential=self._sequential, tape_u=self._tape_u,
                                     tt_capacity=self._tt_capacity)
-        # small rollout batches run as a replayed HIP graph when the net's evaluation is pure stream-ordered device work
-        qn = getattr(self.nnet, "_qnet", None)
-        self._mcts.graph_safe = bool(getattr(self.nnet, "graph_safe", False)) and getattr(qn, "conv_timing", None) is None
         if self.verbose is None:
             from utils.mp_game_runner import MPGameRunner
             self._mcts.verbose = bool(MPGameRunner.verbose)

@@ -47,8 +47,6 @@ class _VNet:
 
 
 class AlphaNNet:
-    graph_safe = True      # v_device is stream-ordered device work only: the MCTS may capture it in a HIP graph
-
     def __init__(self, model_name=None, input_shape=None, _weights=None, blocks=4):
         self.learning_rate = None
         self.lr_schedule = None

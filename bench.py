@@ -267,8 +267,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=4, help="residual blocks of the Q-net")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-conv-timing", action="store_true",
-                    help="no HIP events around the conv launches (roofline.achieved is then null): lets small runs "
-                         "(games x 8 x snakes <= SNK_GRAPH_ROWS rows) replay their rollout ticks from HIP graphs")
+                    help="no HIP events around the conv launches (roofline.achieved is then null): for small, launch-bound runs")
     ap.add_argument("--no-kernel-rooflines", action="store_true")
     args = ap.parse_args()
 
@@ -445,8 +444,7 @@ def main():
                        "games_per_gpu": args.games, "breadth": args.breadth, "parallelism": f"games sharded x{world}", "dist_backend": backend if world > 1 else None,
                        "games_total": args.games * world,
                        "net_evals_per_env_step": evals / max(1, env_steps_rank0), "sim_steps_per_env_step": sims / max(1, env_steps_rank0),
-                       "net_evals_per_s_rank0": evals / dt, "sample_rows_gathered": int(Xg.shape[0]),
-                       "graph_replays": m.stats.get("graph_replays", 0)},
+                       "net_evals_per_s_rank0": evals / dt, "sample_rows_gathered": int(Xg.shape[0])},
             "roofline": {"bound": "mfma",
                          "kernel": {"winograd": "k_conv3x3_wino_f32", "bf16": "k_conv3x3_bf16",
                                     "f16s": "k_conv3x3_f16s" + (" + k_conv3x3_f16s_rect (the same body on sub-rectangles)" if rect else ""),

@@ -311,19 +311,6 @@ int snk_mcts_select(snk_tt *t, const uint32_t *d_entry, int m, float softmax_bas
                     const int32_t *d_rank, int64_t tape_base, uint64_t seed, uint32_t ctr0, uint32_t ctr1,
                     uint8_t *d_moves, float *d_est, float *d_pmf, uint32_t *d_path_entry,
                     uint8_t *d_path_move, int32_t *d_path_len, int path_depth, void *stream);
-/* The two entry points the fixed-shape rollout tick uses so that it can be captured once in a HIP graph and replayed
- * (snake_engine/mcts.py, batches of at most SNK_GRAPH_ROWS rows): the Philox draw counter is read from device memory
- * (uint32[2], advanced by the caller inside the graph) instead of being a launch argument, and the priors are written
- * for the rows flagged d_is_new of a batch in which EVERY row was evaluated (no compaction, no device-to-host count). */
-int snk_mcts_select_dctr(snk_tt *t, const uint32_t *d_entry, int m, float softmax_base, uint64_t seed,
-                         const uint32_t *d_ctr, uint8_t *d_moves, float *d_est, float *d_pmf, uint32_t *d_path_entry,
-                         uint8_t *d_path_move, int32_t *d_path_len, int path_depth, void *stream);
-int snk_tt_set_priors_flagged(snk_tt *t, const uint32_t *d_entry, const uint8_t *d_is_new, int m, const float *d_q,
-                              void *stream);
-/* snk_tt_lookup_insert with the root-turn clock read from device memory (int32[1]): the third graph-replayable entry */
-int snk_tt_lookup_insert_dnow(snk_tt *t, const uint64_t *d_key, const uint8_t *d_active, int m,
-                              const int32_t *d_now_turn, int max_age, uint32_t *d_entry, uint8_t *d_is_new,
-                              void *stream);
 /* The rollout loop's bookkeeping around a tick (mp_game_runner.py:99-113), one launch each:
  * snk_mcts_row_active: d_row_active[b * n_snakes + s] = snake s of sub-game b is alive AND the sub-game is still active
  *   (d_alive_rows: what snk_engine_alive wrote; d_sub_active: uint8[n_subgames]).

@@ -49,6 +49,5 @@ def stub_q_device(planes, mask):
 
 
 class DeviceStubNNet:
-    graph_safe = True      # torch ops on the current stream only
     def v_device(self, planes, mask):
         return stub_q_device(planes, mask)

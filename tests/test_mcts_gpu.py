@@ -482,62 +482,6 @@ def test_cache_views_are_dict_like(env):
     assert len(alice.cached_values) == 0 and alice.records is not None
 
 
-def test_graph_captured_tick_equals_the_eager_ticks(env, monkeypatch):
-    """small rollout batches: the fixed-shape tick replayed from a HIP graph, the same tick launched eagerly, and the
-    compacted tick of the large-batch path draw the same Philox numbers and evaluate the same new keys -> same root moves,
-    same evaluation counts, root Q equal to float32 summation order"""
-    torch, se = env
-    from snake_engine.mcts import DeviceMCTS
-    from stubnet_device import stub_q_device
-
-    import snake_engine.mcts as mcts_mod
-    monkeypatch.setattr(mcts_mod, "GRAPH_ROWS", 1024)
-
-    def mk(graph_ticks, capture):
-        def f():
-            m = DeviceMCTS(stub_q_device, 11, 11, 4, 2, True, 8, 24, seed=77, graph_ticks=graph_ticks)
-            m.graph_capture = capture
-            made.append(m)
-            return m
-        return f
-    made = []
-    VA, VB, MA, MB = _paired_search(se, torch, 8, 5, 24, mk(True, True), mk(False, False), seed=31)
-    g, e = made
-    # one capture per batch shape (a root game that ends shrinks the batch), every other tick is a replay
-    assert 1 <= g.stats["graph_captures"] <= 5 and g.stats["graph_replays"] > 5 * 10 and e.stats["graph_replays"] == 0
-    assert g.stats["graph_captures"] + g.stats["graph_replays"] == g.stats["rollout_ticks"]
-    g.end_of_turn(); e.end_of_turn()
-    assert g.stats["net_evals"] == e.stats["net_evals"] and g.stats["sim_steps"] == e.stats["sim_steps"]
-    assert g.stats["rollout_ticks"] == e.stats["rollout_ticks"] and g.draw_ctr == e.draw_ctr
-    assert np.array_equal(MA, MB)
-    assert np.abs(VA - VB).max() <= 2e-6, np.abs(VA - VB).max()
-    made.clear()
-    VA2, VC, MA2, MC = _paired_search(se, torch, 8, 5, 24, mk(True, True), mk(True, False), seed=31)
-    assert np.array_equal(MA2, MC) and np.abs(VA2 - VC).max() <= 2e-6 and np.array_equal(MA2, MA)
-    assert made[1].stats["graph_captures"] == 0
-
-
-def test_small_self_play_runs_on_graphs_with_the_real_net(env, monkeypatch):
-    """BASELINE configs[0]-sized run through the drop-in classes with the MFMA Q-net: the rollout ticks are graph replays"""
-    torch, se = env
-    from snake_engine import net
-    from utils.agent import Agent
-    from utils.alpha_nnet import AlphaNNet
-    from utils.mp_game_runner import MPGameRunner
-    import snake_engine.mcts as mcts_mod
-    MPGameRunner.verbose = False
-    monkeypatch.setattr(mcts_mod, "GRAPH_ROWS", 1024)         # the graph tick is opt-in (SNK_GRAPH_ROWS)
-    nn_ = AlphaNNet(input_shape=(21, 21, 3), _weights=net.glorot_uniform_weights((21, 21, 3), 4, seed=0))
-    alice = Agent(nn_, 2, True, 8, 25, seed=5)
-    gr = MPGameRunner(11, 11, 4, 1, 8, seed=6)
-    gr.run(alice, max_turns=3)
-    st = alice._mcts.stats
-    assert gr.env_steps == 24 and 1 <= st["graph_captures"] <= 3 and st["graph_replays"] >= 3 * 3 * 4 - 3
-    assert st["net_evals"] > 24 * 20 and 80 <= len(alice.records) <= 96
-    v = np.array(alice.values[:80])
-    assert np.isfinite(v).all() and (np.abs(v) <= 1).all()
-
-
 def test_sequential_mode_tracks_the_c_restatement_on_unrecorded_configurations():
     """beyond the five recorded reference runs: 40 random configurations (7x7 .. 13x13, 2-4 snakes, three health decrements,
     breadth 8-24, depth 4-8, four softmax bases, fresh uniform tapes) played on the device in sequential mode and on
