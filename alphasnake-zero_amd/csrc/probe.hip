@@ -5,6 +5,7 @@
 // time, and reads both again.  No vector work, no memory traffic besides its two result words: the measured kernels are
 // not touched (the guide's rule: no stamp executes inside the real kernel).
 #include "common.h"
+#include <string.h>
 
 __global__ __launch_bounds__(64) void k_clock_probe(unsigned long long *__restrict__ out, unsigned ticks)
 {
@@ -28,4 +29,17 @@ extern "C" int snk_clock_probe(uint64_t *d_out, int microseconds, void *stream)
     k_clock_probe<<<1, 64, 0, (hipStream_t)stream>>>((unsigned long long *)d_out, (unsigned)microseconds * 100u);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+// sha-256 (hex) of a kernel source file as it was when this library was built ("conv_split.hip", "engine.hip", "common.h", ...),
+// NULL for a name the library does not know.  profiles/*.json name the hashes of the sources they were measured on.
+extern "C" const char *snk_source_hash(const char *source_file)
+{
+    static const struct { const char *name, *sha256; } ids[] = {
+#include "build_id.h"
+    };
+    if (!source_file) return nullptr;
+    for (const auto &e : ids)
+        if (!strcmp(e.name, source_file)) return e.sha256;
+    return nullptr;
 }

@@ -34,6 +34,7 @@ vp, i32, u64, f64 = C.c_void_p, C.c_int, C.c_uint64, C.c_double
 PROTOTYPES = {
     "snk_last_error": (C.c_char_p, []),
     "snk_version": (i32, []),
+    "snk_source_hash": (C.c_char_p, [C.c_char_p]),
     "snk_engine_create": (i32, [C.POINTER(vp), i32, i32, i32, i32, i32, f64, u64, i32]),
     "snk_engine_destroy": (i32, [vp]),
     "snk_engine_info": (i32, [vp] + [C.POINTER(i32)] * 5),

@@ -447,6 +447,10 @@ int snk_l2_sum(const float *d_w, const uint8_t *d_decay, long n, double scale, f
  * (s_memtime) and d_out[1] = ticks of the constant 100 MHz counter (s_memrealtime) that passed meanwhile: launched on its
  * own stream beside the measured kernels it gives the clock the chip holds under their load, cycles / ticks x 100 MHz. */
 int snk_clock_probe(uint64_t *d_out, int microseconds, void *stream);
+/* sha-256 (64 hex digits) of a kernel source file of alphasnake-zero_amd/csrc/ ("conv_split.hip", "engine.hip", "common.h", ...)
+ * as it was when the library was built; NULL for an unknown name.  The counter measurements kept under profiles/ carry the
+ * hashes of the sources they were taken on; bench.py quotes them only when the loaded library carries the same ones. */
+const char *snk_source_hash(const char *source_file);
 
 #ifdef __cplusplus
 }

@@ -35,8 +35,11 @@ def obs_key_lo(planes):
     return torch.where(live, x, torch.zeros_like(x)).sum(dim=1)
 
 
-def stub_q_device(planes, mask):
-    """the evaluate(planes, mask) callable DeviceMCTS expects: stub_q with the engine's obstacle mask applied"""
+def stub_q_device(planes, mask, chunk=131072):
+    """the evaluate(planes, mask) callable DeviceMCTS expects: stub_q with the engine's obstacle mask applied
+    (in chunks: the int64 temporaries of a million-row batch at BASELINE configs[2] would take tens of GB)"""
+    if planes.shape[0] > chunk:
+        return torch.cat([stub_q_device(planes[i:i + chunk], mask[i:i + chunk], chunk) for i in range(0, planes.shape[0], chunk)])
     klo = obs_key_lo(planes)
     cols = []
     for m in range(3):
