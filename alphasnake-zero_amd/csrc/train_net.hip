@@ -60,9 +60,11 @@ __global__ __launch_bounds__(TN_THREADS) void k_bn_sums_c(const float *__restric
 }
 
 // sums[0..C-1] = sum (y - center), sums[C..2C-1] = sum (y - center)^2 over `count` values per channel (all ranks)
-__global__ void k_bn_finalize(const double *__restrict__ sums, double count, const float *__restrict__ center,
-                              const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ mov_mean,
-                              float *__restrict__ mov_var, double momentum, double eps, float *__restrict__ mean_out,
+// `center` and `mov_mean` are NOT restrict-qualified: train_step.py passes the moving mean for both (the sums are taken about it
+// and it is updated in place); every thread reads its centre before it writes its moving mean
+__global__ void k_bn_finalize(const double *__restrict__ sums, double count, const float *center,
+                              const float *__restrict__ gamma, const float *__restrict__ beta, float *mov_mean,
+                              float *mov_var, double momentum, double eps, float *__restrict__ mean_out,
                               float *__restrict__ inv_out, float *__restrict__ scale_out, float *__restrict__ shift_out, int C)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;

@@ -34,6 +34,9 @@ vp, i32, u64, f64 = C.c_void_p, C.c_int, C.c_uint64, C.c_double
 PROTOTYPES = {
     "snk_last_error": (C.c_char_p, []),
     "snk_version": (i32, []),
+    "snk_guard_word_create": (i32, [C.POINTER(vp), C.POINTER(vp)]),
+    "snk_guard_word_destroy": (i32, [vp]),
+    "snk_conv3x3_f16s_set_guard_word": (i32, [vp, vp, vp]),
     "snk_source_hash": (C.c_char_p, [C.c_char_p]),
     "snk_engine_create": (i32, [C.POINTER(vp), i32, i32, i32, i32, i32, f64, u64, i32]),
     "snk_engine_destroy": (i32, [vp]),

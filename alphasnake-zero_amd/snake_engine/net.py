@@ -146,6 +146,7 @@ class QNet:
         # SNK_CONV_RECT_LAYERS=n fixes the number of layers that use it
         self.rect = self.conv_algo in ("f16s", "f16a") and os.environ.get("SNK_CONV_RECT", "1") != "0"
         self.background = BACKGROUND_PIXEL
+        self.guard_trips = 0         # batches forward_guarded evaluated again after a clamp
         self.rect_tiles = None       # set to [] to collect every chunk's (images, per-layer GEMM tiles) device tensors
         self._bg = None
         # chunks below this many observations take the full form: a launch that small is bound by one block's duration (the
@@ -155,7 +156,17 @@ class QNet:
         self.n_streams = int(os.environ.get("SNK_NET_STREAMS", "1"))   # 2: chunks alternate between two streams (+0.8 % end to end,
         #    but per-launch HIP-event timings then overlap, so bench.py keeps the single-stream default)
         self._side = None
+        self._guard = None
         self.set_weights(weights)
+
+    def __del__(self):
+        try:
+            if self._guard is not None:
+                torch.cuda.synchronize(self.device)
+                self.L.snk_guard_word_destroy(self._guard[2])
+                self._guard = None
+        except Exception:
+            pass
 
     # ---- weights -----------------------------------------------------------------------------
     def set_weights(self, weights):
@@ -172,6 +183,16 @@ class QNet:
         self.conv_wT, self.conv_sc, self.conv_sh = [], [], []
         st = torch.cuda.current_stream().cuda_stream
         self.conv_x_scale = activation_scales(self.weights)      # used by the "f16s" kernel only
+        # the split-f16 weight images of all layers are rows of ONE buffer, so that the layers' range flags (a word in each
+        # image's tail) come to the host with one strided copy (range_flags)
+        self._wimg = None
+        if self.conv_algo in ("f16s", "f16", "f16a") and self.blocks:
+            self._wimg = torch.empty((2 * self.blocks, F16S_WEIGHT_BYTES), dtype=torch.uint8, device=dev)
+            self._flags_host = torch.empty((2 * self.blocks,), dtype=torch.int32).pin_memory()
+            if self._guard is None:      # the host-mapped word every layer of this net reports a clamp to (forward_guarded)
+                h, d = C.c_void_p(), C.c_void_p()
+                check(self.L.snk_guard_word_create(C.byref(h), C.byref(d)))
+                self._guard = (C.cast(h, C.POINTER(C.c_int32)), d, h)
         for i in range(2 * self.blocks):
             base = 5 + 5 * i
             if self.conv_algo == "bf16":
@@ -180,7 +201,7 @@ class QNet:
             elif self.conv_algo in ("f16s", "f16", "f16a"):
                 if self.conv_algo == "f16a":
                     self.conv_x_scale[i] = 1.0               # f16 activations are staged as they are
-                wT = torch.empty(F16S_WEIGHT_BYTES, dtype=torch.uint8, device=dev)
+                wT = self._wimg[i]
                 check(self.L.snk_conv3x3_prepare_weights_f16s(t[base].contiguous().data_ptr(), wT.data_ptr(),
                                                               self.conv_x_scale[i], st))
             elif self.conv_algo == "winograd":
@@ -189,6 +210,8 @@ class QNet:
             else:
                 wT = torch.empty(9 * 128 * 128, dtype=torch.float32, device=dev)
                 check(self.L.snk_conv3x3_prepare_weights(t[base].contiguous().data_ptr(), wT.data_ptr(), st))
+            if self._wimg is not None:
+                check(self.L.snk_conv3x3_f16s_set_guard_word(wT.data_ptr(), self._guard[1], st))
             sc, sh = fold(*t[base + 1:base + 5])
             self.conv_wT.append(wT); self.conv_sc.append(sc); self.conv_sh.append(sh)
         base = 5 + 10 * self.blocks
@@ -225,11 +248,14 @@ class QNet:
 
     def range_flags(self, clear=True):
         """per tower layer: 1 when a launch since the last call clamped an input (one small device-to-host copy)"""
-        if self.conv_algo not in ("f16s", "f16", "f16a") or not self.conv_wT:
+        if self._wimg is None:
             return []
-        flags = torch.stack([self._tail(i, torch.int32)[4] for i in range(len(self.conv_wT))])
-        out = flags.cpu().tolist()
-        if clear and any(out):
+        flags = self._wimg[:, F16S_FLAG_OFFSET:F16S_FLAG_OFFSET + 4].contiguous().view(torch.int32).reshape(-1)
+        self._flags_host.copy_(flags, non_blocking=True)        # one gather kernel + one copy into pinned memory
+        torch.cuda.current_stream().synchronize()
+        out = self._flags_host.tolist()
+        if clear:
+            self._guard[0][0] = 0           # the net's guard word says "some flag is set": cleared with them
             for i, f in enumerate(out):
                 if f:
                     self._tail(i, torch.int32)[4] = 0
@@ -279,6 +305,27 @@ class QNet:
             shape = (n, self.h, self.w, 128)
             self._ws[k] = [torch.empty(shape, dtype=torch.float32, device=self.device) for _ in range(3)]
         return self._ws[k]
+
+    def forward_guarded(self, planes, mask=None, out=None, tries=4):
+        """forward() whose result is float32-accurate or an error: after the batch the stream is synchronised and the net's
+        guard word read (host-mapped: no copy); a layer that clamped an input gets its activation scale
+        lowered by 2^6 and the WHOLE batch is evaluated again, so no caller ever sees a Q value computed from clamped
+        activations.  (f16s only; the other algorithms have no range to watch and return forward() as it is.)"""
+        if self.conv_algo != "f16s":
+            return self.forward(planes, mask, out)
+        word = self._guard[0]
+        for _ in range(tries):
+            out = self.forward(planes, mask, out)
+            torch.cuda.current_stream().synchronize()
+            if not word[0]:                  # the host-mapped guard word: no launch of this forward (or since the last one) clamped
+                return out
+            bad = [i for i, f in enumerate(self.range_flags()) if f]      # also clears the word
+            if not bad:                      # the word was left over from an unguarded launch whose flags somebody has read since
+                return out
+            self.widen(bad)
+            self.guard_trips += 1
+        raise EngineError(f"split-f16 convolution: inputs of tower layer(s) {bad} still exceed the f16 range after {tries} "
+                          "widenings of their activation scale; use SNK_CONV_ALGO=winograd (no range limit)")
 
     def forward(self, planes, mask=None, out=None):
         """planes: cuda float32 [n, h, w, 3] (NHWC, contiguous); mask: optional cuda uint8 [n, 3].

@@ -245,17 +245,6 @@ class Agent:
             planes, _, _ = eng.observe_all(pairs.contiguous(), want_mask=False, want_key=False)
             self.nnet.calibrate(planes)
         V, moves = self._mcts.search(eng, d_slots, alive)
-        if hasattr(self.nnet, "check_range"):
-            try:
-                self.nnet.check_range()       # raises if a convolution clamped its input during this root turn
-            except EngineError:
-                # Priors computed from clamped activations sit in the table.  The guard has widened the layers' scales
-                # already: forget what the table holds (a cache: the reference's Agent.clear does the same between
-                # generations), search this root turn once more, and give up only if the guard trips again.
-                self._mcts.clear()
-                self._mcts.now -= 1
-                V, moves = self._mcts.search(eng, d_slots, alive)
-                self.nnet.check_range()
         alive_h = alive.cpu().numpy().astype(bool)
         if self.training:
             self._record(eng, d_slots, alive_h, V)

@@ -72,22 +72,15 @@ class AlphaNNet:
             thr = torch.tensor(0.04, dtype=torch.float32, device=planes.device)
             mask = torch.stack([planes[:, cy, cx - 1, 1] >= thr, planes[:, cy - 1, cx, 1] >= thr,
                                 planes[:, cy, cx + 1, 1] >= thr], dim=1).to(torch.uint8).contiguous()
-        return self._qnet.forward(planes, mask)
+        # the split-f16 convolutions clamp inputs beyond the f16 range and say so: forward_guarded reads the flags after the
+        # batch, widens the scale of a layer that clamped and evaluates the batch again -- what leaves here is within the
+        # 1e-5 contract or an EngineError, for host callers (v) and for the search (Agent.make_moves) alike
+        return self._qnet.forward_guarded(planes, mask)
 
     def v(self, X):
         """alpha_nnet.py:61-73: list/array of (h, w, 3) float32 observations -> (N, 3) float32"""
         planes = torch.as_tensor(np.ascontiguousarray(np.array(X, dtype=np.float32)), device=self._qnet.device)
-        for _ in range(4):
-            V = self.v_device(planes).cpu().numpy()
-            if not self._qnet.check_range(on_overflow="widen"):       # nothing was clamped: float32-accurate
-                return V
-        raise RuntimeError("AlphaNNet.v: activations exceed the split-f16 kernel's range even after widening; "
-                           "use SNK_CONV_ALGO=winograd")
-
-    def check_range(self):
-        """range guard of the split-f16 convolutions for device-side callers (Agent.make_moves calls it once per root
-        turn): raises when any evaluation since the last check was clamped"""
-        self._qnet.check_range(on_overflow="raise")
+        return self.v_device(planes).cpu().numpy()
 
     def calibrate(self, planes):
         if not self._qnet.calibrated:

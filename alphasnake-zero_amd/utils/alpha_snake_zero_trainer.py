@@ -108,12 +108,16 @@ class AlphaSnakeZeroTrainer:
             import torch
             from snake_engine.dist import sample_share, all_gather_samples
             world = dist.get_world_size()
-            t = torch.tensor([n], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(t)                                    # the batch count comes from ALL records (trainer.py:64-68)
-            wanted, batch_size, _ = sample_plan(int(t.item()), world)
+            # [records of all ranks, ranks without a record]: the batch count comes from ALL records (trainer.py:64-68), and a rank
+            # that has nothing to sample from is every rank's error -- decided from the reduced tensor, so that all ranks raise
+            # together instead of one raising while its peers wait inside the all-gather
+            t = torch.tensor([n, int(n == 0)], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t)
+            n_all, n_empty = (int(v) for v in t.tolist())
+            if n_empty:
+                raise RuntimeError(f"{n_empty} of {world} ranks recorded no state to sample from (this rank: {n} records)")
+            wanted, batch_size, _ = sample_plan(n_all, world)
             idx, share = sample_share(n, wanted, world, np.random.RandomState(np.random.randint(1 << 31)))
-            if len(idx) != share:
-                raise RuntimeError(f"rank {dist.get_rank()} recorded no state to sample from")
             Xd = alice.records.fetch_device(idx)
             Vd = torch.as_tensor(alice._values_host()[idx], device=Xd.device)
             Xg, Vg = all_gather_samples(Xd, Vd)

@@ -222,11 +222,13 @@ def fit(weights, input_shape, X, Y, epochs=32, batch_size=2048, lr_schedule=None
         cnt = 0
         for s0 in range(0, n, batch_size):
             idx_all = perm[s0:s0 + batch_size]
+            if len(idx_all) < world:
+                # every rank sees the same permutation, so every rank takes this branch: nobody is left inside the batch-norm
+                # or gradient all-reduces of a batch that another rank refused
+                raise RuntimeError(f"fit: a trailing batch of {len(idx_all)} rows cannot be split over {world} ranks")
             idx = idx_all[rank::world]
             lr = lr_at(step, lr_schedule)
             if native is not None:
-                if len(idx) == 0:
-                    raise RuntimeError(f"fit: a batch of {len(idx_all)} rows leaves rank {rank} of {world} without a row")
                 xb, yb = Xd[idx].contiguous(), Yd[idx].contiguous()
                 if lr == 0.0 and not _DEAD_STEPS_FULL:
                     loss2 = native.forward_only(xb, yb, len(idx_all))

@@ -182,6 +182,26 @@ def engine_kernel_rooflines(se, n=32768):
     return out
 
 
+def conv_traffic_profile(L, algo, n_rect, flops_per_launch, profiles_dir=None):
+    """(HBM bytes per average conv launch, profile file) from the newest profiles/*conv*traffic.json that was measured on the
+    kernel sources the loaded library was built from and on the same form; (None, reason) otherwise"""
+    import glob
+    have = {f: (L.snk_source_hash(f.encode()) or b"").decode() for f in ("conv_split.hip", "common.h")}
+    cands = []
+    for path in glob.glob(os.path.join(profiles_dir or os.path.join(REPO, "profiles"), "*traffic.json")):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if d.get("source_sha256") == have and d.get("conv_algo") == algo and d.get("rect_layers") == n_rect \
+                and "hbm_bytes_per_state_layer" in d:
+            cands.append((os.path.getmtime(path), path, d))
+    if not cands:
+        return None, "no profile under profiles/ was measured on this library's csrc/conv_split.hip (snk_source_hash) in this form"
+    _, path, d = max(cands)
+    return d["hbm_bytes_per_state_layer"] * flops_per_launch / (2.0 * 441 * 9 * 128 * 128), os.path.relpath(path, REPO)
+
+
 def workload_label(board, snakes, blocks, games, breadth, world):
     """which BASELINE.json config a run is (shape AND size), or 'custom'"""
     if (board, snakes, blocks) == (11, 4, 4):
@@ -211,6 +231,9 @@ def launch_ranks(n):
     s.close()
     procs = []
     for r in range(n):
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver supports dmabuf IPC only; with the legacy mode RCCL's peer
+        # buffers fail in hipIpcGetMemHandle ("invalid argument").  main() sets the same default for ranks started by
+        # torch.distributed.run; a value the caller exported is left alone.
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
@@ -269,6 +292,8 @@ def main():
     ap.add_argument("--no-conv-timing", action="store_true",
                     help="no HIP events around the conv launches (roofline.achieved is then null): for small, launch-bound runs")
     ap.add_argument("--no-kernel-rooflines", action="store_true")
+    ap.add_argument("--no-clock-probe", action="store_true",
+                    help="skip the untimed extra root turn that samples the shader clock beside the forward chunks (roofline.clock_mhz)")
     args = ap.parse_args()
 
     if args.games_total is not None:
@@ -293,6 +318,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:      # checked before any GPU call: a process that has touched the GPU must never be re-launched
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # before the first HIP call of this rank (see launch_ranks)
+    # the ranks of one node share its host cores: each keeps its share of the cpus this job may use (a rank's host side is one
+    # Python thread sequencing launches; torch's default of one intra-op thread per visible cpu would put N x 256 threads on
+    # a 16-cpu quota)
+    host_threads = max(1, usable_cpus() // world)
+    torch.set_num_threads(host_threads)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     n_dev = torch.cuda.device_count()
     # RCCL needs one GPU per rank; with fewer GPUs than ranks (a 1-GPU box) the ranks share GPUs and talk over gloo
@@ -337,8 +368,6 @@ def main():
     ev0, sim0 = (m.stats["net_evals"], m.stats["sim_steps"]) if m is not None else (0, 0)     # --warmup 0: nothing ran yet
     nnet._qnet.conv_timing = None if args.no_conv_timing else []
     nnet._qnet.rect_tiles = None if args.no_conv_timing or not nnet._qnet.n_rect else []      # GEMM tiles the sub-rectangle layers execute
-    probe = net.ClockProbe(torch.device("cuda", dev_index)) if rank == 0 else None
-    nnet._qnet.clock_probe = probe
     coll_dev = "cuda" if backend == "nccl" else "cpu"
 
     def sync_clock():
@@ -346,6 +375,7 @@ def main():
         return time.time()
     barrier()
     t0 = time.time()
+    cpu0 = time.process_time()
     env_steps = 0
     for k in range(args.steps):                # one root turn per call: the same launches, plus a progress line per step
         gr.run(alice, max_turns=1)
@@ -353,6 +383,7 @@ def main():
         if rank == 0:
             log(f"[rank 0] step {k + 1}/{args.steps}: {gr.env_steps} env-steps, {time.time() - t0:.1f} s since the start of the timed region")
     t_play = sync_clock() - t0
+    cpu_play = time.process_time() - cpu0      # user + system cpu seconds of this rank's process over the self-play steps
     # iteration-end exchange (trainer.py:63-75 across ranks): the row count comes from the records of ALL ranks, every rank
     # sends its share of the sampled rows (all-gather), the six log counters are all-reduced
     n_rec = torch.tensor([len(alice.records)], dtype=torch.int64, device=coll_dev)
@@ -378,9 +409,26 @@ def main():
     m = alice._mcts
     evals = m.stats["net_evals"] - ev0
     sims = m.stats["sim_steps"] - sim0
-    # per-rank figures for reading a scaling curve: every rank's env-steps, self-play time, sampling, the two collectives
-    mine = torch.tensor([float(env_steps), t_play, t1 - t0 - t_play, t2 - t1, t3 - t2, wall_rank, float(evals), float(len(alice.records))],
-                        dtype=torch.float64, device=coll_dev)
+    n_records = len(alice.records)
+    tm = nnet._qnet.conv_timing or []
+    nnet._qnet.conv_timing = None
+    conv_s = sum(a.elapsed_time(b) for a, b, _ in tm) * 1e-3
+    rect_tiles, nnet._qnet.rect_tiles = nnet._qnet.rect_tiles, None
+    # the clock the chip holds under this loop, sampled OUTSIDE the timed region (one more root turn of the same games with a
+    # one-wavefront probe kernel on its own stream beside every forward chunk): nothing extra runs while the metric is timed
+    clk = np.zeros(0)
+    if not args.no_clock_probe and len(gr.games):
+        probe = net.ClockProbe(torch.device("cuda", dev_index))
+        nnet._qnet.clock_probe = probe
+        gr.run(alice, max_turns=1)
+        torch.cuda.synchronize()
+        nnet._qnet.clock_probe = None
+        clk = probe.mhz()
+    clk_med = float(np.median(clk)) if len(clk) else 0.0
+    # per-rank figures for reading a scaling curve: every rank's env-steps, self-play time, sampling, the two collectives, the
+    # host cpu seconds its process used, the GPU seconds of its conv launches, the clock its GPU held
+    mine = torch.tensor([float(env_steps), t_play, t1 - t0 - t_play, t2 - t1, t3 - t2, wall_rank, float(evals), float(n_records),
+                         cpu_play, conv_s, clk_med, float(host_threads)], dtype=torch.float64, device=coll_dev)
     per_rank = mine.unsqueeze(0)
     if world > 1:
         flat_rows = torch.empty(world * mine.numel(), dtype=torch.float64, device=coll_dev)
@@ -394,25 +442,26 @@ def main():
     env_steps = float(per_rank[:, 0].sum())
 
     if rank == 0:
-        tm = nnet._qnet.conv_timing or []
-        nnet._qnet.conv_timing = None
-        conv_s = sum(a.elapsed_time(b) for a, b, _ in tm) * 1e-3
         conv_flops = sum(f for _, _, f in tm)
         achieved = conv_flops / conv_s / 1e12 if conv_s > 0 else None      # None: --no-conv-timing
         algo = nnet._qnet.conv_algo
         peak = 2500.0 if algo in ("bf16", "f16s", "f16", "f16a") else 157.3      # dense MFMA peaks (bf16 / f16, f32), MI355X_MICROARCH.md
-        # MFMA flops the kernel executes per algorithmic (direct-convolution) flop
-        executed = {"f16s": 3.0 * 448 / 441, "f16": 448 / 441.0, "f16a": 448 / 441.0, "winograd": 16 * 121 / (441 * 9.0)}.get(algo, 1.0)
+        # MFMA flops the kernel executes per algorithmic (direct-convolution) flop: MFMAs per product x GEMM rows per pixel
+        T_full = (OBS * OBS + 31) // 32
+        per_product = 3.0 if algo == "f16s" else 1.0           # hi*hi + hi*lo + lo*hi; the reduced-precision forms issue one
+        executed = {"f16s": per_product * T_full * 32 / (OBS * OBS), "f16": T_full * 32 / (OBS * OBS), "f16a": T_full * 32 / (OBS * OBS),
+                    "bf16": T_full * 32 / (OBS * OBS), "winograd": 16 * 121 / (441 * 9.0)}.get(algo, 1.0)
         qn = nnet._qnet
         rect = None
+        qn.rect_tiles = rect_tiles
         if qn.rect_tiles:
             # sub-rectangle form: the first n_rect layers convolve the board window grown by one pixel per layer only; what
             # the launches executed = the 32-row GEMM tiles the device-side plans counted + the full layers' tiles
-            T_full, n_layers = (OBS * OBS + 31) // 32, 2 * qn.blocks
+            n_layers = 2 * qn.blocks
             imgs = sum(mm for mm, _ in qn.rect_tiles)
             per_layer = torch.stack([c[:, 1] for _, c in qn.rect_tiles]).to(torch.float64).sum(dim=0).cpu().numpy()
             tiles = float(per_layer.sum()) + float(imgs) * T_full * (n_layers - qn.n_rect)
-            executed = 3.0 * tiles * 32 / (float(imgs) * n_layers * OBS * OBS)
+            executed = per_product * tiles * 32 / (float(imgs) * n_layers * OBS * OBS)
             rect = {"layers": qn.n_rect, "of": n_layers,
                     "tiles_executed_vs_full_per_layer": [float(v) / (imgs * T_full) for v in per_layer],
                     "tiles_executed_vs_full": tiles / (float(imgs) * T_full * n_layers),
@@ -421,12 +470,12 @@ def main():
                             "(bit-identical to the full convolution, tests/test_rect_conv_gpu.py); `achieved` still counts the "
                             "reference's full direct convolution"}
             qn.rect_tiles = None
-        traffic = None      # HBM bytes per average launch, from the committed rocprofv3 --pmc passes (profiles/)
-        tfile = os.path.join(REPO, "profiles", {"f16s": "r3b_conv_rect_traffic.json" if nnet._qnet.n_rect == 6 else "r3_conv_f16s_traffic.json",
-                                                "winograd": "r1_conv_traffic.json"}.get(algo, "none"))
-        if os.path.exists(tfile) and tm:
-            per_state_layer = json.load(open(tfile))["hbm_bytes_per_state_layer"]
-            traffic = per_state_layer * (conv_flops / len(tm)) / (2.0 * 441 * 9 * 128 * 128) if judged else None
+        # HBM bytes per average launch, from the committed rocprofv3 --pmc passes (profiles/, made by tools/conv_traffic.py).  A
+        # profile is quoted only for the kernel it was measured on: it names the sha-256 of csrc/conv_split.hip + common.h and the
+        # form (algorithm, sub-rectangle layers), and the LOADED library reports the hashes of the sources it was built from
+        traffic, traffic_src = None, None
+        if tm and judged:
+            traffic, traffic_src = conv_traffic_profile(se.lib(), algo, qn.n_rect, conv_flops / len(tm))
         res = {
             "metric": "self-play env-steps/sec (11x11, 4 snakes, 50 MCTS sims)",
             "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -442,7 +491,8 @@ def main():
                                    f"{args.breadth} (= {args.breadth // 8 * 8} rollouts), depth 8, health_dec 1, softmax_base 2, "
                                    "training=True, gen-0 Glorot net (seed 0), fp32 Q-net",
                        "games_per_gpu": args.games, "breadth": args.breadth, "parallelism": f"games sharded x{world}", "dist_backend": backend if world > 1 else None,
-                       "games_total": args.games * world,
+                       "games_total": args.games * world, "host_threads_per_rank": host_threads,
+                       "env": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")},
                        "net_evals_per_env_step": evals / max(1, env_steps_rank0), "sim_steps_per_env_step": sims / max(1, env_steps_rank0),
                        "net_evals_per_s_rank0": evals / dt, "sample_rows_gathered": int(Xg.shape[0])},
             "roofline": {"bound": "mfma",
@@ -451,7 +501,8 @@ def main():
                                     "f16": "k_conv3x3_f16s<SPLIT = false>",
                                     "f16a": "k_conv3x3_f16s<SPLIT = false, IO16>"}.get(algo, "k_conv3x3_f32"),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak if achieved else None, "traffic": traffic, "launches": len(tm),
+                         "frac": achieved / peak if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
+                         "launches": len(tm),
                          "flops_convention": "algorithmic = direct 3x3 convolution, 2*441*1152*128 per state and layer (SURVEY 8d)",
                          "executed_frac": achieved / peak * executed if achieved else None,
                          "algorithm": {"winograd": "Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: executes 16*121/(441*9) = 0.488 of the "
@@ -469,18 +520,22 @@ def main():
             # what a non-linear scaling curve is made of: one row per rank (rank r = GPU r of the node)
             "ranks": [{"rank": r, "env_steps": int(v[0]), "self_play_s": v[1], "sample_rows_s": v[2], "all_gather_s": v[3],
                        "all_reduce_s": v[4], "wall_s": v[5], "env_steps_per_s": v[0] / v[5], "net_evals": int(v[6]),
-                       "records": int(v[7])} for r, v in enumerate(per_rank)],
+                       "records": int(v[7]), "host_cpu_s": v[8], "conv_gpu_s": v[9] if tm else None,
+                       "self_play_minus_conv_s": v[1] - v[9] if tm else None,
+                       "clock_mhz_median": v[10] or None, "host_threads": int(v[11])} for r, v in enumerate(per_rank)],
+            "ranks_note": "host_cpu_s = user + system cpu seconds of the rank's process over the self-play steps (one Python thread "
+                          "sequencing launches; host_threads = torch intra-op threads = usable cpus // ranks); conv_gpu_s = HIP-event "
+                          "time of its conv launches; self_play_minus_conv_s = every other kernel + the time its GPU waited for the host",
             "exchange": {"dist_backend": backend if world > 1 else None, "rows_per_rank": int(share), "rows_gathered": int(Xg.shape[0]),
                          "bytes_per_rank": int(share) * (OBS * OBS * 3 + 3) * 4,
                          "all_gather_s_max": float(per_rank[:, 3].max()), "all_reduce_s_max": float(per_rank[:, 4].max())},
         }
-        clk = probe.mhz() if probe is not None else np.zeros(0)
-        nnet._qnet.clock_probe = None
         if len(clk):
             held = float(np.median(clk))
             res["roofline"]["clock_mhz"] = {"median": held, "p10": float(np.percentile(clk, 10)), "p90": float(np.percentile(clk, 90)),
                                             "samples": int(len(clk)), "nominal": 2400.0,
-                                            "how": "one-wavefront probe kernel on its own stream beside every forward chunk: "
+                                            "how": "one-wavefront probe kernel on its own stream beside every forward chunk of ONE EXTRA, "
+                                                   "UNTIMED root turn after the timed region (the same games, the next turn): "
                                                    "s_memtime / s_memrealtime x 100 MHz over 200 us (csrc/probe.hip)"}
             if res["roofline"]["executed_frac"]:
                 res["roofline"]["executed_frac_of_held_clock_peak"] = res["roofline"]["executed_frac"] * 2400.0 / held

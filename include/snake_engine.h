@@ -182,7 +182,8 @@ int snk_conv3x3_bn_f32_winograd(const float *d_x, const float *d_U, const float 
  * discard the result when it is non-zero (the net wrapper lowers x_scale and re-evaluates, or raises).
  * snk_conv3x3_prepare_weights_f16s: Keras kernel (3,3,128,128) -> the split weights in MFMA fragment order;
  *   d_wS: SNK_CONV_F16S_WEIGHT_BYTES bytes (9*128*128 hi/lo pairs, then the tail: float 2^-k, 2^k, x_scale,
- *   1/x_scale, int32 range flag (cleared here), 12 bytes of padding).
+ *   1/x_scale, int32 range flag (cleared here), 4 bytes of padding, the 8-byte address of an optional
+ *   guard word shared by the net's layers (cleared here; snk_conv3x3_f16s_set_guard_word)).
  *   x_scale: a power of two the layer's INPUT activations are multiplied by before the split (undone exactly in
  *   the epilogue); choose it so that the largest |activation| * x_scale stays well below 65504 (1.0f is always
  *   valid; the net wrapper derives it from the producing layer's batch-norm parameters).
@@ -191,6 +192,14 @@ int snk_conv3x3_bn_f32_winograd(const float *d_x, const float *d_U, const float 
 #define SNK_CONV_F16S_TAIL_OFFSET (9 * 128 * 128 * 4)
 #define SNK_CONV_F16S_FLAG_OFFSET (9 * 128 * 128 * 4 + 16)
 int snk_conv3x3_prepare_weights_f16s(const float *d_w_hwio, void *d_wS, float x_scale, void *stream);
+/* One word for all layers of a net: snk_guard_word_create allocates a host-mapped, coherent int32 (*h_word: the host address,
+ * *d_word: the address kernels use); snk_conv3x3_f16s_set_guard_word stores d_word in bytes 24..31 of a weight image's tail
+ * (snk_conv3x3_prepare_weights_f16s clears them: register again after every prepare; NULL unregisters).  A launch that clamps
+ * then also stores 1 to that word, so after synchronising the stream the host reads *h_word -- no copy, no kernel -- and looks
+ * at the per-layer flags only when it is non-zero (QNet.forward_guarded: widen the layer's x_scale, evaluate the batch again). */
+int snk_guard_word_create(int32_t **h_word, int32_t **d_word);
+int snk_guard_word_destroy(int32_t *h_word);
+int snk_conv3x3_f16s_set_guard_word(void *d_wS, int32_t *d_word, void *stream);
 int snk_conv3x3_bn_f16s(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
                         const float *d_residual, float *d_out, int n_images, int height, int width, int relu,
                         void *stream);

@@ -34,9 +34,16 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert all(0.3 < v <= 1.0 for v in sr["tiles_executed_vs_full_per_layer"]) and 0.5 < sr["tiles_executed_vs_full"] < 1.0
     assert sr["tiles_executed_vs_full_per_layer"] == sorted(sr["tiles_executed_vs_full_per_layer"])
     assert abs(r["executed_frac"] - r["frac"] * 3.0 * 448 / 441 * sr["tiles_executed_vs_full"]) < 1e-6
-    clk = r["clock_mhz"]                                            # the clock the chip held beside the measured kernels
-    assert clk["samples"] >= 1 and 500.0 < clk["p10"] <= clk["median"] <= clk["p90"] < 2700.0
+    # derived fractions stay fractions: algorithmic <= executed (three MFMAs per product) <= the peak, also at the clock held
+    assert 0 < r["frac"] <= r["executed_frac"] <= 1.0 and r["executed_frac"] <= r["executed_frac_of_held_clock_peak"] <= 1.0
+    clk = r["clock_mhz"]                                            # the clock the chip held in an untimed extra turn of the same loop
+    assert clk["samples"] >= 1 and 500.0 < clk["p10"] <= clk["median"] <= clk["p90"] < 2700.0 and "UNTIMED" in clk["how"]
+    # traffic is quoted only from a profile measured on the sources the loaded library was built from (else null + the reason)
+    assert (r["traffic"] is None) != str(r["traffic_source"]).endswith(".json"), (r["traffic"], r["traffic_source"])
     assert len(d["ranks"]) == 1 and d["ranks"][0]["env_steps"] == 32 and d["exchange"]["dist_backend"] is None
+    rk = d["ranks"][0]
+    assert rk["host_threads"] == d["config"]["host_threads_per_rank"] >= 1 and 0 < rk["host_cpu_s"] and 0 < rk["conv_gpu_s"] < rk["self_play_s"]
+    assert d["config"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "env-steps/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     for k in ("step", "clone", "observe"):
@@ -69,8 +76,30 @@ def test_bench_gpus_2_launches_its_own_ranks():
         assert r["all_gather_s"] > 0 and r["all_reduce_s"] > 0 and r["env_steps_per_s"] > 0
     # whole-job value: both ranks' root env-steps (2 turns x 16 games each, nobody dies in two turns) over the slowest rank's time
     assert abs(d["value"] - 2 * 2 * 16 / (d["ms_per_step"] * 2e-3)) / d["value"] < 0.05
+    assert abs(d["value"] - sum(r["env_steps"] for r in d["ranks"]) / max(r["wall_s"] for r in d["ranks"])) / d["value"] < 0.05
     assert "cpu_baseline" not in d                                 # rank 0 at N = 1 only
     assert d["config"]["dist_backend"] in ("nccl", "gloo")
+    # the ranks share the host: each runs usable cpus // 2 torch threads, and the IPC mode this pool's driver needs is set
+    assert all(r["host_threads"] == d["config"]["host_threads_per_rank"] >= 1 and r["host_cpu_s"] > 0 for r in d["ranks"])
+    assert d["config"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_one_rank_under_the_launcher_is_the_plain_line():
+    """N = 1 started the way the driver starts N > 1 (python -m torch.distributed.run) describes the same workload as the plain run"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    args = ["--gpus", "1", "--games", "16", "--breadth", "16", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-rooflines",
+            "--no-clock-probe"]
+    a = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(REPO, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=600)
+    assert a.returncode == 0, a.stderr[-3000:]
+    b = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=600)
+    assert b.returncode == 0, b.stderr[-3000:]
+    da, db = (json.loads([l for l in o.stdout.splitlines() if l.strip().startswith("{")][-1]) for o in (a, b))
+    assert da["config"]["workload"] == db["config"]["workload"] and da["n_gpus"] == db["n_gpus"] == 1
+    assert da["config"]["parallelism"] == db["config"]["parallelism"] and da["ranks"][0]["env_steps"] == db["ranks"][0]["env_steps"] == 16
+    assert da["metric"] == db["metric"] and da["scaling"] == db["scaling"] and da["dtype"] == db["dtype"]
 
 
 def test_bench_games_total_splits_the_job_over_the_ranks():

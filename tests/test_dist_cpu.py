@@ -62,6 +62,50 @@ def test_two_rank_exchange(tmp_path):
     assert torch.equal(res[0]["Xg"], res[1]["Xg"])
 
 
+def _collect_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [repo, os.path.join(repo, "alphasnake-zero_amd")]
+    from utils.alpha_snake_zero_trainer import AlphaSnakeZeroTrainer
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        class Alice:                       # rank 1 played games that recorded nothing
+            records = [0] * (40 if rank == 0 else 0)
+            values = records
+        tr = AlphaSnakeZeroTrainer(8, 8, 8, 1e-3, 0.98)
+        try:
+            tr._collect(Alice())
+            what = "returned"
+        except RuntimeError as e:
+            what = str(e)
+        open(os.path.join(out_dir, f"c{rank}.txt"), "w").write(what)
+        # fit: a trailing batch smaller than the world is refused by EVERY rank (same permutation on all of them)
+        from utils import trainer_torch
+        from snake_engine.net import glorot_uniform_weights
+        ws = glorot_uniform_weights((5, 5, 3), blocks=1, seed=0)
+        X = np.zeros((5, 5, 5, 3), np.float32); Y = np.zeros((5, 3), np.float32)
+        try:
+            trainer_torch.fit(ws, (5, 5, 3), X, Y, epochs=1, batch_size=4, lr_schedule=None, device="cpu", seed=0, verbose=False)
+            what = "returned"
+        except RuntimeError as e:
+            what = str(e)
+        open(os.path.join(out_dir, f"f{rank}.txt"), "w").write(what)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_rank_without_records_and_an_unsplittable_batch_fail_on_every_rank(tmp_path):
+    """a rank that cannot contribute must not raise alone while its peers wait inside a collective: both ranks raise the same
+    error, decided from the all-reduced counts (iteration-end sampling) or from what every rank sees (the fit's trailing batch)"""
+    world, port = 2, _free_port()
+    mp.spawn(_collect_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert "1 of 2 ranks recorded no state" in open(tmp_path / f"c{r}.txt").read()
+        assert "trailing batch of 1 rows cannot be split over 2 ranks" in open(tmp_path / f"f{r}.txt").read()
+
+
 def test_shard_range_partitions_everything():
     from snake_engine.dist import shard_range, sample_share
     for total in (1, 7, 8, 4096, 262144):

@@ -449,10 +449,12 @@ def test_agent_calibrates_new_weights_and_checks_the_range_every_turn(env, monke
     assert nn_._qnet.calibrated and nn_._qnet.range_flags() == [0] * 8 and gr.env_steps == 16
 
 
-def test_agent_recovers_from_a_tripped_range_guard_inside_a_root_turn(env, monkeypatch):
-    """scales that are far too large for the activations (set after the calibration, as a weight update would leave them):
-    the first search of the turn clamps, the guard widens the scales, the agent forgets the table and searches the turn
-    again -- make_moves returns moves computed from float32-accurate values instead of raising into the training loop"""
+def test_a_clamped_batch_is_evaluated_again_inside_the_search(env, monkeypatch):
+    """scales that are far too large for the activations (set after the calibration, as a weight update would leave them): the
+    first batch of the next root turn clamps, AlphaNNet.v_device (QNet.forward_guarded) widens the layer's scale and evaluates
+    THAT BATCH again before anything reaches the transposition table -- the search runs once, the table keeps the statistics of
+    the earlier turns (the reference keeps them until Agent.clear, agent.py:140-147), and records, values and counts equal
+    those of an undisturbed twin run"""
     torch, se, net = env
     monkeypatch.setenv("SNK_CONV_ALGO", "f16s")
     from utils.agent import Agent
@@ -460,20 +462,36 @@ def test_agent_recovers_from_a_tripped_range_guard_inside_a_root_turn(env, monke
     from utils.mp_game_runner import MPGameRunner
     MPGameRunner.verbose = False
     ws = net.glorot_uniform_weights((21, 21, 3), blocks=4, seed=2)
-    nn_ = AlphaNNet(input_shape=(21, 21, 3), _weights=ws)
-    alice = Agent(nn_, 2, True, 4, 8, seed=3)
-    gr = MPGameRunner(11, 11, 4, 1, 8, seed=5)
-    gr.run(alice, max_turns=1)                                      # calibrates
-    good = list(nn_._qnet.conv_x_scale)
-    nn_._qnet.set_x_scale(3, good[3] * 2.0 ** 12)                   # far beyond the f16 range for this layer's inputs
-    searches = []
-    orig = alice._mcts.search
-    alice._mcts.search = lambda *a, **k: (searches.append(1), orig(*a, **k))[1]
-    gr.run(alice, max_turns=1)
-    assert len(searches) == 2, "one clamped search, one repeated with the widened scale"
-    assert nn_._qnet.conv_x_scale[3] == good[3] * 64.0 and nn_._qnet.range_flags() == [0] * 8
-    gr.run(alice, max_turns=1)
-    assert len(searches) == 3 and gr.env_steps == 8
+
+    def play(disturb):
+        import random
+        random.seed(11)                     # MPGameRunner draws the start boards with python's `random` (game.py:25-30, 46)
+        nn_ = AlphaNNet(input_shape=(21, 21, 3), _weights=ws)
+        alice = Agent(nn_, 2, True, 4, 8, seed=3)
+        gr = MPGameRunner(11, 11, 4, 1, 8, seed=5)
+        gr.run(alice, max_turns=1)                                      # calibrates
+        good = list(nn_._qnet.conv_x_scale)
+        entries1 = len(alice.cached_values)
+        if disturb:
+            nn_._qnet.set_x_scale(3, good[3] * 2.0 ** 12)               # far beyond the f16 range for this layer's inputs
+        searches = []
+        orig = alice._mcts.search
+        alice._mcts.search = lambda *a, **k: (searches.append(1), orig(*a, **k))[1]
+        gr.run(alice, max_turns=2)
+        assert len(searches) == 2 and gr.env_steps == 16, "one search per root turn, clamp or not"
+        assert nn_._qnet.range_flags() == [0] * 8
+        return nn_, alice, good, entries1
+
+    nn_a, a, good, e1a = play(False)
+    nn_b, b, _, e1b = play(True)
+    assert nn_a._qnet.guard_trips == 0 and nn_b._qnet.guard_trips >= 1
+    assert good[3] <= nn_b._qnet.conv_x_scale[3] <= good[3] * 64.0 and nn_b._qnet.conv_x_scale[:3] == good[:3]
+    assert e1a == e1b > 0 and len(a.cached_values) == len(b.cached_values) > e1a, "nothing was forgotten, both tables grew alike"
+    assert a._mcts.stats == b._mcts.stats, (a._mcts.stats, b._mcts.stats)          # evaluations, rollout tics, ticks: no double count
+    assert a._mcts.draw_ctr == b._mcts.draw_ctr and a._mcts.now == b._mcts.now == 3
+    assert len(a.records) == len(b.records) and all(x.tobytes() == y.tobytes() for x, y in zip(a.records[:], b.records[:]))
+    va, vb = np.array(a.values[:]), np.array(b.values[:])
+    assert np.abs(va - vb).max() <= TOL_Q, np.abs(va - vb).max()
     # a net without a range to watch is "calibrated" at once: no observation pass per root turn
     monkeypatch.setenv("SNK_CONV_ALGO", "winograd")
     nw = AlphaNNet(input_shape=(21, 21, 3), _weights=ws)
