@@ -36,6 +36,20 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// the 16-bit activation type of the reduced-precision towers is f16 or (BF) bf16; both travel through the kernel as 16-bit
+// patterns typed _Float16 (staging copies them untouched), only the MFMA and these two conversions know the difference
+template <bool BF> __device__ __forceinline__ float hs_from16(_Float16 v)
+{
+    if (BF) return (float)__builtin_bit_cast(__bf16, v);
+    return (float)v;
+}
+template <bool BF> __device__ __forceinline__ _Float16 hs_to16(float v)
+{
+    if (BF) return __builtin_bit_cast(_Float16, (__bf16)v);            // v_cvt_pk_bf16_f32: round to nearest even, float32's range
+    return (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);    // saturating: an f16 infinity would turn the next layer into NaNs
+}
 
 #define HS_C 128
 #define HS_KC 16                                         // input channels per chunk = one MFMA k step
@@ -103,12 +117,16 @@ extern "C" int snk_dbg_conv_stamps(unsigned long long *h_out, int n_blocks)
 // RECT: the block's "image" is a sub-rectangle (ry0, rx0, rh, rw) of the Hd x Wd canvas (see k_rect_plan below): GEMM rows are
 //   the rectangle's pixels in row-major order, the LDS rows are pitched rw + 2 with the halo columns taken from the canvas
 //   (zero outside it), global rows stay pitched Wd.
-template <int NI, int MODE, bool SPLIT, int IO16, bool RECT>
+// BF (with IO16 bit 0, reduced-precision form only): the 16-bit type is bf16 -- BASELINE configs[4]'s "bf16 MFMA conv" as it is
+//   worded: bf16 activations in HBM, bf16 weights, v_mfma_f32_32x32x16_bf16, float32 accumulation and epilogue.  bf16 has
+//   float32's exponent range, so there is no scale to choose and nothing to clamp.
+template <int NI, int MODE, bool SPLIT, int IO16, bool RECT, bool BF = false>
 __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *smem, const int img, const int tile0, const int ntile,
                                          const int ry0, const int rx0, const int rh, const int rw, const unsigned bbox,
                                          const int part, const int parts)
 {
     static_assert(IO16 == 0 || !SPLIT, "f16 activations only exist in the reduced-precision form");
+    static_assert(!BF || (IO16 & 1), "the bf16 form reads bf16 activations");
     constexpr bool IN16 = (IO16 & 1) != 0, OUT16 = (IO16 & 2) != 0;
     constexpr bool STATS = MODE == 4;
     const bool has_res = MODE == 0 ? p.res != nullptr : (MODE == 2 || MODE == 3);
@@ -226,7 +244,8 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
         la[i] = (unsigned)((y_ - (y_first - 1)) * P + x_ + 1) * HS_LDP + 16 * h;
     }
 #define HS_LDS(off) (*(const f16x8 *)(smem + (off)))
-#define HS_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define HS_MFMA(a, b, c) c = BF ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0) \
+                              : __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 // One tap of a chunk = NI fenced regions, each = { the ds_reads of the tile two ahead; a share of the staging work;
 // this tile's three MFMAs }.  The fences keep the A fragments two tiles ahead of their use (the compiler otherwise
 // sinks the reads to the MFMAs that consume them and the wave eats the LDS latency once per tile).  The tile sequence
@@ -341,7 +360,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
                 if (IN16) {                                                                     \
                     const _Float16 *rb_ = (RECT && res_stale[j]) ? (const _Float16 *)p.bg_res + 4 * cq : (const _Float16 *)p.res + obase; \
                     const f16x4 r16_ = *(const f16x4 *)(rb_ + max(off[(pass) & 1][j], 0));      \
-                    rv[(pass) & 1][j] = make_float4((float)r16_[0], (float)r16_[1], (float)r16_[2], (float)r16_[3]); \
+                    rv[(pass) & 1][j] = make_float4(hs_from16<BF>(r16_[0]), hs_from16<BF>(r16_[1]), hs_from16<BF>(r16_[2]), hs_from16<BF>(r16_[3])); \
                 } else {                                                                        \
                     const float *rb_ = (RECT && res_stale[j]) ? p.bg_res + 4 * cq : p.res + obase; \
                     rv[(pass) & 1][j] = *(const float4 *)(rb_ + max(off[(pass) & 1][j], 0));    \
@@ -382,9 +401,8 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
             }
             if (has_out && off[pass & 1][j] >= 0) {
                 if (OUT16) {
-                    f16x4 o16_;                                    // saturating: an f16 infinity would turn the next layer into NaNs
-                    o16_[0] = (_Float16)__builtin_amdgcn_fmed3f(v.x, -65504.f, 65504.f); o16_[1] = (_Float16)__builtin_amdgcn_fmed3f(v.y, -65504.f, 65504.f);
-                    o16_[2] = (_Float16)__builtin_amdgcn_fmed3f(v.z, -65504.f, 65504.f); o16_[3] = (_Float16)__builtin_amdgcn_fmed3f(v.w, -65504.f, 65504.f);
+                    f16x4 o16_;
+                    o16_[0] = hs_to16<BF>(v.x); o16_[1] = hs_to16<BF>(v.y); o16_[2] = hs_to16<BF>(v.z); o16_[3] = hs_to16<BF>(v.w);
                     *(f16x4 *)((_Float16 *)p.out + obase + off[pass & 1][j]) = o16_;
                 } else *(float4 *)(p.out + obase + off[pass & 1][j]) = v;
             }
@@ -428,7 +446,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     HS_STAMP(4)
 }
 
-template <int NI, int MODE, bool SPLIT = true, int IO16 = 0>
+template <int NI, int MODE, bool SPLIT = true, int IO16 = 0, bool BF = false>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
 {
     __shared__ __align__(16) unsigned char smem[HS_SMEM];
@@ -441,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
         else { img = b / p.n_blk; blk = b - img * p.n_blk; }
     }
     const int tile0 = blk * p.tiles_base + min(blk, p.tiles_rem), ntile = p.tiles_base + (blk < p.tiles_rem ? 1 : 0);
-    hs_block<NI, MODE, SPLIT, IO16, false>(p, smem, img, tile0, ntile, 0, 0, 0, 0, 0u, 0, 1);
+    hs_block<NI, MODE, SPLIT, IO16, false, BF>(p, smem, img, tile0, ntile, 0, 0, 0, 0, 0u, 0, 1);
 }
 
 // The sub-rectangle form.  The reference's observation (game.py:215-257) is one background pixel (0, WALL, 0) everywhere
@@ -451,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
 // per staging item and per shortcut row when the block sets up its addresses).  Blocks take (image, rectangle, tile range,
 // bounding box) from descriptors written by k_rect_plan; the M-tile count of a block selects the body at run time
 // (wave-uniform), so one launch covers every rectangle shape of the batch.
-template <int MODE, bool SPLIT = true, int IO16 = 0>
+template <int MODE, bool SPLIT = true, int IO16 = 0, bool BF = false>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s_rect(ConvHsArgs p)
 {
     __shared__ __align__(16) unsigned char smem[HS_SMEM];
@@ -460,10 +478,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s_rect(ConvHsArgs p)
     if ((int)blockIdx.x >= nd) return;
     const int img = (int)d.x, ry0 = d.y & 255, rx0 = (d.y >> 8) & 255, rh = (d.y >> 16) & 255, rw = d.y >> 24;
     const int tile0 = d.z & 255, ntile = (d.z >> 8) & 255, part = (d.z >> 16) & 255, parts = d.z >> 24;
-#define HS_RECT_CASE(NI_) case NI_: hs_block<NI_, MODE, SPLIT, IO16, true>(p, smem, img, tile0, ntile, ry0, rx0, rh, rw, d.w, part, parts); break;
+#define HS_RECT_CASE(NI_) case NI_: hs_block<NI_, MODE, SPLIT, IO16, true, BF>(p, smem, img, tile0, ntile, ry0, rx0, rh, rw, d.w, part, parts); break;
     switch (ntile) {
         HS_RECT_CASE(1) HS_RECT_CASE(2) HS_RECT_CASE(3) HS_RECT_CASE(4) HS_RECT_CASE(5) HS_RECT_CASE(6) HS_RECT_CASE(7)
-    default: hs_block<8, MODE, SPLIT, IO16, true>(p, smem, img, tile0, ntile, ry0, rx0, rh, rw, d.w, part, parts); break;
+    default: hs_block<8, MODE, SPLIT, IO16, true, BF>(p, smem, img, tile0, ntile, ry0, rx0, rh, rw, d.w, part, parts); break;
     }
 #undef HS_RECT_CASE
 }
@@ -511,7 +529,8 @@ __global__ void k_f16s_tail_from(const float *__restrict__ w_tail, const float *
 
 // Keras kernel (kh, kw, cin, cout) float32 -> split f16 fragments in the order the conv kernel's waves load them
 // FLIP: the kernel of the INPUT GRADIENT of the same layer -- taps mirrored, channel axes swapped: w'[tap][ci][co] = w[8 - tap][co][ci]
-template <bool FLIP>
+// BF: the parts are written as bf16 patterns (the bf16 tower uses the hi parts only)
+template <bool FLIP, bool BF = false>
 __global__ void k_f16s_weights(const float *__restrict__ w, _Float16 *__restrict__ wS, const float *__restrict__ tail)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;          // one f16x8 fragment piece
@@ -525,6 +544,11 @@ __global__ void k_f16s_weights(const float *__restrict__ w, _Float16 *__restrict
     for (int j = 0; j < 8; ++j) {
         const int cin = HS_KC * c + 8 * h + j;
         const float val = (FLIP ? w[(long)((8 - tap) * HS_C + cout) * HS_C + cin] : w[(long)(tap * HS_C + cin) * HS_C + cout]) * mul;
+        if (BF) {
+            const __bf16 hb = (__bf16)val;
+            wS[(long)v * 8 + j] = __builtin_bit_cast(_Float16, hl ? (__bf16)(val - (float)hb) : hb);
+            continue;
+        }
         const _Float16 hi = (_Float16)val;
         wS[(long)v * 8 + j] = hl ? (_Float16)(val - (float)hi) : hi;
     }
@@ -571,6 +595,17 @@ extern "C" int snk_conv3x3_prepare_weights_f16s(const float *d_w_hwio, void *d_w
     return 0;
 }
 
+// the weight image of the bf16 tower (snk_conv3x3_bn_bf16_act16): the same layout with bf16 parts, activation scale 1
+extern "C" int snk_conv3x3_prepare_weights_bf16(const float *d_w_hwio, void *d_wS, void *stream)
+{
+    SNK_REQUIRE(d_w_hwio && d_wS, "snk_conv3x3_prepare_weights_bf16: NULL argument");
+    float *tail = (float *)((_Float16 *)d_wS + HS_WS_ELEMS);
+    k_f16s_wscale<<<1, 1024, 0, (hipStream_t)stream>>>(d_w_hwio, tail, 1.0f);
+    k_f16s_weights<false, true><<<(HS_WS_ELEMS / 8 + 255) / 256, 256, 0, (hipStream_t)stream>>>(d_w_hwio, (_Float16 *)d_wS, tail);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // the training step's form: the input scale is read on the device from d_in_tail = { ., ., scale, 1 / scale } (what
 // snk_bn_train_apply / snk_bn_train_grad_apply measured while writing the tensor this layer reads); input_gradient != 0
 // lays out the kernel of the layer's input gradient (the same convolution with mirrored taps and swapped channel axes);
@@ -593,7 +628,7 @@ extern "C" int snk_conv3x3_prepare_weights_f16s_train(const float *d_w_hwio, voi
 static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
                             const float *d_residual, float *d_out, const float *d_w1x1, float s1, float b1, float *d_h1,
                             int n_images, int height, int width, int relu, bool split, void *stream, int io16 = 0,
-                            const float *d_center = nullptr, float *d_stat_part = nullptr, int *grid_out = nullptr)
+                            const float *d_center = nullptr, float *d_stat_part = nullptr, int *grid_out = nullptr, bool bf = false)
 {
     SNK_REQUIRE(n_images >= 0 && height >= 1 && width >= 3, "snk_conv3x3_bn_f16s: bad shape %d x %d x %d", n_images, height, width);
     SNK_REQUIRE(d_out != d_x, "snk_conv3x3_bn_f16s: in-place convolution is not possible (blocks read their neighbours' input rows)");
@@ -646,13 +681,17 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
     if (!split && io16) {        // f16 activations in HBM (io16: 1 = f16 in, f32 out; 3 = f16 in and out)
 #define HS_LAUNCH_IO(NI_)                                                                       \
     case NI_:                                                                                   \
-        if (io16 == 3) k_conv3x3_f16s<NI_, 0, false, 3><<<grid, 256, 0, st>>>(a);               \
+        if (bf && io16 == 3) k_conv3x3_f16s<NI_, 0, false, 3, true><<<grid, 256, 0, st>>>(a);   \
+        else if (bf) k_conv3x3_f16s<NI_, 0, false, 1, true><<<grid, 256, 0, st>>>(a);           \
+        else if (io16 == 3) k_conv3x3_f16s<NI_, 0, false, 3><<<grid, 256, 0, st>>>(a);          \
         else k_conv3x3_f16s<NI_, 0, false, 1><<<grid, 256, 0, st>>>(a);                         \
         break;
         switch (n_mt) {
             HS_LAUNCH_IO(1) HS_LAUNCH_IO(2) HS_LAUNCH_IO(3) HS_LAUNCH_IO(4) HS_LAUNCH_IO(5) HS_LAUNCH_IO(6) HS_LAUNCH_IO(7)
         default:
-            if (io16 == 3) k_conv3x3_f16s<8, 0, false, 3><<<grid, 256, 0, st>>>(a);
+            if (bf && io16 == 3) k_conv3x3_f16s<8, 0, false, 3, true><<<grid, 256, 0, st>>>(a);
+            else if (bf) k_conv3x3_f16s<8, 0, false, 1, true><<<grid, 256, 0, st>>>(a);
+            else if (io16 == 3) k_conv3x3_f16s<8, 0, false, 3><<<grid, 256, 0, st>>>(a);
             else k_conv3x3_f16s<8, 0, false, 1><<<grid, 256, 0, st>>>(a);
             break;
         }
@@ -844,7 +883,7 @@ extern "C" int snk_conv_rect_plan(const float *d_planes, float b0, float b1, flo
 static int conv_f16s_rect_launch(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
                                  const float *d_residual, float *d_out, const void *d_desc, const int *d_count,
                                  const float *d_bg_in, int grow_in, const float *d_bg_res, int grow_res, const float *d_bg_out,
-                                 int n_images, int height, int width, bool act16, void *stream)
+                                 int n_images, int height, int width, bool act16, void *stream, bool bf = false)
 {
     SNK_REQUIRE(grow_in >= 0 && grow_in < 128 && grow_res >= 0 && grow_res < 128, "snk_conv3x3_bn_f16s_rect: grow_in %d, grow_res %d", grow_in, grow_res);
     SNK_REQUIRE(d_x && d_wS && d_scale && d_shift && d_out && d_desc && d_count, "snk_conv3x3_bn_f16s_rect: NULL argument");
@@ -856,7 +895,10 @@ static int conv_f16s_rect_launch(const float *d_x, const void *d_wS, const float
     ConvHsArgs a = {d_x, (const f16x8 *)d_wS, (const float *)((const _Float16 *)d_wS + HS_WS_ELEMS), d_scale, d_shift,
                     d_residual, d_out, nullptr, nullptr, 0.f, 0.f, height, width, 1, 0, 0, 1, 0, nullptr, nullptr,
                     (const uint4 *)d_desc, d_count, d_bg_out, d_bg_in, d_residual ? d_bg_res : nullptr, grow_in, grow_res};
-    if (act16) {
+    if (act16 && bf) {
+        if (d_residual) k_conv3x3_f16s_rect<2, false, 3, true><<<(int)mb, 256, 0, (hipStream_t)stream>>>(a);
+        else k_conv3x3_f16s_rect<1, false, 3, true><<<(int)mb, 256, 0, (hipStream_t)stream>>>(a);
+    } else if (act16) {
         if (d_residual) k_conv3x3_f16s_rect<2, false, 3><<<(int)mb, 256, 0, (hipStream_t)stream>>>(a);
         else k_conv3x3_f16s_rect<1, false, 3><<<(int)mb, 256, 0, (hipStream_t)stream>>>(a);
     } else if (d_residual) k_conv3x3_f16s_rect<2><<<(int)mb, 256, 0, (hipStream_t)stream>>>(a);
@@ -884,6 +926,17 @@ extern "C" int snk_conv3x3_bn_f16_act16_rect(const void *d_x16, const void *d_wS
     return conv_f16s_rect_launch((const float *)d_x16, d_wS, d_scale, d_shift, (const float *)d_residual16, (float *)d_out16, d_desc,
                                  d_count, (const float *)d_bg_in16, grow_in, (const float *)d_bg_res16, grow_res,
                                  (const float *)d_bg_out16, n_images, height, width, true, stream);
+}
+
+// the same for the bf16 tower (bf16 activations in and out, bf16 background images, weights = snk_conv3x3_prepare_weights_bf16)
+extern "C" int snk_conv3x3_bn_bf16_act16_rect(const void *d_x16, const void *d_wS, const float *d_scale, const float *d_shift,
+                                              const void *d_residual16, void *d_out16, const void *d_desc, const int *d_count,
+                                              const void *d_bg_in16, int grow_in, const void *d_bg_res16, int grow_res,
+                                              const void *d_bg_out16, int n_images, int height, int width, void *stream)
+{
+    return conv_f16s_rect_launch((const float *)d_x16, d_wS, d_scale, d_shift, (const float *)d_residual16, (float *)d_out16, d_desc,
+                                 d_count, (const float *)d_bg_in16, grow_in, (const float *)d_bg_res16, grow_res,
+                                 (const float *)d_bg_out16, n_images, height, width, true, stream, true);
 }
 
 extern "C" int snk_conv3x3_bn_f16s(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
@@ -947,4 +1000,17 @@ extern "C" int snk_conv3x3_bn_f16_act16(const void *d_x16, const void *d_wS, con
     SNK_REQUIRE(d_x16 && d_wS && d_scale && d_shift && d_out, "snk_conv3x3_bn_f16_act16: NULL argument");
     return conv_f16s_launch((const float *)d_x16, d_wS, d_scale, d_shift, (const float *)d_residual16, (float *)d_out, nullptr, 0.f,
                             0.f, nullptr, n_images, height, width, relu, false, stream, out_f16 ? 3 : 1);
+}
+
+// BASELINE configs[4] as it is worded, "bf16 MFMA conv": bf16 activations in HBM (d_x16 / d_residual16: bf16 [n][H][W][128]; the
+// output is bf16, or float32 for the layer the head reads), bf16 weights (snk_conv3x3_prepare_weights_bf16), products on
+// v_mfma_f32_32x32x16_bf16, float32 accumulation, batch norm / shortcut / ReLU in float32.  The block body is hs_block: the same
+// staging, LDS image, fragment pipeline and epilogue as the f16-activation tower.
+extern "C" int snk_conv3x3_bn_bf16_act16(const void *d_x16, const void *d_wS, const float *d_scale, const float *d_shift,
+                                         const void *d_residual16, void *d_out, int out_bf16, int n_images, int height, int width,
+                                         int relu, void *stream)
+{
+    SNK_REQUIRE(d_x16 && d_wS && d_scale && d_shift && d_out, "snk_conv3x3_bn_bf16_act16: NULL argument");
+    return conv_f16s_launch((const float *)d_x16, d_wS, d_scale, d_shift, (const float *)d_residual16, (float *)d_out, nullptr, 0.f,
+                            0.f, nullptr, n_images, height, width, relu, false, stream, out_bf16 ? 3 : 1, nullptr, nullptr, nullptr, true);
 }

@@ -174,169 +174,6 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_conv3x3_f32(ConvArgs p)
 }
 
 // ------------------------------------------------------------------------------------------
-// bf16 form of the direct kernel (BASELINE.json configs[4]: "bf16 MFMA conv"; NOT the 1e-5 parity path):
-// same implicit GEMM and block tile, activations stay float32 in HBM (BN / residual / ReLU in float32), the two
-// operand tiles are rounded to bf16 on their way into LDS and multiplied by v_mfma_f32_32x32x16_bf16 with float32
-// accumulation: 16x the fp32 MFMA rate.  K chunk = 32 input channels of one tap = 2 MFMA k-steps; LDS rows are
-// 32 bf16 + 8 pad (80 bytes) so 16-lane ds_read_b128 groups are conflict free.  Weights are pre-rounded to bf16
-// once ([tap][cout][cin]).
-// ------------------------------------------------------------------------------------------
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef short bf16x4 __attribute__((ext_vector_type(4)));
-
-__device__ static inline unsigned short f32_to_bf16_rn(float f)
-{
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)((u >> 16) | 0x40);      // NaN stays NaN
-    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);                      // round to nearest even
-}
-
-struct ConvBf16Args {
-    const float *x;               // [M][128] float32 activations
-    const unsigned short *wT;     // [9][128 cout][128 cin] bf16
-    const float *scale, *shift, *res;
-    float *out;
-    int M, Hd, Wd, relu;
-};
-
-#define CB_BK 32
-#define CB_LD 40        // bf16 elements per LDS row (32 + 8 pad)
-
-__global__ __launch_bounds__(256, 4) void k_conv3x3_bf16(ConvBf16Args p)
-{
-    __shared__ __align__(16) unsigned short As[2][CV_BM][CB_LD];
-    __shared__ __align__(16) unsigned short Bs[2][CV_BN][CB_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm = wv & 1, wn = wv >> 1;
-    const int h = lane >> 5, l31 = lane & 31;
-    const int m0 = blockIdx.x * CV_BM;
-    const int HW = p.Hd * p.Wd;
-
-    // staging: A tile 128 rows x 32 float32 = 1 024 float4 -> 4 per thread (row tid / 8 + 32 i, float4 column tid % 8);
-    //          B tile 128 rows x 32 bf16 = 512 x 16 bytes -> 2 per thread (row tid / 4 + 64 i, 16-byte column tid % 4)
-    const int c4 = tid & 7, srow = tid >> 3;
-    const int bc = tid & 3, brow = tid >> 2;
-    int ay[4], ax[4];
-    const float *abase[4];
-    bool avalid[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + srow + 32 * i;
-        avalid[i] = m < p.M;
-        const int mm = avalid[i] ? m : 0;
-        const int rem = mm % HW;
-        ay[i] = rem / p.Wd;
-        ax[i] = rem - ay[i] * p.Wd;
-        abase[i] = p.x + (long)mm * CV_C + c4 * 4;
-    }
-    const unsigned short *bbase = p.wT + (long)brow * CV_C + bc * 8;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    float4 ra0, ra1, ra2, ra3;
-    uint4 rb0, rb1;
-    bool ok0 = false, ok1 = false, ok2 = false, ok3 = false;
-#define CB_LOADA(i, RA, OK)                                                                     \
-    {                                                                                           \
-        const int yy_ = ay[i] + dy_, xx_ = ax[i] + dx_;                                         \
-        OK = avalid[i] && yy_ >= 0 && yy_ < p.Hd && xx_ >= 0 && xx_ < p.Wd;                     \
-        RA = *(const float4 *)(abase[i] + (OK ? aoff_ : 0l) + cin0_);                           \
-    }
-#define CB_LOAD(c)                                                                              \
-    {                                                                                           \
-        const int tap_ = (c) % 9, cin0_ = ((c) / 9) * CB_BK;                                    \
-        const int dy_ = tap_ / 3 - 1, dx_ = tap_ - (tap_ / 3) * 3 - 1;                          \
-        const long aoff_ = (long)(dy_ * p.Wd + dx_) * CV_C;                                     \
-        CB_LOADA(0, ra0, ok0) CB_LOADA(1, ra1, ok1) CB_LOADA(2, ra2, ok2) CB_LOADA(3, ra3, ok3) \
-        rb0 = *(const uint4 *)(bbase + ((long)(tap_ * CV_C) * CV_C + cin0_));                   \
-        rb1 = *(const uint4 *)(bbase + ((long)(tap_ * CV_C + 64) * CV_C + cin0_));              \
-    }
-#define CB_STOREA(buf, i, RA, OK)                                                               \
-    {                                                                                           \
-        float4 v_ = RA;                                                                         \
-        if (!OK) v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                          \
-        bf16x4 q_;                                                                              \
-        q_[0] = (short)f32_to_bf16_rn(v_.x); q_[1] = (short)f32_to_bf16_rn(v_.y);               \
-        q_[2] = (short)f32_to_bf16_rn(v_.z); q_[3] = (short)f32_to_bf16_rn(v_.w);               \
-        *(bf16x4 *)&As[buf][srow + 32 * i][c4 * 4] = q_;                                        \
-    }
-#define CB_STORE(buf)                                                                           \
-    {                                                                                           \
-        CB_STOREA(buf, 0, ra0, ok0) CB_STOREA(buf, 1, ra1, ok1)                                 \
-        CB_STOREA(buf, 2, ra2, ok2) CB_STOREA(buf, 3, ra3, ok3)                                 \
-        *(uint4 *)&Bs[buf][brow][bc * 8] = rb0;                                                 \
-        *(uint4 *)&Bs[buf][brow + 64][bc * 8] = rb1;                                            \
-    }
-
-    CB_LOAD(0);
-    CB_STORE(0);
-    __syncthreads();
-
-    constexpr int NCHUNK = 9 * (CV_C / CB_BK);
-    for (int c = 0; c < NCHUNK; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < NCHUNK) CB_LOAD(c + 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < CB_BK / 16; ++ks) {
-            bf16x8 a[2], b[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {       // lane holds A[row l31][k = 8 h + j], B[k = 8 h + j][col l31], j = 0..7
-                a[t] = *(const bf16x8 *)&As[buf][wm * 64 + t * 32 + l31][ks * 16 + 8 * h];
-                b[t] = *(const bf16x8 *)&Bs[buf][wn * 64 + t * 32 + l31][ks * 16 + 8 * h];
-            }
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rt], b[ct], acc[rt][ct], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < NCHUNK) CB_STORE(buf ^ 1);
-        __syncthreads();
-    }
-#undef CB_LOADA
-#undef CB_LOAD
-#undef CB_STOREA
-#undef CB_STORE
-
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const int col = wn * 64 + ct * 32 + l31;
-        const float sc = p.scale[col], sh = p.shift[col];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int m = m0 + row;
-                if (m < p.M) {
-                    float v = acc[rt][ct][r] * sc + sh;
-                    if (p.res) v += p.res[(long)m * CV_C + col];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    p.out[(long)m * CV_C + col] = v;
-                }
-            }
-    }
-}
-
-// Keras kernel (kh, kw, cin, cout) float32 -> (tap, cout, cin) bf16
-__global__ void k_transpose_w_bf16(const float *__restrict__ w, unsigned short *__restrict__ wT)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 9 * CV_C * CV_C) return;
-    const int tap = i / (CV_C * CV_C), r = i - tap * CV_C * CV_C;
-    const int co = r / CV_C, ci = r - co * CV_C;
-    wT[i] = f32_to_bf16_rn(w[(long)(tap * CV_C + ci) * CV_C + co]);
-}
-
-// ------------------------------------------------------------------------------------------
 // Winograd F(2x2, 3x3) form of the same layer (fp32 throughout): Y = A^T [ (G g G^T) . (B^T d B) ] A.
 // 16 transformed positions p = (xi, nu), each a GEMM [tiles x 128 cin] x [128 cin x 128 cout] on
 // v_mfma_f32_32x32x2_f32: 16 * 121 * 128 * 128 MACs per 21x21 image instead of 441 * 9 * 128 * 128
@@ -656,7 +493,7 @@ __global__ __launch_bounds__(256) void k_stem_conv(StemArgs p)
 // (the gather of k_stem_conv costs as many instructions as its FMAs: 2.3 TB/s of output, round 1).  Thread
 // (pg = tid / 32, cq = tid % 32) computes outputs 4 cq .. 4 cq + 3 of pixels pg, pg + 8, ...; its 27 x 4 weights stay in
 // registers; the 32 lanes of a pixel write its 512-byte row.  Same tap order as k_stem_conv: identical sums.
-template <bool OUT16>          // OUT16: the output activations are written as f16 (the reduced-precision tower with f16 activations)
+template <int OUT16>           // OUT16: the output activations are written as f16 (1) or bf16 (2): the reduced-precision towers with 16-bit activations
 __global__ __launch_bounds__(256) void k_stem_conv_img(StemArgs p)
 {
     extern __shared__ __align__(16) float st_img[];
@@ -698,7 +535,12 @@ __global__ __launch_bounds__(256) void k_stem_conv_img(StemArgs p)
         float4 v;
         v.x = fmaxf(alo.x * sc.x + sh.x, 0.f); v.y = fmaxf(alo.y * sc.y + sh.y, 0.f);
         v.z = fmaxf(ahi.x * sc.z + sh.z, 0.f); v.w = fmaxf(ahi.y * sc.w + sh.w, 0.f);
-        if (OUT16) {
+        if (OUT16 == 2) {
+            typedef __bf16 st_bf16x4 __attribute__((ext_vector_type(4)));
+            st_bf16x4 o_;
+            o_[0] = (__bf16)v.x; o_[1] = (__bf16)v.y; o_[2] = (__bf16)v.z; o_[3] = (__bf16)v.w;    // v_cvt_pk_bf16_f32: round to nearest even
+            *(st_bf16x4 *)(out16 + (long)px * CV_C) = o_;
+        } else if (OUT16) {
             typedef _Float16 st_f16x4 __attribute__((ext_vector_type(4)));
             st_f16x4 o_;
             o_[0] = (_Float16)fminf(v.x, 65504.f); o_[1] = (_Float16)fminf(v.y, 65504.f);      // post-ReLU: saturate upwards only
@@ -724,7 +566,7 @@ __global__ __launch_bounds__(256) void k_stem_conv_img(StemArgs p)
 // the accumulators: for each accumulator register the two 32-lane halves write 128 contiguous bytes of two pixel rows.
 typedef _Float16 sm_f16x8 __attribute__((ext_vector_type(8)));
 typedef float sm_f32x16 __attribute__((ext_vector_type(16)));
-template <bool OUT16>
+template <int OUT16>
 __global__ __launch_bounds__(256) void k_stem_conv_mfma(StemArgs p)
 {
     extern __shared__ __align__(16) float st_img[];
@@ -863,7 +705,8 @@ __global__ __launch_bounds__(256) void k_stem_conv_mfma(StemArgs p)
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
                         const float v = fmaxf(__builtin_fmaf(acc[nt][r], scl[nt], shf[nt]), floor_);
-                        if (OUT16) out16[(long)row * CV_C + 32 * nt + l31] = (_Float16)fminf(v, 65504.f);
+                        if (OUT16 == 2) ((__bf16 *)out16)[(long)row * CV_C + 32 * nt + l31] = (__bf16)v;
+                        else if (OUT16) out16[(long)row * CV_C + 32 * nt + l31] = (_Float16)fminf(v, 65504.f);
                         else out[(long)row * CV_C + 32 * nt + l31] = v;
                     }
                 }
@@ -1018,29 +861,6 @@ extern "C" int snk_conv3x3_bn_f32(const float *d_x, const float *d_wT, const flo
 
 
 
-extern "C" int snk_conv3x3_prepare_weights_bf16(const float *d_w_hwio, void *d_wT_bf16, void *stream)
-{
-    SNK_REQUIRE(d_w_hwio && d_wT_bf16, "snk_conv3x3_prepare_weights_bf16: NULL argument");
-    k_transpose_w_bf16<<<(9 * CV_C * CV_C + 255) / 256, 256, 0, (hipStream_t)stream>>>(d_w_hwio, (unsigned short *)d_wT_bf16);
-    SNK_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
-extern "C" int snk_conv3x3_bn_bf16(const float *d_x, const void *d_wT_bf16, const float *d_scale, const float *d_shift,
-                                   const float *d_residual, float *d_out, int n_images, int height, int width, int relu,
-                                   void *stream)
-{
-    SNK_REQUIRE(d_x && d_wT_bf16 && d_scale && d_shift && d_out, "snk_conv3x3_bn_bf16: NULL argument");
-    SNK_REQUIRE(d_out != d_x, "snk_conv3x3_bn_bf16: in-place convolution is not possible");
-    if (n_images <= 0) return 0;
-    const long M = (long)n_images * height * width;
-    SNK_REQUIRE(M < (1l << 31), "snk_conv3x3_bn_bf16: batch of %d images too large for one call", n_images);
-    ConvBf16Args a = {d_x, (const unsigned short *)d_wT_bf16, d_scale, d_shift, d_residual, d_out, (int)M, height, width, relu};
-    k_conv3x3_bf16<<<(int)((M + CV_BM - 1) / CV_BM), 256, 0, (hipStream_t)stream>>>(a);
-    SNK_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
 extern "C" int snk_conv3x3_prepare_weights_winograd(const float *d_w_hwio, float *d_U, void *stream)
 {
     SNK_REQUIRE(d_w_hwio && d_U, "snk_conv3x3_prepare_weights_winograd: NULL argument");
@@ -1071,7 +891,7 @@ extern "C" int snk_conv3x3_bn_f32_winograd(const float *d_x, const float *d_U, c
 
 // images a block of k_stem_conv_mfma takes per iteration (their padded float32 copies share the 64 KB of dynamic LDS), and the
 // launch that goes with it; SNK_STEM_GROUP=1 restores one image per iteration (A/B runs)
-template <bool OUT16>
+template <int OUT16>
 static void stem_mfma_launch(StemArgs a, int n_images, size_t lds_one, int max_grid, hipStream_t st)
 {
     static const int group_max = getenv("SNK_STEM_GROUP") ? max(1, min(4, atoi(getenv("SNK_STEM_GROUP")))) : 4;
@@ -1093,8 +913,8 @@ extern "C" int snk_stem_conv_bn_relu_f32(const float *d_x, const float *d_w, con
     // default: the MFMA form on 512 persistent blocks (2 resident per CU); SNK_STEM=valu selects the packed-FMA form
     static const int stem_grid = getenv("SNK_STEM_GRID") ? atoi(getenv("SNK_STEM_GRID")) : 512;
     static const int stem_valu = getenv("SNK_STEM") ? !strcmp(getenv("SNK_STEM"), "valu") : 0;
-    if (lds <= 64 * 1024 && !stem_valu) stem_mfma_launch<false>(a, n_images, lds, stem_grid, (hipStream_t)stream);
-    else if (lds <= 64 * 1024) k_stem_conv_img<false><<<min(n_images, 768), 256, lds, (hipStream_t)stream>>>(a);
+    if (lds <= 64 * 1024 && !stem_valu) stem_mfma_launch<0>(a, n_images, lds, stem_grid, (hipStream_t)stream);
+    else if (lds <= 64 * 1024) k_stem_conv_img<0><<<min(n_images, 768), 256, lds, (hipStream_t)stream>>>(a);
     else k_stem_conv<<<(int)((M + ST_PX - 1) / ST_PX), 256, 0, (hipStream_t)stream>>>(a);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
@@ -1113,26 +933,43 @@ extern "C" int snk_stem_conv_bn_relu_f32_rect(const float *d_x, const float *d_w
     const size_t lds = (size_t)(height + 2) * (width + 2) * 3 * sizeof(float);
     SNK_REQUIRE(lds <= 64 * 1024 && height <= 255 && width <= 255, "snk_stem_conv_bn_relu_f32_rect: observation %d x %d too large", height, width);
     StemArgs a = {d_x, d_w, d_scale, d_shift, d_out, (int)M, height, width, 0, (const unsigned *)d_bbox, grow};
-    stem_mfma_launch<false>(a, n_images, lds, 512, (hipStream_t)stream);
+    stem_mfma_launch<0>(a, n_images, lds, 512, (hipStream_t)stream);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
-// the same with the output written as f16 (the f16-activation tower, snk_conv3x3_bn_f16_act16_rect)
+// the same with the output written as f16 / bf16 (the towers with 16-bit activations: snk_conv3x3_bn_f16_act16_rect, _bf16_act16_rect)
+static int stem_out16_launch(const char *who, int bf, const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,
+                             void *d_out16, const void *d_bbox, int grow, int n_images, int height, int width, void *stream)
+{
+    SNK_REQUIRE(d_x && d_w && d_scale && d_shift && d_out16, "%s: NULL argument", who);
+    SNK_REQUIRE(!d_bbox || (grow >= 1 && grow < 128 && height <= 255 && width <= 255), "%s: bad rectangle arguments", who);
+    if (n_images <= 0) return 0;
+    const long M = (long)n_images * height * width;
+    SNK_REQUIRE(M < (1l << 31), "%s: batch too large", who);
+    const size_t lds = (size_t)(height + 2) * (width + 2) * 3 * sizeof(float);
+    SNK_REQUIRE(lds <= 64 * 1024, "%s: observation %d x %d too large", who, height, width);
+    StemArgs a = {d_x, d_w, d_scale, d_shift, (float *)d_out16, (int)M, height, width, 0, (const unsigned *)d_bbox, d_bbox ? grow : 0};
+    if (bf) stem_mfma_launch<2>(a, n_images, lds, 512, (hipStream_t)stream);
+    else stem_mfma_launch<1>(a, n_images, lds, 512, (hipStream_t)stream);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" int snk_stem_conv_bn_relu_f16out_rect(const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,
                                                  void *d_out16, const void *d_bbox, int grow, int n_images, int height, int width,
                                                  void *stream)
 {
-    SNK_REQUIRE(d_x && d_w && d_scale && d_shift && d_out16 && d_bbox && grow >= 1 && grow < 128, "snk_stem_conv_bn_relu_f16out_rect: bad argument");
-    if (n_images <= 0) return 0;
-    const long M = (long)n_images * height * width;
-    SNK_REQUIRE(M < (1l << 31), "snk_stem_conv_bn_relu_f16out_rect: batch too large");
-    const size_t lds = (size_t)(height + 2) * (width + 2) * 3 * sizeof(float);
-    SNK_REQUIRE(lds <= 64 * 1024 && height <= 255 && width <= 255, "snk_stem_conv_bn_relu_f16out_rect: observation %d x %d too large", height, width);
-    StemArgs a = {d_x, d_w, d_scale, d_shift, (float *)d_out16, (int)M, height, width, 0, (const unsigned *)d_bbox, grow};
-    stem_mfma_launch<true>(a, n_images, lds, 512, (hipStream_t)stream);
-    SNK_CHECK_HIP(hipGetLastError());
-    return 0;
+    SNK_REQUIRE(d_bbox, "snk_stem_conv_bn_relu_f16out_rect: NULL bounding boxes");
+    return stem_out16_launch("snk_stem_conv_bn_relu_f16out_rect", 0, d_x, d_w, d_scale, d_shift, d_out16, d_bbox, grow, n_images, height, width, stream);
+}
+
+extern "C" int snk_stem_conv_bn_relu_bf16out_rect(const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,
+                                                  void *d_out16, const void *d_bbox, int grow, int n_images, int height, int width,
+                                                  void *stream)
+{
+    SNK_REQUIRE(d_bbox, "snk_stem_conv_bn_relu_bf16out_rect: NULL bounding boxes");
+    return stem_out16_launch("snk_stem_conv_bn_relu_bf16out_rect", 1, d_x, d_w, d_scale, d_shift, d_out16, d_bbox, grow, n_images, height, width, stream);
 }
 
 // the bare stem convolution (training step: the batch statistics of its output come first, train.hip)
@@ -1145,25 +982,22 @@ extern "C" int snk_stem_conv_f32(const float *d_x, const float *d_w, float *d_ou
     const size_t lds = (size_t)(height + 2) * (width + 2) * 3 * sizeof(float);
     SNK_REQUIRE(lds <= 64 * 1024, "snk_stem_conv_f32: observation %d x %d too large", height, width);
     StemArgs a = {d_x, d_w, nullptr, nullptr, d_out, (int)M, height, width, 1};
-    stem_mfma_launch<false>(a, n_images, lds, 512, (hipStream_t)stream);
+    stem_mfma_launch<0>(a, n_images, lds, 512, (hipStream_t)stream);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
-// the same with the output written as f16 [n][H][W][128] (input of snk_conv3x3_bn_f16_act16)
+// the whole-canvas stem with the output written as f16 / bf16 [n][H][W][128] (input of snk_conv3x3_bn_f16_act16 / _bf16_act16)
 extern "C" int snk_stem_conv_bn_relu_f16out(const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,
                                             void *d_out16, int n_images, int height, int width, void *stream)
 {
-    SNK_REQUIRE(d_x && d_w && d_scale && d_shift && d_out16, "snk_stem_conv_bn_relu_f16out: NULL argument");
-    if (n_images <= 0) return 0;
-    const long M = (long)n_images * height * width;
-    SNK_REQUIRE(M < (1l << 31), "snk_stem_conv_bn_relu_f16out: batch too large");
-    const size_t lds = (size_t)(height + 2) * (width + 2) * 3 * sizeof(float);
-    SNK_REQUIRE(lds <= 64 * 1024, "snk_stem_conv_bn_relu_f16out: observation %d x %d too large", height, width);
-    StemArgs a = {d_x, d_w, d_scale, d_shift, (float *)d_out16, (int)M, height, width};
-    stem_mfma_launch<true>(a, n_images, lds, 512, (hipStream_t)stream);
-    SNK_CHECK_HIP(hipGetLastError());
-    return 0;
+    return stem_out16_launch("snk_stem_conv_bn_relu_f16out", 0, d_x, d_w, d_scale, d_shift, d_out16, nullptr, 0, n_images, height, width, stream);
+}
+
+extern "C" int snk_stem_conv_bn_relu_bf16out(const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,
+                                             void *d_out16, int n_images, int height, int width, void *stream)
+{
+    return stem_out16_launch("snk_stem_conv_bn_relu_bf16out", 1, d_x, d_w, d_scale, d_shift, d_out16, nullptr, 0, n_images, height, width, stream);
 }
 
 extern "C" int snk_head_f32(const float *d_x, const float *d_w1x1, float bn_scale, float bn_shift, const float *d_fc1_w,

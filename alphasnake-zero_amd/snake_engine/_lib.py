@@ -58,7 +58,10 @@ PROTOTYPES = {
     "snk_conv3x3_prepare_weights": (i32, [vp, vp, vp]),
     "snk_conv3x3_bn_f32": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "snk_conv3x3_prepare_weights_bf16": (i32, [vp, vp, vp]),
-    "snk_conv3x3_bn_bf16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "snk_conv3x3_bn_bf16_act16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "snk_conv3x3_bn_bf16_act16_rect": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, i32, i32, i32, vp]),
+    "snk_stem_conv_bn_relu_bf16out": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "snk_stem_conv_bn_relu_bf16out_rect": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "snk_conv3x3_prepare_weights_winograd": (i32, [vp, vp, vp]),
     "snk_conv3x3_bn_f32_winograd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "snk_conv3x3_prepare_weights_f16s": (i32, [vp, vp, C.c_float, vp]),

@@ -136,15 +136,17 @@ class QNet:
         self.clock_probe = None      # set to a ClockProbe to sample the chip's clock beside every forward chunk
         # "f16s" (default): float32-accurate split-f16 MFMA kernel (csrc/conv_split.hip); "winograd": F(2x2,3x3) fp32 MFMA
         # kernel; "direct": implicit-GEMM fp32 MFMA kernel; reduced precision for configs[4], NOT within the 1e-5 parity
-        # tolerance: "f16" (the f16s kernel with the hi parts only, one MFMA per product) and "bf16" (im2col bf16 MFMA)
+        # tolerance: "f16" (the f16s kernel with the hi parts only, one MFMA per product, float32 activations)
         self.conv_algo = os.environ.get("SNK_CONV_ALGO", "f16s")
         # "f16a": "f16" with the tower's activations stored as f16 in HBM (half the traffic; the f16 form with float32
-        # activations is HBM-bound): the fastest reduced-precision option, for BASELINE configs[4]
+        # activations is HBM-bound); "bf16": the same block body on bf16 -- bf16 activations in HBM, bf16 weights,
+        # v_mfma_f32_32x32x16_bf16: BASELINE configs[4]'s "bf16 MFMA conv" as it is worded
         if self.conv_algo not in ("f16s", "winograd", "direct", "bf16", "f16", "f16a"):
             raise EngineError(f"SNK_CONV_ALGO={self.conv_algo!r}: expected f16s, winograd, direct, f16, f16a or bf16")
         # sub-rectangle form of the first tower layers (snk_conv3x3_bn_f16s_rect): SNK_CONV_RECT=0 switches it off,
         # SNK_CONV_RECT_LAYERS=n fixes the number of layers that use it
-        self.rect = self.conv_algo in ("f16s", "f16a") and os.environ.get("SNK_CONV_RECT", "1") != "0"
+        self.rect = self.conv_algo in ("f16s", "f16a", "bf16") and os.environ.get("SNK_CONV_RECT", "1") != "0"
+        self.act16 = {"f16a": torch.float16, "bf16": torch.bfloat16}.get(self.conv_algo)      # 16-bit activations in HBM
         self.background = BACKGROUND_PIXEL
         self.guard_trips = 0         # batches forward_guarded evaluated again after a clamp
         self.rect_tiles = None       # set to [] to collect every chunk's (images, per-layer GEMM tiles) device tensors
@@ -186,7 +188,7 @@ class QNet:
         # the split-f16 weight images of all layers are rows of ONE buffer, so that the layers' range flags (a word in each
         # image's tail) come to the host with one strided copy (range_flags)
         self._wimg = None
-        if self.conv_algo in ("f16s", "f16", "f16a") and self.blocks:
+        if self.conv_algo in ("f16s", "f16", "f16a", "bf16") and self.blocks:
             self._wimg = torch.empty((2 * self.blocks, F16S_WEIGHT_BYTES), dtype=torch.uint8, device=dev)
             self._flags_host = torch.empty((2 * self.blocks,), dtype=torch.int32).pin_memory()
             if self._guard is None:      # the host-mapped word every layer of this net reports a clamp to (forward_guarded)
@@ -196,7 +198,8 @@ class QNet:
         for i in range(2 * self.blocks):
             base = 5 + 5 * i
             if self.conv_algo == "bf16":
-                wT = torch.empty(9 * 128 * 128, dtype=torch.int16, device=dev)
+                self.conv_x_scale[i] = 1.0
+                wT = self._wimg[i]
                 check(self.L.snk_conv3x3_prepare_weights_bf16(t[base].contiguous().data_ptr(), wT.data_ptr(), st))
             elif self.conv_algo in ("f16s", "f16", "f16a"):
                 if self.conv_algo == "f16a":
@@ -210,7 +213,7 @@ class QNet:
             else:
                 wT = torch.empty(9 * 128 * 128, dtype=torch.float32, device=dev)
                 check(self.L.snk_conv3x3_prepare_weights(t[base].contiguous().data_ptr(), wT.data_ptr(), st))
-            if self._wimg is not None:
+            if self._wimg is not None and self.conv_algo != "bf16":
                 check(self.L.snk_conv3x3_f16s_set_guard_word(wT.data_ptr(), self._guard[1], st))
             sc, sh = fold(*t[base + 1:base + 5])
             self.conv_wT.append(wT); self.conv_sc.append(sc); self.conv_sh.append(sh)
@@ -359,15 +362,25 @@ class QNet:
             main.wait_stream(sd)
         return out
 
+    def _fn16(self):
+        """(stem, stem on rectangles, layer, layer on rectangles) of the tower with 16-bit activations"""
+        L = self.L
+        if self.conv_algo == "bf16":
+            return (L.snk_stem_conv_bn_relu_bf16out, L.snk_stem_conv_bn_relu_bf16out_rect, L.snk_conv3x3_bn_bf16_act16,
+                    L.snk_conv3x3_bn_bf16_act16_rect)
+        return (L.snk_stem_conv_bn_relu_f16out, L.snk_stem_conv_bn_relu_f16out_rect, L.snk_conv3x3_bn_f16_act16,
+                L.snk_conv3x3_bn_f16_act16_rect)
+
     def _forward_chunk_f16a(self, planes, mask, out, s0, m, k):
-        """the tower with f16 activations in HBM: stem -> f16, every layer f16 -> f16, the last one f16 -> float32"""
+        """the tower with f16 / bf16 activations in HBM: stem -> 16 bit, every layer 16 -> 16 bit, the last one 16 bit -> float32"""
         st = torch.cuda.current_stream().cuda_stream
         L, h, w = self.L, self.h, self.w
+        stem16, stem16_rect, conv16, conv16_rect = self._fn16()
         key = ("a16", k)
         if self._ws is None:
             self._ws = {}
         if key not in self._ws or self._ws[key][0].shape[0] < m:
-            bufs = [torch.empty((m, h, w, 128), dtype=torch.float16, device=self.device) for _ in range(3)]
+            bufs = [torch.empty((m, h, w, 128), dtype=self.act16, device=self.device) for _ in range(3)]
             bufs.append(torch.empty((m, h, w, 128), dtype=torch.float32, device=self.device))
             self._ws[key] = bufs
         bufs = self._ws[key]
@@ -375,11 +388,11 @@ class QNet:
         x = planes[s0:s0 + m]
         plan = self._rect_plan(x, m, k, st) if self._use_rect(m) else None
         if plan is not None and self.n_rect >= 2:
-            check(L.snk_stem_conv_bn_relu_f16out_rect(x.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(),
-                                                      self.stem_sh.data_ptr(), a.data_ptr(), plan[3].data_ptr(), 1, m, h, w, st))
+            check(stem16_rect(x.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(),
+                              self.stem_sh.data_ptr(), a.data_ptr(), plan[3].data_ptr(), 1, m, h, w, st))
         else:
-            check(L.snk_stem_conv_bn_relu_f16out(x.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(),
-                                                 self.stem_sh.data_ptr(), a.data_ptr(), m, h, w, st))
+            check(stem16(x.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(),
+                         self.stem_sh.data_ptr(), a.data_ptr(), m, h, w, st))
         cur, t1, t2 = a, b, c
         tm = self.conv_timing
 
@@ -388,13 +401,13 @@ class QNet:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(torch.cuda.current_stream())
             if plan is not None and i < self.n_rect:       # a sub-rectangle layer is never the last one: f16 output
-                check(L.snk_conv3x3_bn_f16_act16_rect(xin.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
-                                                      self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),
-                                                      dst.data_ptr(), *self._rect_args(i, plan, res), m, h, w, st))
+                check(conv16_rect(xin.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
+                                  self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),
+                                  dst.data_ptr(), *self._rect_args(i, plan, res), m, h, w, st))
             else:
-                check(L.snk_conv3x3_bn_f16_act16(xin.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
-                                                 self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),
-                                                 dst.data_ptr(), int(out_f16), m, h, w, 1, st))
+                check(conv16(xin.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
+                             self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),
+                             dst.data_ptr(), int(out_f16), m, h, w, 1, st))
             if tm is not None:
                 e1.record(torch.cuda.current_stream())
                 tm.append((e0, e1, 2.0 * m * h * w * 9 * 128 * 128))
@@ -413,7 +426,7 @@ class QNet:
     def _forward_chunk(self, planes, mask, out, s0, m, k):
         if self.clock_probe is not None:          # bench.py: a one-wavefront clock sample beside this chunk's kernels
             self.clock_probe.launch()
-        if self.conv_algo == "f16a" and self.blocks > 0:
+        if self.act16 is not None and self.blocks > 0:
             return self._forward_chunk_f16a(planes, mask, out, s0, m, k)
         st = torch.cuda.current_stream().cuda_stream
         L, h, w = self.L, self.h, self.w
@@ -461,11 +474,11 @@ class QNet:
         scale change."""
         if self._bg is None:
             m, st = 1, torch.cuda.current_stream().cuda_stream
-            a16 = self.conv_algo == "f16a"
-            dt = torch.float16 if a16 else torch.float32
+            a16 = self.act16 is not None
+            dt = self.act16 if a16 else torch.float32
             blank = torch.tensor(self.background, dtype=torch.float32, device=self.device).repeat(1, self.h, self.w, 1).contiguous()
             bufs = [torch.empty((1, self.h, self.w, 128), dtype=dt, device=self.device) for _ in range(3)]
-            stem = self.L.snk_stem_conv_bn_relu_f16out if a16 else self.L.snk_stem_conv_bn_relu_f32
+            stem = self._fn16()[0] if a16 else self.L.snk_stem_conv_bn_relu_f32
             check(stem(blank.data_ptr(), self.stem_w.data_ptr(), self.stem_sc.data_ptr(), self.stem_sh.data_ptr(),
                        bufs[0].data_ptr(), m, self.h, self.w, st))
             bg = torch.empty((1 + self.n_rect, self.h, self.w, 128), dtype=dt, device=self.device)
@@ -475,9 +488,9 @@ class QNet:
 
             def conv(i, x, res, out):
                 if a16:
-                    check(self.L.snk_conv3x3_bn_f16_act16(x.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
-                                                          self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),
-                                                          out.data_ptr(), 1, m, self.h, self.w, 1, st))
+                    check(self._fn16()[2](x.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
+                                          self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),
+                                          out.data_ptr(), 1, m, self.h, self.w, 1, st))
                 else:
                     self._conv(i, x, res, out, m, st)
             for i in range(self.n_rect):
@@ -551,7 +564,7 @@ class QNet:
                 e1.record(torch.cuda.current_stream())
                 tm.append((e0, e1, 2.0 * m * self.h * self.w * 9 * 128 * 128))
             return
-        fn = {"winograd": self.L.snk_conv3x3_bn_f32_winograd, "bf16": self.L.snk_conv3x3_bn_bf16,
+        fn = {"winograd": self.L.snk_conv3x3_bn_f32_winograd,
               "f16s": self.L.snk_conv3x3_bn_f16s, "f16": self.L.snk_conv3x3_bn_f16}.get(
             self.conv_algo, self.L.snk_conv3x3_bn_f32)
         check(fn(x.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),

@@ -282,7 +282,7 @@ def main():
     ap.add_argument("--breadth", type=int, default=50)
     ap.add_argument("--chunk", type=int, default=8192, help="states per net forward chunk")
     ap.add_argument("--conv-algo", choices=["winograd", "direct", "bf16", "f16s", "f16", "f16a"], default=None,
-                    help="default: f16s (float32-accurate split-f16 MFMA, the judged configuration); winograd, direct: f32 MFMA; bf16 = configs[4]-style bf16 MFMA, outside the 1e-5 tolerance")
+                    help="default: f16s (float32-accurate split-f16 MFMA, the judged configuration); winograd, direct: f32 MFMA; f16 / f16a / bf16: reduced precision for configs[4] (bf16 = bf16 activations in HBM + v_mfma_f32_32x32x16_bf16), outside the 1e-5 tolerance")
     ap.add_argument("--conv-rect", choices=["0", "1"], default=None,
                     help="0: every tower layer convolves the whole canvas (the A/B arm of the sub-rectangle form; env SNK_CONV_RECT)")
     ap.add_argument("--board", type=int, default=11, choices=[7, 11, 19], help="board side; 19 with --snakes 8 --blocks 10 = BASELINE configs[4]")
@@ -481,7 +481,7 @@ def main():
             "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if args.games_total is not None else "weak", "vs_baseline": None,
-            "dtype": {"bf16": "bf16 operands, f32 accumulate (outside the 1e-5 parity tolerance)",
+            "dtype": {"bf16": "bf16 operands and bf16 activations in HBM, f32 accumulate (outside the 1e-5 parity tolerance)",
                       "f16": "f16 operands, f32 accumulate (outside the 1e-5 parity tolerance)",
                       "f16a": "f16 operands and f16 activations in HBM, f32 accumulate (outside the 1e-5 parity tolerance)",
                       "f16s": "f32 (tower convolutions: each f32 operand split into f16 hi + lo, 3 f16 MFMAs per product, f32 accumulate)"}.get(algo, "f32"),
@@ -496,7 +496,7 @@ def main():
                        "net_evals_per_env_step": evals / max(1, env_steps_rank0), "sim_steps_per_env_step": sims / max(1, env_steps_rank0),
                        "net_evals_per_s_rank0": evals / dt, "sample_rows_gathered": int(Xg.shape[0])},
             "roofline": {"bound": "mfma",
-                         "kernel": {"winograd": "k_conv3x3_wino_f32", "bf16": "k_conv3x3_bf16",
+                         "kernel": {"winograd": "k_conv3x3_wino_f32", "bf16": "k_conv3x3_f16s<SPLIT = false, IO16, BF = true>" + (" + its sub-rectangle form" if rect else ""),
                                     "f16s": "k_conv3x3_f16s" + (" + k_conv3x3_f16s_rect (the same body on sub-rectangles)" if rect else ""),
                                     "f16": "k_conv3x3_f16s<SPLIT = false>",
                                     "f16a": "k_conv3x3_f16s<SPLIT = false, IO16>"}.get(algo, "k_conv3x3_f32"),
@@ -507,7 +507,7 @@ def main():
                          "executed_frac": achieved / peak * executed if achieved else None,
                          "algorithm": {"winograd": "Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: executes 16*121/(441*9) = 0.488 of the "
                                                    "algorithmic flops, fp32 throughout",
-                                       "bf16": "implicit GEMM on v_mfma_f32_32x32x16_bf16",
+                                       "bf16": "implicit GEMM on v_mfma_f32_32x32x16_bf16 (the split kernel's block body), bf16 operands, bf16 activations in HBM (reduced precision)",
                                        "f16": "implicit GEMM on v_mfma_f32_32x32x16_f16, f16-rounded operands (reduced precision)",
                                        "f16a": "implicit GEMM on v_mfma_f32_32x32x16_f16, f16 operands, f16 activations in HBM (reduced precision)",
                                        "f16s": "implicit GEMM on v_mfma_f32_32x32x16_f16 with split operands: 3 MFMAs (hi*hi, hi*lo, lo*hi) per "

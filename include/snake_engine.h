@@ -160,13 +160,6 @@ int snk_conv3x3_prepare_weights(const float *d_w_hwio, float *d_wT, void *stream
 int snk_conv3x3_bn_f32(const float *d_x, const float *d_wT, const float *d_scale, const float *d_shift,
                        const float *d_residual, float *d_out, int n_images, int height, int width,
                        int relu, void *stream);
-/* bf16 form (BASELINE.json configs[4], "bf16 MFMA conv"; NOT the 1e-5 parity path): float32 activations in HBM,
- * operands rounded to bf16 on the way into LDS, v_mfma_f32_32x32x16_bf16 with float32 accumulation.
- * d_wT_bf16: uint16[9*128*128] (tap, cout, cin) from snk_conv3x3_prepare_weights_bf16. */
-int snk_conv3x3_prepare_weights_bf16(const float *d_w_hwio, void *d_wT_bf16, void *stream);
-int snk_conv3x3_bn_bf16(const float *d_x, const void *d_wT_bf16, const float *d_scale, const float *d_shift,
-                        const float *d_residual, float *d_out, int n_images, int height, int width, int relu,
-                        void *stream);
 /* The same layer in Winograd F(2x2,3x3) form (fp32 throughout, 2.05x fewer MFMA flops on 21x21 images):
  * snk_conv3x3_prepare_weights_winograd: Keras kernel (3,3,128,128) -> U = G g G^T laid out
  *   [16 positions][cin/4][cout][4] (float[16*128*128], evaluated in float64, stored float32). */
@@ -262,6 +255,27 @@ int snk_conv3x3_bn_f16_act16(const void *d_x16, const void *d_wS, const float *d
                              int relu, void *stream);
 int snk_stem_conv_bn_relu_f16out(const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,
                                  void *d_out16, int n_images, int height, int width, void *stream);
+/* BASELINE.json configs[4] AS IT IS WORDED -- "bf16 MFMA conv" (outside the 1e-5 tolerance, never the default): the same block
+ * body instantiated for bf16.  Activations are bf16 [n][H][W][128] arrays in HBM (d_x16 / d_residual16; the output is bf16 when
+ * out_bf16 != 0, float32 for the layer the head reads), weights are bf16 in the split image's layout
+ * (snk_conv3x3_prepare_weights_bf16: SNK_CONV_F16S_WEIGHT_BYTES bytes, hi parts used), products run on
+ * v_mfma_f32_32x32x16_bf16 with float32 accumulation; batch norm, shortcut and ReLU in float32.  bf16 has float32's exponent
+ * range: no activation scale, no clamp, no range flag.  snk_stem_conv_bn_relu_bf16out is the stem that feeds it; the
+ * sub-rectangle forms (_rect) take bf16 background images.  (Rounds 1-3 had an im2col kernel with float32 activations under
+ * the name snk_conv3x3_bn_bf16: 0.17 of the MFMA peak; retired in round 4.) */
+int snk_conv3x3_prepare_weights_bf16(const float *d_w_hwio, void *d_wS, void *stream);
+int snk_conv3x3_bn_bf16_act16(const void *d_x16, const void *d_wS, const float *d_scale, const float *d_shift,
+                              const void *d_residual16, void *d_out, int out_bf16, int n_images, int height, int width,
+                              int relu, void *stream);
+int snk_conv3x3_bn_bf16_act16_rect(const void *d_x16, const void *d_wS, const float *d_scale, const float *d_shift,
+                                   const void *d_residual16, void *d_out16, const void *d_desc, const int *d_count,
+                                   const void *d_bg_in16, int grow_in, const void *d_bg_res16, int grow_res,
+                                   const void *d_bg_out16, int n_images, int height, int width, void *stream);
+int snk_stem_conv_bn_relu_bf16out(const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,
+                                  void *d_out16, int n_images, int height, int width, void *stream);
+int snk_stem_conv_bn_relu_bf16out_rect(const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,
+                                       void *d_out16, const void *d_bbox, int grow, int n_images, int height, int width,
+                                       void *stream);
 int snk_head_dense_f32(const float *d_h1, const float *d_fc1_w, const float *d_fc1_b, const float *d_fc2_w,
                        const float *d_fc2_b, const uint8_t *d_mask, float *d_q, int n_images, int height, int width,
                        void *stream);

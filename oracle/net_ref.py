@@ -14,7 +14,7 @@ import torch.nn.functional as F
 BN_EPS = 1e-3
 
 
-def forward(weights, states, legacy_mask=False, apply_mask=True, bf16_conv=False, f16_act=False):
+def forward(weights, states, legacy_mask=False, apply_mask=True, bf16_conv=False, f16_act=False, bf16_act=False):
     """weights: list in Keras get_weights() order (snake_engine/net.py docstring); states (N,h,w,3) float32.
     Returns (N,3) float32 numpy: AlphaNNet.v(states)."""
     x_np = np.ascontiguousarray(states, np.float32)
@@ -29,10 +29,14 @@ def forward(weights, states, legacy_mask=False, apply_mask=True, bf16_conv=False
 
     def bn(x, g, b, m, v):
         return F.batch_norm(x, m, v, g, b, training=False, eps=BN_EPS)
-    def r16(v):      # f16_act: the tower's activations live in HBM as f16 (round to nearest even), the last layer's output stays float32
+    def r16(v):      # f16_act / bf16_act: the tower's activations live in HBM as f16 / bf16 (round to nearest even), the last layer's output stays float32
+        if bf16_act:
+            return v.to(torch.bfloat16).to(torch.float32)
         return v.to(torch.float16).to(torch.float32) if f16_act else v
 
     def conv16(x, k):   # ... and the tower convolutions take f16-rounded weights (scaled by the power of two that brings max|w| to [256, 512))
+        if bf16_act:    # bf16 weights (a power-of-two scale does not move a bf16 rounding), the activations are bf16 numbers already
+            return conv(x, k.to(torch.bfloat16).to(torch.float32))
         if not f16_act:
             return conv(x, k, bf16_conv)
         sc_ = 2.0 ** (8 - int(np.floor(np.log2(float(k.abs().max())))))

@@ -319,42 +319,77 @@ def test_f16_reduced_precision_layer_and_net(env, monkeypatch):
 
 
 def test_bf16_conv_layer_and_net(env, monkeypatch):
-    """configs[4] ("bf16 MFMA conv"): operands rounded to bf16, float32 accumulation.  Against a float64 reference
-    computed from the SAME bf16-rounded operands the layer is exact to float32 rounding; the whole 10-block 19x19 net
-    is compared with the CPU restatement that rounds the conv operands the same way (tolerance 1e-3: over 20 layers bf16
-    rounding of slightly different float32 activations flips last bits) and stays within 5e-2 of the float32 net."""
+    """configs[4] as BASELINE.json words it, "bf16 MFMA conv" (`SNK_CONV_ALGO=bf16`): the tower's block body (hs_block)
+    instantiated for bf16 -- bf16 activations in HBM, bf16 weights, v_mfma_f32_32x32x16_bf16, float32 accumulation and epilogue.
+    One layer against a float64 convolution of the SAME bf16 operands, at 21x21 and 37x37 (float32 output: float32 rounding;
+    bf16 output: that result rounded once); the whole nets (11x11 / 4 blocks in chunks, 19x19 / 10 blocks; full and
+    sub-rectangle forms) against the CPU restatement with the same rounding points (oracle/net_ref.py bf16_act=True)."""
     torch, se, net = env
     from snake_engine._lib import lib, check
+    from snake_engine.net import F16S_WEIGHT_BYTES
     from oracle import net_ref
     L = lib()
     g = torch.Generator().manual_seed(11)
-    n, hw = 3, 21
-    x = torch.randn(n, hw, hw, 128, generator=g)
-    w = torch.randn(3, 3, 128, 128, generator=g) * 0.05
-    sc, sh = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.1
-    r = torch.randn(n, hw, hw, 128, generator=g)
-    xb, wb = x.to(torch.bfloat16).double(), w.to(torch.bfloat16).double()
-    ref = torch.nn.functional.conv2d(xb.permute(0, 3, 1, 2), wb.permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1)
-    ref = (ref * sc.double() + sh.double() + r.double()).clamp_min(0)
-    dev = [t.cuda() for t in (x, w, sc, sh, r)]
-    wT = torch.empty(9 * 128 * 128, dtype=torch.int16, device="cuda")
-    out = torch.full((n, hw, hw, 128), float("nan"), device="cuda")
-    check(L.snk_conv3x3_prepare_weights_bf16(dev[1].data_ptr(), wT.data_ptr(), _st()))
-    check(L.snk_conv3x3_bn_bf16(dev[0].data_ptr(), wT.data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(),
-                                out.data_ptr(), n, hw, hw, 1, _st()))
-    err = (out.cpu().double() - ref).abs().max().item()
-    assert err <= 2e-5 * ref.abs().max().item(), err
-    # the 19x19 / 10-block net of configs[4]
+    for n, hw in ((3, 21), (2, 37), (1, 13)):
+        x = torch.randn(n, hw, hw, 128, generator=g).to(torch.bfloat16)
+        r = torch.randn(n, hw, hw, 128, generator=g).to(torch.bfloat16)
+        w = torch.randn(3, 3, 128, 128, generator=g) * 0.05
+        sc, sh = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.1
+        wb = w.to(torch.bfloat16).double()
+        ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), wb.permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1)
+        ref = (ref * sc.double() + sh.double() + r.double()).clamp_min(0)
+        xd, rd, wd, scd, shd = x.cuda(), r.cuda(), w.cuda().contiguous(), sc.cuda(), sh.cuda()
+        wS = torch.empty(F16S_WEIGHT_BYTES, dtype=torch.uint8, device="cuda")
+        check(L.snk_conv3x3_prepare_weights_bf16(wd.data_ptr(), wS.data_ptr(), _st()))
+        o32 = torch.full((n, hw, hw, 128), float("nan"), device="cuda")
+        check(L.snk_conv3x3_bn_bf16_act16(xd.data_ptr(), wS.data_ptr(), scd.data_ptr(), shd.data_ptr(), rd.data_ptr(),
+                                          o32.data_ptr(), 0, n, hw, hw, 1, _st()))
+        scale = ref.abs().max().item()
+        assert (o32.cpu().double() - ref).abs().max().item() <= 2e-5 * scale
+        o16 = torch.full((n, hw, hw, 128), float("nan"), dtype=torch.bfloat16, device="cuda")
+        check(L.snk_conv3x3_bn_bf16_act16(xd.data_ptr(), wS.data_ptr(), scd.data_ptr(), shd.data_ptr(), rd.data_ptr(),
+                                          o16.data_ptr(), 1, n, hw, hw, 1, _st()))
+        got = o16.cpu()
+        assert torch.isfinite(got).all()
+        want = ref.to(torch.bfloat16)         # the bf16 output is the float32 result rounded once: one bf16 ulp apart at most
+        err = (got.double() - want.double()).abs()
+        assert (err <= 2.0 ** -7 * want.double().abs() + 2e-5 * scale).all() and (got == want).float().mean().item() > 0.99
+        # no residual, no ReLU (the generic epilogue)
+        o32.fill_(float("nan"))
+        check(L.snk_conv3x3_bn_bf16_act16(xd.data_ptr(), wS.data_ptr(), scd.data_ptr(), shd.data_ptr(), None,
+                                          o32.data_ptr(), 0, n, hw, hw, 0, _st()))
+        ref0 = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), wb.permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1) * sc.double() + sh.double()
+        assert (o32.cpu().double() - ref0).abs().max().item() <= 2e-5 * ref0.abs().max().item()
     monkeypatch.setenv("SNK_CONV_ALGO", "bf16")
-    s = load_golden("states_19x19x8.npz")
-    states = s["raw"][:6]
+    s = load_golden("states_11x11x4.npz")
+    states = s["raw"][:128]
+    wsn = _randomised_bn(net.glorot_uniform_weights((21, 21, 3), blocks=4, seed=0), 5)
+    same = net_ref.forward(wsn, states, apply_mask=False, bf16_act=True)
+    full = net_ref.forward(wsn, states, apply_mask=False)
+    for chunk, rect in ((40, "1"), (4096, "1"), (4096, "0")):          # 40: below the sub-rectangle threshold (full form, fine blocks)
+        monkeypatch.setenv("SNK_CONV_RECT", rect)
+        qn = net.QNet(wsn, (21, 21, 3), max_chunk=chunk)
+        assert qn.n_rect == (6 if rect == "1" else 0) and qn.act16 == torch.bfloat16
+        got = qn.forward(torch.as_tensor(states, device="cuda")).cpu().numpy()
+        # bf16 rounding of an activation turns a last-bit float32 difference (summation order) into a 2^-8 relative one
+        assert np.abs(got - same).max() <= 1.5e-2, np.abs(got - same).max()
+        assert np.abs(got - full).max() <= 5e-2, np.abs(got - full).max()
+        if rect == "0":
+            got_full = got
+        elif chunk == 4096:
+            got_rect = got
+    assert np.array_equal(got_rect, got_full), "the sub-rectangle form of the bf16 tower is bit-identical to the full form"
+    monkeypatch.setenv("SNK_CONV_RECT", "1")
+    # the 19x19 / 10-block net of configs[4]
+    s19 = load_golden("states_19x19x8.npz")
+    states = s19["raw"][:6]
     ws = _randomised_bn(net.glorot_uniform_weights((37, 37, 3), blocks=10, seed=1), 4)
-    mask = torch.as_tensor(s["mask"][s["raw_index"][:6]], device="cuda")
+    mask = torch.as_tensor(s19["mask"][s19["raw_index"][:6]], device="cuda")
     got = net.QNet(ws, (37, 37, 3)).forward(torch.as_tensor(states, device="cuda"), mask).cpu().numpy()
-    ref16 = net_ref.forward(ws, states, bf16_conv=True)
+    ref16 = net_ref.forward(ws, states, bf16_act=True)
     ref32 = net_ref.forward(ws, states)
-    assert np.abs(got - ref16).max() <= 1e-3, np.abs(got - ref16).max()
-    assert np.abs(got - ref32).max() <= 5e-2, np.abs(got - ref32).max()
+    assert np.abs(got - ref16).max() <= 3e-2, np.abs(got - ref16).max()
+    assert np.abs(got - ref32).max() <= 1e-1, np.abs(got - ref32).max()
 
 
 # ---- range guard of the split-f16 kernel ------------------------------------------------------------------------------

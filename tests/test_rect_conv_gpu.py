@@ -239,12 +239,13 @@ def test_rect_form_gives_the_same_bits_as_the_full_form(env, board, snakes, bloc
     assert saved > 0
 
 
+@pytest.mark.parametrize("algo", ["f16a", "bf16"])
 @pytest.mark.parametrize("board,snakes,blocks,n_games", [(11, 4, 4, 96), (19, 8, 10, 6)])
-def test_f16_activation_tower_rect_form_gives_the_same_bits(env, board, snakes, blocks, n_games, monkeypatch):
-    """the reduced-precision tower with f16 activations (SNK_CONV_ALGO=f16a, BASELINE configs[4]) through its
-    sub-rectangle layers == through its full layers, bit for bit"""
+def test_f16_activation_tower_rect_form_gives_the_same_bits(env, board, snakes, blocks, n_games, algo, monkeypatch):
+    """the reduced-precision towers with 16-bit activations (SNK_CONV_ALGO=f16a / bf16, BASELINE configs[4]) through their
+    sub-rectangle layers == through their full layers, bit for bit"""
     torch, se, net = env
-    monkeypatch.setenv("SNK_CONV_ALGO", "f16a")
+    monkeypatch.setenv("SNK_CONV_ALGO", algo)
     h = w = 2 * board - 1
     ws = _randomised_bn(net.glorot_uniform_weights((h, w, 3), blocks=blocks, seed=board), 6)
     planes, _ = _mid_game_planes(se, torch, n_games, board, snakes, 10, seed=200 + board)
@@ -254,7 +255,7 @@ def test_f16_activation_tower_rect_form_gives_the_same_bits(env, board, snakes, 
     monkeypatch.setenv("SNK_CONV_RECT", "1")
     rect = net.QNet(ws, (h, w, 3), max_chunk=8192)
     rect.rect_min = 1
-    assert full.n_rect == 0 and rect.n_rect >= 2 and rect.backgrounds().dtype == torch.float16
+    assert full.n_rect == 0 and rect.n_rect >= 2 and rect.backgrounds().dtype == (torch.float16 if algo == "f16a" else torch.bfloat16)
     q_full = full.forward(planes)
     for t in rect._ws.get(("a16", 0), []) if rect._ws else []:
         t.fill_(float("nan"))

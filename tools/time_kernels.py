@@ -36,14 +36,6 @@ def main():
         t = timeit(lambda: check(L.snk_conv3x3_bn_f32_winograd(x.data_ptr(), U.data_ptr(), sc.data_ptr(), sh.data_ptr(), x.data_ptr(), o.data_ptr(), n, 21, 21, 1, st)))
         fl = 2 * n * 441 * 1152 * 128
         print(f"conv3x3 winograd f32 n={n}: {t*1e3:.3f} ms  {fl/t/1e12:.1f} TFLOP/s (direct-equivalent)")
-    for n in (4096,):
-        x = torch.randn(n, 21, 21, 128, device="cuda"); o = torch.empty_like(x)
-        w = torch.randn(3, 3, 128, 128, device="cuda") * 0.05; wb = torch.empty(9 * 128 * 128, dtype=torch.int16, device="cuda")
-        sc = torch.ones(128, device="cuda"); sh = torch.zeros(128, device="cuda")
-        check(L.snk_conv3x3_prepare_weights_bf16(w.data_ptr(), wb.data_ptr(), st))
-        t = timeit(lambda: check(L.snk_conv3x3_bn_bf16(x.data_ptr(), wb.data_ptr(), sc.data_ptr(), sh.data_ptr(), x.data_ptr(), o.data_ptr(), n, 21, 21, 1, st)))
-        fl = 2 * n * 441 * 1152 * 128
-        print(f"conv3x3 bf16 n={n}: {t*1e3:.3f} ms  {fl/t/1e12:.1f} TFLOP/s")
     for n in (8192,):
         xs = torch.randn(n, 21, 21, 3, device="cuda"); o = torch.empty(n, 21, 21, 128, device="cuda")
         w3 = torch.randn(3, 3, 3, 128, device="cuda"); sc = torch.ones(128, device="cuda"); sh = torch.zeros(128, device="cuda")
