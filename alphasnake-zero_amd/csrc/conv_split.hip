@@ -62,6 +62,9 @@ template <bool BF> __device__ __forceinline__ _Float16 hs_to16(float v)
 #define HS_WS_ELEMS (9 * HS_C * HS_C * 2)                // f16 numbers in the split weight image; four floats follow it
 #define HS_RING 3
 #define HS_AHEAD 2
+#ifndef HS_XLOAD_TAP
+#define HS_XLOAD_TAP 0                                   // the tap at whose start the next chunk's pixel loads are issued (A/B: make variant EXTRA=-DHS_XLOAD_TAP=1)
+#endif
 #define HS_NST 5                                         // staging items per thread and chunk: 64 pixels x 4 float4 each
 
 struct ConvHsArgs {
@@ -261,7 +264,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
                 __builtin_amdgcn_sched_barrier(0);                                              \
                 if (i == 0) {                                                                   \
                     if (MORE || (s) + HS_AHEAD < 9) { HS_LOADB(((s) + HS_AHEAD) % HS_RING, gnext + (s)); } \
-                    if ((s) == 0 && MORE) { HS_LOAD(c + 1) }                                    \
+                    if ((s) == HS_XLOAD_TAP && MORE) { HS_LOAD(c + 1) }                         \
                 }                                                                               \
                 {                                                                               \
                     const int tl_ = (s) * NI + i - (9 * NI - 2 * HS_NST);                       \
