@@ -1,5 +1,6 @@
 """The production search at BASELINE.json's full sizes, under the driver's GPU tests: ONE root turn of configs[1] (4 096 games,
-max_MCTS_breadth 50) and of configs[2] (32 768 games, breadth 200) through the drop-in classes (utils.mp_game_runner.MPGameRunner
+max_MCTS_breadth 50), of configs[2] (32 768 games, breadth 200) and of one GPU's share of the configs[4] shape (19x19, 8 snakes,
+4 096 games) through the drop-in classes (utils.mp_game_runner.MPGameRunner
 -> utils.agent.Agent -> snake_engine.DeviceMCTS: Agent.make_moves agent.py:25-111, the rollout ticks agent.py:161-223,
 MPGameRunner.run mp_game_runner.py:23-77) on mid-game boards, with the deterministic device stub net (tests/stubnet_device.py:
 no convolution time, so the turn costs seconds) and a transposition table that starts too small (the growth path runs).
@@ -44,9 +45,10 @@ def _counters_of(states):
     return np.array([st.counters[:] for st in states], np.int64)
 
 
-@pytest.mark.parametrize("games,breadth,tt_cap,stride", [(4096, 50, 1 << 20, 5), (32768, 200, 1 << 24, 40)],
-                         ids=["configs1_4096x50", "configs2_32768x200"])
-def test_one_root_turn_at_full_size(oracle, games, breadth, tt_cap, stride):
+@pytest.mark.parametrize("board,S,games,breadth,tt_cap,stride",
+                         [(11, 4, 4096, 50, 1 << 20, 5), (11, 4, 32768, 200, 1 << 24, 40), (19, 8, 4096, 16, 1 << 22, 10)],
+                         ids=["configs1_4096x50", "configs2_32768x200", "configs4_shape_19x19x8_4096x16"])
+def test_one_root_turn_at_full_size(oracle, board, S, games, breadth, tt_cap, stride):
     import torch
     import snake_engine as se
     from snake_engine.engine import compact_from_state
@@ -55,8 +57,7 @@ def test_one_root_turn_at_full_size(oracle, games, breadth, tt_cap, stride):
     from utils.agent import Agent
     from utils.mp_game_runner import MPGameRunner
     t_start = time.time()
-    H = W = 11
-    S = 4
+    H = W = board
     old = MPGameRunner.verbose, MPGameRunner.init
     MPGameRunner.verbose, MPGameRunner.init = False, "device"
     try:
@@ -66,8 +67,10 @@ def test_one_root_turn_at_full_size(oracle, games, breadth, tt_cap, stride):
     eng = gr.engine
     redealt = _mid_game_boards(torch, eng, games, 24, seed=games)
     alive0 = eng.alive().cpu().numpy().astype(bool)
-    assert (alive0.sum(axis=1) >= 2).all() and 0 < redealt < games // 2
-    assert len({int(v) for v in alive0.sum(axis=1)}) == 3, "boards with 2, 3 and 4 snakes (rollout depths 8, 6, 4, agent.py:45)"
+    assert (alive0.sum(axis=1) >= 2).all() and redealt < games // 2 and (redealt > 0 or board > 11)
+    n_alive0 = alive0.sum(axis=1)
+    assert len({int(v) for v in n_alive0}) >= 3, "boards with different numbers of snakes: several rollout depths 8 - 2 (alive - 2), agent.py:45"
+    n_ticks = max(1, 8 - 2 * (int(n_alive0.min()) - 2))
     counters0 = np.array(eng.sum_counters(), np.int64)
     sample = np.arange(0, games, stride, dtype=np.int32)
     pre = eng.export(sample)
@@ -100,17 +103,18 @@ def test_one_root_turn_at_full_size(oracle, games, breadth, tt_cap, stride):
     cap, occ, ovf = mcts.tt.status()
     assert not ovf
     assert mcts.stats["net_evals"] == occ, "every entry the table created was evaluated exactly once (agent.py:177-201)"
-    assert mcts.tt.generation >= 1 and cap > tt_cap, "the table outgrew its initial capacity between epochs"
+    if board == 11:
+        assert mcts.tt.generation >= 1 and cap > tt_cap, "the table outgrew its initial capacity between epochs"
     epochs, B = breadth // 8, games * 8
-    assert mcts.stats["rollout_ticks"] == epochs * 8                     # a board with 2 snakes alive rolls out to depth 8
-    assert epochs * B <= mcts.stats["sim_steps"] <= epochs * B * 8
+    assert mcts.stats["rollout_ticks"] == epochs * n_ticks               # the deepest rollout is that of the board with the fewest snakes
+    assert epochs * B <= mcts.stats["sim_steps"] <= epochs * B * n_ticks
     assert occ >= n_rows // 2 and mcts.stats["net_evals"] >= epochs * games
     post_all = eng.export()
     c_all = _counters_of(post_all)
     assert np.array_equal(np.array(eng.sum_counters(), np.int64), c_all.sum(axis=0)), "snk_engine_sum_counters_sync vs the exported boards"
     assert np.array_equal(c_all[:, 5].sum() - counters0[5], games), "every live game made one tic (game_length)"
     over = np.array([sum(st.alive[:S]) <= 1 for st in post_all])
-    assert over.sum() == games - len(gr.games) and over.sum() > 0
+    assert over.sum() == games - len(gr.games) and (over.sum() > 0 or board > 11)
     from utils.mp_game_runner import LOG_FIELDS
     assert np.array_equal(np.array([gr._totals[k] for k in LOG_FIELDS], np.int64), c_all[over].sum(axis=0)), \
         "the runner's log counters are those of the games that ended (mp_game_runner.py:54-60)"
@@ -122,7 +126,7 @@ def test_one_root_turn_at_full_size(oracle, games, breadth, tt_cap, stride):
 
     # ---- the strided sample against the oracle -----------------------------------------------------------------------------------
     rec_idx = np.concatenate([np.arange(row0[g], row0[g + 1]) for g in sample])
-    assert len(rec_idx) >= 2000
+    assert len(rec_idx) >= 1500
     states = alice.records.fetch(rec_idx)
     post = eng.export(sample)
     k = n_spawn = n_live_ticks = 0
