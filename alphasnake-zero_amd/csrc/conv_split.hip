@@ -306,14 +306,14 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     HS_STAMP(3)
     // range guard: an input beyond the f16 range after scaling was clamped, the layer's result is then NOT float32-accurate.
     // The flag word sits behind the scales in the weight image (one per layer); the host reads it (QNet.check_range).
-    // The same event is also stored to the word tail[6..7] points to, when the caller registered one (a host-mapped word shared
-    // by all layers, snk_conv3x3_f16s_set_guard_word): after a stream synchronisation the host knows from ONE word, without a
-    // copy, whether any launch of a forward clamped.
+    // The same event is also stored to the device word tail[6..7] points to, when the caller registered one (ONE word for all
+    // layers of a net, snk_conv3x3_f16s_set_guard_word): the kernels of a rollout tick that follow the evaluation are gated on it
+    // (csrc/mcts.hip TICK_GATE), and the host learns from one word whether any launch of a forward clamped.
     if (amax >= 65504.f) {
         int *t = (int *)const_cast<float *>(p.wscale_inv);
         atomicOr(t + 4, 1);
         int *shared = *(int *const *)(t + 6);
-        if (shared) __hip_atomic_store(shared, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (shared) __hip_atomic_store(shared, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     HS_STAMP_REAL(6)
 #undef HS_TAP
@@ -557,25 +557,7 @@ __global__ void k_f16s_weights(const float *__restrict__ w, _Float16 *__restrict
     }
 }
 
-// ---- the guard word: one host-mapped, coherent int32 that every layer of a net reports clamps to ------------------------------
-extern "C" int snk_guard_word_create(int32_t **h_word, int32_t **d_word)
-{
-    SNK_REQUIRE(h_word && d_word, "snk_guard_word_create: NULL argument");
-    void *h = nullptr, *d = nullptr;
-    SNK_CHECK_HIP(hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent));
-    *(volatile int32_t *)h = 0;
-    SNK_CHECK_HIP(hipHostGetDevicePointer(&d, h, 0));
-    *h_word = (int32_t *)h;
-    *d_word = (int32_t *)d;
-    return 0;
-}
-
-extern "C" int snk_guard_word_destroy(int32_t *h_word)
-{
-    if (h_word) SNK_CHECK_HIP(hipHostFree(h_word));
-    return 0;
-}
-
+// ---- the guard word: one device int32 that every layer of a net reports clamps to ----------------------------------------------
 __global__ void k_f16s_set_guard_word(int *tail, int *word) { *(int **)(tail + 6) = word; }
 
 extern "C" int snk_conv3x3_f16s_set_guard_word(void *d_wS, int32_t *d_word, void *stream)

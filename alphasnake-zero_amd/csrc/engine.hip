@@ -100,7 +100,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
                                                        int16_t *__restrict__ spawned_out,
                                                        uint64_t *__restrict__ empty_out, int health_dec,
                                                        double chance, uint32_t seed_lo, uint32_t seed_hi,
-                                                       const uint8_t *__restrict__ active)
+                                                       const uint8_t *__restrict__ active, const int *__restrict__ skip)
 {
     using cell_t = typename CellT<H * W>::type;
     BOARD_DIMS(L)
@@ -111,7 +111,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step(uint8_t *__restrict__ st
     const int gi = (blockIdx.x * WAVES_PER_BLOCK + wv) * GPW + gq;
     // games whose `active` flag is 0 are frozen (a rollout sub-game that reached its depth cap, mp_game_runner.py:108):
     // neither loaded nor stored; the flag load is independent of the record load (no slot indirection, one round trip)
-    const bool frozen = gi < n && active && !active[gi];
+    // (skip: the rollout tick's gate, csrc/mcts.hip TICK_GATE -- a non-zero word freezes every game of the launch)
+    const bool frozen = gi < n && ((active && !active[gi]) || (skip && *(volatile const int *)skip));
     const bool valid = gi < n && !frozen;
     const int S = SS > 0 ? SS : L.S, mask = L.cap_mask;
 // value of sub-lane o of the game's lane group: with 16-lane groups (= one DPP row) a row_share move, one VALU instruction,
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step_quad(uint8_t *__restrict
                                                             int16_t *__restrict__ spawned_out,
                                                             uint64_t *__restrict__ empty_out, int health_dec,
                                                             double chance, uint32_t seed_lo, uint32_t seed_hi,
-                                                            const uint8_t *__restrict__ active)
+                                                            const uint8_t *__restrict__ active, const int *__restrict__ skip)
 {
     using cell_t = uint8_t;
     const int HH = H > 0 ? H : L.H, WW = W > 0 ? W : L.W;
@@ -361,7 +362,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_step_quad(uint8_t *__restrict
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int sl = lane & 3, gq = lane >> 2;
     const int gi = (blockIdx.x * WAVES_PER_BLOCK + wv) * GPWQ + gq;
-    const bool frozen = gi < n && active && !active[gi];
+    // (skip: the rollout tick's gate, csrc/mcts.hip TICK_GATE -- a non-zero word freezes every game of the launch)
+    const bool frozen = gi < n && ((active && !active[gi]) || (skip && *(volatile const int *)skip));
     const bool valid = gi < n && !frozen;
     const int S = SS > 0 ? SS : L.S, mask = L.cap_mask;
     const int FW = H > 0 ? QFW : L.FW;
@@ -1159,12 +1161,13 @@ extern "C" int snk_engine_clone(const snk_engine *src, const int32_t *d_src_slot
 }
 
 static int step_launch(snk_engine *e, const int32_t *d_slots, int n, const uint8_t *d_moves, const int16_t *d_spawn_tape,
-                       uint8_t *d_done, int16_t *d_spawned, uint64_t *d_empty, const uint8_t *d_active, void *stream)
+                       uint8_t *d_done, int16_t *d_spawned, uint64_t *d_empty, const uint8_t *d_active, void *stream,
+                       const int32_t *d_skip = nullptr)
 {
     const Layout L = e->L;
     // four games per wavefront where the per-game LDS is small (11x11, 7x7), one per wavefront on 19x19
 #define STEP_ARGS e->d_state, L, d_slots, n, d_moves, d_spawn_tape, d_done, d_spawned, d_empty, e->health_dec, e->food_chance, \
-                  (uint32_t)e->seed, (uint32_t)(e->seed >> 32), d_active
+                  (uint32_t)e->seed, (uint32_t)(e->seed >> 32), d_active, d_skip
     static const bool wide = getenv("SNK_STEP_FORM") && !strcmp(getenv("SNK_STEP_FORM"), "wide");   // A/B: the lane-group kernel
     if (L.S <= 4 && L.NC <= 255 && !wide) {               // a quad per game, sixteen games per wavefront
         const size_t lds = (size_t)WAVES_PER_BLOCK * 16 * lds_per_game_quad(L);
@@ -1202,13 +1205,13 @@ extern "C" int snk_engine_step(snk_engine *e, const int32_t *d_slots, int n, con
 }
 
 extern "C" int snk_engine_step_active(snk_engine *e, const uint8_t *d_active, int n, const uint8_t *d_moves, uint8_t *d_done,
-                                      void *stream)
+                                      const int32_t *d_skip, void *stream)
 {
     SNK_REQUIRE(e != nullptr, "snk_engine_step_active: engine is NULL");
     SNK_REQUIRE(n >= 0 && n <= e->n_slots, "snk_engine_step_active: n=%d exceeds %d slots", n, e->n_slots);
     if (n == 0) return 0;
     SNK_REQUIRE(d_moves != nullptr && d_active != nullptr, "snk_engine_step_active: NULL argument");
-    return step_launch(e, nullptr, n, d_moves, nullptr, d_done, nullptr, nullptr, d_active, stream);
+    return step_launch(e, nullptr, n, d_moves, nullptr, d_done, nullptr, nullptr, d_active, stream, d_skip);
 }
 
 extern "C" int snk_engine_alive(const snk_engine *e, const int32_t *d_slots, int n, uint8_t *d_alive,

@@ -119,9 +119,16 @@ __global__ void k_tt_find(snk_tt T, const unsigned long long *__restrict__ key, 
 }
 
 // new entries: prior = net output, visits 1,1,1 (agent.py:193-201)
+// TICK GATE (round 4): the kernels of a rollout tick that follow the leaf evaluation -- priors, move choice, back-up, the
+// sub-games' tic, retirement -- take an optional device word and do NOTHING when it is non-zero.  The word is the Q-net's range
+// guard (set by a convolution launch that had to clamp an input): a tick whose evaluation cannot be trusted leaves no trace, the
+// host notices at the next tick's existing read-back and runs that evaluation and these kernels again (snake_engine/mcts.py).
+#define TICK_GATE(skip) if ((skip) && *(volatile const int *)(skip)) return;
+
 __global__ void k_tt_set_priors(snk_tt T, const uint32_t *__restrict__ entry, const int32_t *__restrict__ idx, int n,
-                                const float *__restrict__ q)
+                                const float *__restrict__ q, const int *__restrict__ skip)
 {
+    TICK_GATE(skip)
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const uint32_t e = entry[idx ? idx[j] : j];
@@ -185,8 +192,9 @@ struct PathBufs {
 __global__ void k_mcts_select(snk_tt T, const uint32_t *__restrict__ entry, int m, float base, const double *__restrict__ tape,
                               const int32_t *__restrict__ rank, long tape_base, uint32_t seed_lo, uint32_t seed_hi,
                               uint32_t ctr0, uint32_t ctr1, uint8_t *__restrict__ moves, float *__restrict__ est,
-                              float *__restrict__ pmf_out, PathBufs P)
+                              float *__restrict__ pmf_out, PathBufs P, const int *__restrict__ skip)
 {
+    TICK_GATE(skip)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     const uint32_t e = entry[i];
@@ -206,8 +214,10 @@ __global__ void k_mcts_select(snk_tt T, const uint32_t *__restrict__ entry, int 
 }
 
 // in-rollout back-up (agent.py:208-220): every ancestor edge of the snake's path gets visit += 1, total += est
-__global__ void k_mcts_backup(snk_tt T, const uint32_t *__restrict__ entry, int m, const float *__restrict__ est, PathBufs P)
+__global__ void k_mcts_backup(snk_tt T, const uint32_t *__restrict__ entry, int m, const float *__restrict__ est, PathBufs P,
+                              const int *__restrict__ skip)
 {
+    TICK_GATE(skip)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     if (entry[i] == TT_NONE) return;
@@ -224,8 +234,10 @@ __global__ void k_mcts_backup(snk_tt T, const uint32_t *__restrict__ entry, int 
 
 // the same in the reference's sequential order (ids order, live Q reads): parity runs on tiny cases.
 // pmf was fixed before the loop (agent.py:204); V[i] aliases the live cache row (agent.py:181, 214).
-__global__ void k_mcts_backup_seq(snk_tt T, const uint32_t *__restrict__ entry, int m, const float *__restrict__ pmf, PathBufs P)
+__global__ void k_mcts_backup_seq(snk_tt T, const uint32_t *__restrict__ entry, int m, const float *__restrict__ pmf, PathBufs P,
+                                  const int *__restrict__ skip)
 {
+    TICK_GATE(skip)
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     for (int i = 0; i < m; ++i) {
         const uint32_t e = entry[i];
@@ -453,11 +465,12 @@ extern "C" int snk_tt_find(snk_tt *t, const uint64_t *d_key, int m, int now_turn
     return 0;
 }
 
-extern "C" int snk_tt_set_priors(snk_tt *t, const uint32_t *d_entry, const int32_t *d_idx, int n, const float *d_q, void *stream)
+extern "C" int snk_tt_set_priors(snk_tt *t, const uint32_t *d_entry, const int32_t *d_idx, int n, const float *d_q,
+                                 const int32_t *d_skip, void *stream)
 {
     SNK_REQUIRE(t && d_entry && d_q, "snk_tt_set_priors: NULL argument");
     if (n <= 0) return 0;
-    k_tt_set_priors<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(*t, d_entry, d_idx, n, d_q);
+    k_tt_set_priors<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(*t, d_entry, d_idx, n, d_q, d_skip);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -465,28 +478,28 @@ extern "C" int snk_tt_set_priors(snk_tt *t, const uint32_t *d_entry, const int32
 extern "C" int snk_mcts_select(snk_tt *t, const uint32_t *d_entry, int m, float softmax_base, const double *d_tape_u,
                                const int32_t *d_rank, int64_t tape_base, uint64_t seed, uint32_t ctr0, uint32_t ctr1,
                                uint8_t *d_moves, float *d_est, float *d_pmf, uint32_t *d_path_entry, uint8_t *d_path_move,
-                               int32_t *d_path_len, int path_depth, void *stream)
+                               int32_t *d_path_len, int path_depth, const int32_t *d_skip, void *stream)
 {
     SNK_REQUIRE(t && d_entry && d_moves && d_path_entry && d_path_move && d_path_len, "snk_mcts_select: NULL argument");
     if (m <= 0) return 0;
     PathBufs P = {d_path_entry, d_path_move, d_path_len, path_depth};
     k_mcts_select<<<(m + 255) / 256, 256, 0, (hipStream_t)stream>>>(*t, d_entry, m, softmax_base, d_tape_u, d_rank, (long)tape_base,
                                                                     (uint32_t)seed, (uint32_t)(seed >> 32), ctr0, ctr1, d_moves, d_est,
-                                                                    d_pmf, P);
+                                                                    d_pmf, P, d_skip);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 extern "C" int snk_mcts_backup(snk_tt *t, const uint32_t *d_entry, int m, const float *d_est, const float *d_pmf,
                                uint32_t *d_path_entry, uint8_t *d_path_move, int32_t *d_path_len, int path_depth,
-                               int sequential, void *stream)
+                               int sequential, const int32_t *d_skip, void *stream)
 {
     SNK_REQUIRE(t && d_entry && d_path_entry && d_path_move && d_path_len, "snk_mcts_backup: NULL argument");
     SNK_REQUIRE(sequential ? d_pmf != nullptr : d_est != nullptr, "snk_mcts_backup: needs d_pmf (sequential) or d_est");
     if (m <= 0) return 0;
     PathBufs P = {d_path_entry, d_path_move, d_path_len, path_depth};
-    if (sequential) k_mcts_backup_seq<<<1, 64, 0, (hipStream_t)stream>>>(*t, d_entry, m, d_pmf, P);
-    else k_mcts_backup<<<(m + 255) / 256, 256, 0, (hipStream_t)stream>>>(*t, d_entry, m, d_est, P);
+    if (sequential) k_mcts_backup_seq<<<1, 64, 0, (hipStream_t)stream>>>(*t, d_entry, m, d_pmf, P, d_skip);
+    else k_mcts_backup<<<(m + 255) / 256, 256, 0, (hipStream_t)stream>>>(*t, d_entry, m, d_est, P, d_skip);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -503,8 +516,9 @@ __global__ void k_mcts_row_active(const uint8_t *__restrict__ alive_rows, const 
 // after the tick's step: the sub-games that moved are counted (sim_steps += number of active ones), then a sub-game retires
 // when its game is over or its depth cap is reached (tick >= depth: mp_game_runner.py:108-113)
 __global__ void k_mcts_retire(uint8_t *__restrict__ sub_active, const uint8_t *__restrict__ done, const int32_t *__restrict__ sub_depth,
-                              int tick, int B, unsigned long long *__restrict__ sim_steps)
+                              int tick, int B, unsigned long long *__restrict__ sim_steps, const int *__restrict__ skip)
 {
+    TICK_GATE(skip)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool act = i < B && sub_active[i] != 0;
     const unsigned long long moved = __ballot(act);
@@ -547,12 +561,12 @@ extern "C" int snk_mcts_row_active(const uint8_t *d_alive_rows, const uint8_t *d
 }
 
 extern "C" int snk_mcts_retire(uint8_t *d_sub_active, const uint8_t *d_done, const int32_t *d_sub_depth, int tick, int n_subgames,
-                               int64_t *d_sim_steps, void *stream)
+                               int64_t *d_sim_steps, const int32_t *d_skip, void *stream)
 {
     SNK_REQUIRE(d_sub_active && d_done && d_sub_depth && d_sim_steps, "snk_mcts_retire: NULL argument");
     if (n_subgames <= 0) return 0;
     k_mcts_retire<<<(n_subgames + 255) / 256, 256, 0, (hipStream_t)stream>>>(d_sub_active, d_done, d_sub_depth, tick, n_subgames,
-                                                                             (unsigned long long *)d_sim_steps);
+                                                                             (unsigned long long *)d_sim_steps, d_skip);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }

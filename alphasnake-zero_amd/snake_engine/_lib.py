@@ -34,8 +34,6 @@ vp, i32, u64, f64 = C.c_void_p, C.c_int, C.c_uint64, C.c_double
 PROTOTYPES = {
     "snk_last_error": (C.c_char_p, []),
     "snk_version": (i32, []),
-    "snk_guard_word_create": (i32, [C.POINTER(vp), C.POINTER(vp)]),
-    "snk_guard_word_destroy": (i32, [vp]),
     "snk_conv3x3_f16s_set_guard_word": (i32, [vp, vp, vp]),
     "snk_source_hash": (C.c_char_p, [C.c_char_p]),
     "snk_engine_create": (i32, [C.POINTER(vp), i32, i32, i32, i32, i32, f64, u64, i32]),
@@ -46,7 +44,7 @@ PROTOTYPES = {
     "snk_engine_reset": (i32, [vp, vp, i32, vp, vp]),
     "snk_engine_clone": (i32, [vp, vp, i32, vp, vp, i32, vp]),
     "snk_engine_step": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp]),
-    "snk_engine_step_active": (i32, [vp, vp, i32, vp, vp, vp]),
+    "snk_engine_step_active": (i32, [vp, vp, i32, vp, vp, vp, vp]),
     "snk_engine_alive": (i32, [vp, vp, i32, vp, vp, vp]),
     "snk_engine_ids": (i32, [vp, vp, i32, vp, vp, vp, vp, vp]),
     "snk_engine_observe": (i32, [vp, vp, i32, i32, vp, vp, vp, i32, vp]),
@@ -85,13 +83,13 @@ PROTOTYPES = {
     "snk_tt_rebuild_sync": (i32, [vp, u64, i32, i32]),
     "snk_tt_lookup_insert": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     "snk_tt_find": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
-    "snk_tt_set_priors": (i32, [vp, vp, vp, i32, vp, vp]),
+    "snk_tt_set_priors": (i32, [vp, vp, vp, i32, vp, vp, vp]),
     "snk_tt_read_q": (i32, [vp, vp, i32, i32, vp, vp]),
-    "snk_mcts_select": (i32, [vp, vp, i32, C.c_float, vp, vp, C.c_int64, u64, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "snk_mcts_select": (i32, [vp, vp, i32, C.c_float, vp, vp, C.c_int64, u64, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, i32, vp, vp]),
     "snk_mcts_gather_rows": (i32, [vp, i32, vp, vp, vp, vp, vp]),
     "snk_mcts_row_active": (i32, [vp, vp, i32, i32, vp, vp]),
-    "snk_mcts_retire": (i32, [vp, vp, vp, i32, i32, vp, vp]),
-    "snk_mcts_backup": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "snk_mcts_retire": (i32, [vp, vp, vp, i32, i32, vp, vp, vp]),
+    "snk_mcts_backup": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     "snk_mcts_terminal_backup": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, vp]),
     "snk_mcts_root_moves": (i32, [vp, vp, i32, C.c_float, i32, vp, vp, C.c_int64, u64, C.c_uint32, C.c_uint32, vp, vp]),
     "snk_softermax_argmax": (i32, [vp, i32, C.c_float, vp, vp, vp]),

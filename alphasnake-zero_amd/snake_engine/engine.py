@@ -101,11 +101,12 @@ class Engine:
         check(self.L.snk_engine_step(self.h, _ptr(slots), n, _ptr(moves), _ptr(spawn_tape), _ptr(done),
                                      _ptr(spawned), _ptr(empty), _stream()))
 
-    def step_active(self, active, moves, n, done=None):
-        """slots 0..n-1, only those with active[i] != 0 move (the rollout loop's depth-retired sub-games stay frozen)"""
+    def step_active(self, active, moves, n, done=None, skip=0):
+        """slots 0..n-1, only those with active[i] != 0 move (the rollout loop's depth-retired sub-games stay frozen);
+        skip: address of a device int32 that, when non-zero at launch time, freezes every game (the rollout tick's gate)"""
         assert active.dtype == torch.uint8 and active.is_cuda and active.is_contiguous() and active.numel() >= n
         assert moves.dtype == torch.uint8 and moves.is_cuda and moves.is_contiguous() and moves.numel() >= n * self.S
-        check(self.L.snk_engine_step_active(self.h, _ptr(active), n, _ptr(moves), _ptr(done), _stream()))
+        check(self.L.snk_engine_step_active(self.h, _ptr(active), n, _ptr(moves), _ptr(done), skip or None, _stream()))
 
     def alive(self, slots=None, n=None, out=None, n_alive=None):
         slots = self._i32(slots)

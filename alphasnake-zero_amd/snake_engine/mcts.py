@@ -84,6 +84,14 @@ class DeviceMCTS:
         self.roll = None                  # rollout engine (sub-games; food_spawn_chance 0, game.py:268)
         self._bufs_B = -1
         self.verbose = False              # print the reference's per-epoch line (agent.py:57-58)
+        # Range guard of the evaluation (set by the owner: an object with guard_ptr / guard_tripped() / guard_recover(), i.e. a
+        # snake_engine.net.QNet, or None).  With a guard, evaluate() must not synchronise: the kernels of a tick that follow the
+        # evaluation are gated on the device word guard_ptr (they do nothing when a convolution had to clamp an activation), the
+        # host reads the word's mirror at the NEXT tick's existing read-back and, if it is set, lets the guard widen its scales
+        # and runs that tick's evaluation and tail again -- a tick is played exactly once, from trusted values, and nothing of
+        # an untrusted evaluation ever reaches the table (agent.py:161-223 knows no such event: nnet.v is exact there).
+        self.guard = None
+        self.guard_redos = 0
         self.stats = dict(net_evals=0, rollout_ticks=0, sim_steps=0, lookups=0)
         self._sim_steps_pending = []      # device counters of the sub-game tics, folded into stats at the turn's end
 
@@ -122,7 +130,7 @@ class DeviceMCTS:
             self.eval_mask = torch.empty((m, 3), dtype=torch.uint8, device=dev)
             self.done = torch.empty((B,), dtype=torch.uint8, device=dev)
             self.rewards = torch.empty((m,), dtype=torch.int8, device=dev)
-            self.cmp_idx = torch.empty((m,), dtype=torch.int32, device=dev)
+            self.cmp_idx = torch.empty((2, m), dtype=torch.int32, device=dev)       # ping-pong: a tick that is run again needs its own list
             self.cmp_cnt = torch.empty((1,), dtype=torch.int32, device=dev)
             self.cmp_scratch = torch.empty((self.L.snk_compact_scratch_elems(m),), dtype=torch.int32, device=dev)
             self.planes = None
@@ -169,42 +177,82 @@ class DeviceMCTS:
             sub_active = torch.ones((B,), dtype=torch.uint8, device=self.device)
             sim_steps_dev = torch.zeros((), dtype=torch.int64, device=self.device)
             row_active = self.row_active
-            for tick in range(1, n_ticks + 1):
+            guard = self.guard
+            gate = guard.guard_ptr if guard is not None else 0
+            pend = None                     # the last tick whose evaluation has not been verified yet (guarded runs only)
+
+            def head(pp):
+                """the tick up to its read-back: which rows are live, their masks and keys, table lookup, the list of new keys"""
                 self.roll.alive(n=B, out=self.alive_rows)
                 check(L.snk_mcts_row_active(_ptr(self.alive_rows), _ptr(sub_active), B, S, _ptr(row_active), st))
                 self.roll.observe(self.pairs, m, None, self.mask, self.key, legacy_mask=self.legacy_mask)
                 check(L.snk_tt_lookup_insert(tt, _ptr(self.key), _ptr(row_active), m, self.now, self.max_depth,
                                              _ptr(self.entry), _ptr(self.is_new), st))
-                check(L.snk_compact_flags(_ptr(self.is_new), m, _ptr(self.cmp_idx), _ptr(self.cmp_cnt),
+                check(L.snk_compact_flags(_ptr(self.is_new), m, _ptr(self.cmp_idx[pp]), _ptr(self.cmp_cnt),
                                           _ptr(self.cmp_scratch), st))
-                n_eval = int(self.cmp_cnt.item())               # the one host read-back of the tick
-                if n_eval:
-                    idx = self.cmp_idx[:n_eval]
-                    eval_pairs, eval_mask = self.eval_pairs[:n_eval], self.eval_mask[:n_eval]
-                    check(L.snk_mcts_gather_rows(_ptr(idx), n_eval, _ptr(self.pairs), _ptr(self.mask), _ptr(eval_pairs), _ptr(eval_mask), st))
-                    planes = self._planes(n_eval)
-                    self.roll.observe(eval_pairs, n_eval, planes, None, None)
+                return int(self.cmp_cnt.item())                 # the one host read-back of the tick
+
+            def tail(t):
+                """evaluation of the new keys + everything that follows it (t: what the tick needs to be run again unchanged)"""
+                if t["n_eval"]:
+                    idx = self.cmp_idx[t["pp"]][:t["n_eval"]]
+                    eval_pairs, eval_mask = self.eval_pairs[:t["n_eval"]], self.eval_mask[:t["n_eval"]]
+                    check(L.snk_mcts_gather_rows(_ptr(idx), t["n_eval"], _ptr(self.pairs), _ptr(self.mask), _ptr(eval_pairs), _ptr(eval_mask), st))
+                    planes = self._planes(t["n_eval"])
+                    self.roll.observe(eval_pairs, t["n_eval"], planes, None, None)
                     q = self.evaluate(planes, eval_mask)            # nnet.v(all_states) (agent.py:190)
-                    check(L.snk_tt_set_priors(tt, _ptr(self.entry), _ptr(idx), n_eval, _ptr(q.contiguous()), st))
-                    self.stats["net_evals"] += n_eval
-                rank, n_rows = None, 0
+                    check(L.snk_tt_set_priors(tt, _ptr(self.entry), _ptr(idx), t["n_eval"], _ptr(q.contiguous()), gate or None, st))
+                rank = None
                 if self.tape is not None:
                     rank = (torch.cumsum(row_active, 0, dtype=torch.int32) - 1).contiguous()
-                    n_rows = int(row_active.sum().item())
-                c0, c1 = self._next_ctr()
-                check(L.snk_mcts_select(tt, _ptr(self.entry), m, self.base, _ptr(self.tape), _ptr(rank), self.tape_pos,
-                                        self.seed, c0, c1, _ptr(self.moves), _ptr(self.est), _ptr(self.pmf),
-                                        _ptr(self.path_entry), _ptr(self.path_move), _ptr(self.path_len), D, st))
-                self.tape_pos += n_rows
+                check(L.snk_mcts_select(tt, _ptr(self.entry), m, self.base, _ptr(self.tape), _ptr(rank), t["tape_pos"],
+                                        self.seed, t["c0"], t["c1"], _ptr(self.moves), _ptr(self.est), _ptr(self.pmf),
+                                        _ptr(self.path_entry), _ptr(self.path_move), _ptr(self.path_len), D, gate or None, st))
                 check(L.snk_mcts_backup(tt, _ptr(self.entry), m, _ptr(self.est), _ptr(self.pmf), _ptr(self.path_entry),
-                                        _ptr(self.path_move), _ptr(self.path_len), D, seq, st))
+                                        _ptr(self.path_move), _ptr(self.path_len), D, seq, gate or None, st))
                 # tic every live sub-game (mp_game_runner.py:104-106) in one launch over all B slots; sub-games retired by
                 # their depth cap must not move: their `active` flag is 0 and the kernel skips them (no host read-back)
-                self.roll.step_active(sub_active, self.moves, B, done=self.done)
+                self.roll.step_active(sub_active, self.moves, B, done=self.done, skip=gate)
                 # the sub-games that moved are counted, then the finished ones and those at their depth cap retire
                 # (mp_game_runner.py:108-113): one launch (this was a chain of eight tensor expressions)
-                check(L.snk_mcts_retire(_ptr(sub_active), _ptr(self.done), _ptr(sub_depth_i32), tick, B, _ptr(sim_steps_dev), st))
+                check(L.snk_mcts_retire(_ptr(sub_active), _ptr(self.done), _ptr(sub_depth_i32), t["tick"], B, _ptr(sim_steps_dev),
+                                        gate or None, st))
+
+            def verify():
+                """called right after a host synchronisation: did the pending tick's evaluation clamp?  Then the device skipped
+                that tick's tail (the gate): widen the scales and run evaluation + tail again, until an evaluation holds."""
+                nonlocal pend
+                redone = False
+                while pend is not None and guard.guard_tripped():
+                    if pend["redos"] >= 4:
+                        raise EngineError("the Q-net's range guard tripped four times on the same batch; use SNK_CONV_ALGO=winograd")
+                    guard.guard_recover()
+                    pend["redos"] += 1
+                    self.guard_redos += 1
+                    tail(pend)
+                    torch.cuda.current_stream().synchronize()      # a rare path: wait for the repeated evaluation's verdict
+                    redone = True
+                pend = None
+                return redone
+
+            pp = 0
+            for tick in range(1, n_ticks + 1):
+                n_eval = head(pp)
+                if guard is not None and verify():
+                    n_eval = head(pp)      # the previous tick has only now been played: this tick's rows are different ones
+                n_rows = int(row_active.sum().item()) if self.tape is not None else 0
+                c0, c1 = self._next_ctr()
+                t = dict(pp=pp, n_eval=n_eval, tick=tick, c0=c0, c1=c1, tape_pos=self.tape_pos, redos=0)
+                tail(t)
+                self.tape_pos += n_rows
+                self.stats["net_evals"] += n_eval
                 self.stats["rollout_ticks"] += 1
+                if guard is not None and n_eval:
+                    pend = t
+                pp ^= 1
+            if pend is not None:             # the epoch's last evaluation is verified before its terminal back-up builds on it
+                torch.cuda.current_stream().synchronize()
+                verify()
             self._sim_steps_pending.append(sim_steps_dev)
             check(L.snk_engine_rewards(self.roll.h, None, B, _ptr(self.rewards), st))
             check(L.snk_mcts_terminal_backup(tt, _ptr(self.rewards), m, _ptr(self.path_entry), _ptr(self.path_move),

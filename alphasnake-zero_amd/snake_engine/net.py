@@ -161,15 +161,6 @@ class QNet:
         self._guard = None
         self.set_weights(weights)
 
-    def __del__(self):
-        try:
-            if self._guard is not None:
-                torch.cuda.synchronize(self.device)
-                self.L.snk_guard_word_destroy(self._guard[2])
-                self._guard = None
-        except Exception:
-            pass
-
     # ---- weights -----------------------------------------------------------------------------
     def set_weights(self, weights):
         self.weights = [np.ascontiguousarray(w, np.float32) for w in weights]
@@ -191,10 +182,8 @@ class QNet:
         if self.conv_algo in ("f16s", "f16", "f16a", "bf16") and self.blocks:
             self._wimg = torch.empty((2 * self.blocks, F16S_WEIGHT_BYTES), dtype=torch.uint8, device=dev)
             self._flags_host = torch.empty((2 * self.blocks,), dtype=torch.int32).pin_memory()
-            if self._guard is None:      # the host-mapped word every layer of this net reports a clamp to (forward_guarded)
-                h, d = C.c_void_p(), C.c_void_p()
-                check(self.L.snk_guard_word_create(C.byref(h), C.byref(d)))
-                self._guard = (C.cast(h, C.POINTER(C.c_int32)), d, h)
+            if self._guard is None:      # ONE device word every layer of this net reports a clamp to, and its pinned host mirror
+                self._guard = (torch.zeros((1,), dtype=torch.int32, device=dev), torch.zeros((1,), dtype=torch.int32).pin_memory())
         for i in range(2 * self.blocks):
             base = 5 + 5 * i
             if self.conv_algo == "bf16":
@@ -214,7 +203,7 @@ class QNet:
                 wT = torch.empty(9 * 128 * 128, dtype=torch.float32, device=dev)
                 check(self.L.snk_conv3x3_prepare_weights(t[base].contiguous().data_ptr(), wT.data_ptr(), st))
             if self._wimg is not None and self.conv_algo != "bf16":
-                check(self.L.snk_conv3x3_f16s_set_guard_word(wT.data_ptr(), self._guard[1], st))
+                check(self.L.snk_conv3x3_f16s_set_guard_word(wT.data_ptr(), self._guard[0].data_ptr(), st))
             sc, sh = fold(*t[base + 1:base + 5])
             self.conv_wT.append(wT); self.conv_sc.append(sc); self.conv_sh.append(sh)
         base = 5 + 10 * self.blocks
@@ -258,7 +247,8 @@ class QNet:
         torch.cuda.current_stream().synchronize()
         out = self._flags_host.tolist()
         if clear:
-            self._guard[0][0] = 0           # the net's guard word says "some flag is set": cleared with them
+            self._guard[0].zero_()          # the net's guard word says "some flag is set": cleared with them
+            self._guard[1].zero_()
             for i, f in enumerate(out):
                 if f:
                     self._tail(i, torch.int32)[4] = 0
@@ -309,24 +299,45 @@ class QNet:
             self._ws[k] = [torch.empty(shape, dtype=torch.float32, device=self.device) for _ in range(3)]
         return self._ws[k]
 
+    # ---- the range guard as ONE word: csrc/conv_split.hip stores 1 to `guard_ptr` when a launch clamps --------------------------
+    @property
+    def guard_ptr(self):
+        """address of the net's device guard word (0: this net has no range to watch): the gate of the rollout tick's kernels"""
+        return self._guard[0].data_ptr() if self._guard is not None and self.conv_algo == "f16s" else 0
+
+    def guard_post(self):
+        """after a forward: copy the guard word to its pinned host mirror, asynchronously -- `guard_tripped` is valid once the
+        stream has been synchronised past this point (the search reads it at its next tick's existing read-back)"""
+        self._guard[1].copy_(self._guard[0], non_blocking=True)
+
+    def guard_tripped(self):
+        return bool(self._guard[1][0])
+
+    def guard_recover(self):
+        """a launch clamped: lower the flagged layers' activation scales by 2^6, clear the flags and the word"""
+        bad = [i for i, f in enumerate(self.range_flags()) if f]      # also clears the word and its mirror
+        self.widen(bad)
+        self.guard_trips += 1
+        return bad
+
     def forward_guarded(self, planes, mask=None, out=None, tries=4):
-        """forward() whose result is float32-accurate or an error: after the batch the stream is synchronised and the net's
-        guard word read (host-mapped: no copy); a layer that clamped an input gets its activation scale
-        lowered by 2^6 and the WHOLE batch is evaluated again, so no caller ever sees a Q value computed from clamped
-        activations.  (f16s only; the other algorithms have no range to watch and return forward() as it is.)"""
-        if self.conv_algo != "f16s":
+        """forward() whose result is float32-accurate or an error, for callers that can wait: after the batch the guard word is
+        copied back and the stream synchronised; a layer that clamped an input gets its activation scale lowered by 2^6 and
+        the WHOLE batch is evaluated again, so the caller never sees a Q value computed from clamped activations.  (f16s
+        only; the other algorithms have no range to watch and return forward() as it is.  The search does not wait: its
+        tick kernels are gated on the word instead, snake_engine/mcts.py.)"""
+        if not self.guard_ptr:                 # no range to watch / a net without tower layers
             return self.forward(planes, mask, out)
-        word = self._guard[0]
+        bad = []
         for _ in range(tries):
             out = self.forward(planes, mask, out)
+            self.guard_post()
             torch.cuda.current_stream().synchronize()
-            if not word[0]:                  # the host-mapped guard word: no launch of this forward (or since the last one) clamped
+            if not self.guard_tripped():
                 return out
-            bad = [i for i, f in enumerate(self.range_flags()) if f]      # also clears the word
+            bad = self.guard_recover()
             if not bad:                      # the word was left over from an unguarded launch whose flags somebody has read since
                 return out
-            self.widen(bad)
-            self.guard_trips += 1
         raise EngineError(f"split-f16 convolution: inputs of tower layer(s) {bad} still exceed the f16 range after {tries} "
                           "widenings of their activation scale; use SNK_CONV_ALGO=winograd (no range limit)")
 

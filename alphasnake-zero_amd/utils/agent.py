@@ -211,6 +211,8 @@ class Agent:
     # ---- the net behind the search ------------------------------------------------------------------
     def _evaluate(self, planes, mask):
         nnet = self.nnet
+        if self._mcts is not None and self._mcts.guard is not None:      # gated ticks: no synchronisation per leaf batch
+            return nnet.v_device_unguarded(planes, mask)
         if hasattr(nnet, "v_device"):
             return nnet.v_device(planes, mask)
         V = np.asarray(nnet.v(list(planes.cpu().numpy())), np.float32)      # any object with the reference's .v(X)
@@ -230,6 +232,7 @@ class Agent:
                                     self.max_MCTS_depth, self.max_MCTS_breadth, seed=self._seed,
                                     device=eng.device.index, sequential=self._sequential, tape_u=self._tape_u,
                                     tt_capacity=self._tt_capacity)
+        self._mcts.guard = getattr(self.nnet, "guard", None)         # the Q-net's range-guard word gates the rollout ticks
         if self.verbose is None:
             from utils.mp_game_runner import MPGameRunner
             self._mcts.verbose = bool(MPGameRunner.verbose)
@@ -330,7 +333,7 @@ class MCTSAgent(Agent):
             planes = torch.empty((idx.numel(),) + eng.obs_shape, dtype=torch.float32, device=dev)
             eng.observe(pairs.index_select(0, idx).contiguous(), idx.numel(), planes, None, None)
             q = self._evaluate(planes, mask.index_select(0, idx).contiguous()).contiguous()
-            check(L.snk_tt_set_priors(tt.h, entry.data_ptr(), idx.data_ptr(), idx.numel(), q.data_ptr(), st))
+            check(L.snk_tt_set_priors(tt.h, entry.data_ptr(), idx.data_ptr(), idx.numel(), q.data_ptr(), None, st))
         D = max([len(self._entries[g][s]) for g, s in ids] + [0]) + 1
         pe = np.full((m, D), -1, np.int32); pm = np.zeros((m, D), np.uint8); pl = np.zeros(m, np.int32)
         for i, (g, s) in enumerate(ids):
@@ -341,9 +344,9 @@ class MCTSAgent(Agent):
         est = torch.empty((m,), dtype=torch.float32, device=dev)
         self._ctr += 1
         check(L.snk_mcts_select(tt.h, entry.data_ptr(), m, float(self.softmax_base), None, None, 0, self._seed, self._ctr, 0x4D41,
-                                mv.data_ptr(), est.data_ptr(), None, d_pe.data_ptr(), d_pm.data_ptr(), d_pl.data_ptr(), D, st))
+                                mv.data_ptr(), est.data_ptr(), None, d_pe.data_ptr(), d_pm.data_ptr(), d_pl.data_ptr(), D, None, st))
         check(L.snk_mcts_backup(tt.h, entry.data_ptr(), m, est.data_ptr(), None, d_pe.data_ptr(), d_pm.data_ptr(),
-                                d_pl.data_ptr(), D, 0, st))                       # agent.py:208-220
+                                d_pl.data_ptr(), D, 0, None, st))                 # agent.py:208-220
         mv_h, ent_h, key_h = mv.cpu().numpy(), entry.cpu().numpy(), key.cpu().numpy()
         for i, (g, s) in enumerate(ids):                                         # agent.py:221-222
             self.keys[g][s].append(key_h[i].tobytes())

@@ -77,6 +77,19 @@ class AlphaNNet:
         # 1e-5 contract or an EngineError, for host callers (v) and for the search (Agent.make_moves) alike
         return self._qnet.forward_guarded(planes, mask)
 
+    @property
+    def guard(self):
+        """the Q-net when its evaluations carry a range guard word (the search gates its tick kernels on it), else None"""
+        return self._qnet if self._qnet.guard_ptr else None
+
+    def v_device_unguarded(self, planes, mask):
+        """the search's leaf evaluation: the forward and the asynchronous copy of the guard word, no synchronisation -- the
+        caller MUST gate what it does with the result on `guard.guard_ptr` and check `guard.guard_tripped()` at its next
+        synchronisation (snake_engine.mcts.DeviceMCTS does)"""
+        q = self._qnet.forward(planes, mask)
+        self._qnet.guard_post()
+        return q
+
     def v(self, X):
         """alpha_nnet.py:61-73: list/array of (h, w, 3) float32 observations -> (N, 3) float32"""
         planes = torch.as_tensor(np.ascontiguousarray(np.array(X, dtype=np.float32)), device=self._qnet.device)

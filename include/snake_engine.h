@@ -89,7 +89,7 @@ int snk_engine_clone(const snk_engine *src, const int32_t *d_src_slots, int n, s
  * cross-snake rules as DPP quad broadcasts and LDS bit planes; larger boards run k_step with 16 lanes per game (64 from 122
  * cells on, i.e. one wavefront per game on 19x19).  BASELINE.json's wording "one wavefront steps one game" is the 19x19 form;
  * on 11x11/4 it was measured instruction-bound (three quarters of the lanes idle: 73.7 us per 262 144 games) against 54.9 us for
- * the quad form, the time of a plain copy of the same records.                                  */
+ * the quad form, the time of a plain copy of the same records.
  * d_moves: uint8[n][S] relative moves indexed by snake id (entries of dead snakes ignored).
  * d_spawn_tape: NULL -> food spawn decided on device (Philox; chance = food_spawn_chance,
  *   uniform choice among empty cells, game.py:130-138); else int16[n]: cell to spawn or -1
@@ -103,9 +103,12 @@ int snk_engine_step(snk_engine *e, const int32_t *d_slots, int n, const uint8_t 
                     uint64_t *d_empty, void *stream);
 /* The lock-step form of MCTSMPGameRunner.run (mp_game_runner.py:104-113): slots 0..n-1, of which only those with
  * d_active[i] != 0 are stepped; the others (sub-games retired by their depth cap) are neither read nor written and
- * report d_done[i] = 0.  Food spawning follows the engine's food_spawn_chance (0 for sub-games, game.py:268).   */
+ * report d_done[i] = 0.  Food spawning follows the engine's food_spawn_chance (0 for sub-games, game.py:268).
+ * d_skip (optional): the rollout tick's gate -- a device int32; when it is non-zero at launch time the call steps NO game
+ * (every game reports d_done = 0).  The search passes the Q-net's range-guard word (snk_conv3x3_f16s_set_guard_word): a tick
+ * whose leaf evaluation clamped an activation is not played, the host evaluates again and repeats it.            */
 int snk_engine_step_active(snk_engine *e, const uint8_t *d_active, int n, const uint8_t *d_moves,
-                           uint8_t *d_done, void *stream);
+                           uint8_t *d_done, const int32_t *d_skip, void *stream);
 
 /* ---- Game.get_ids / alive bookkeeping (game.py:76-77) -----------------------------------
  * d_alive: uint8[n][S] (1 = snake alive), d_n_alive (optional): int32[n].                     */
@@ -193,13 +196,13 @@ int snk_conv3x3_bn_f32_winograd(const float *d_x, const float *d_U, const float 
 #define SNK_CONV_F16S_TAIL_OFFSET (9 * 128 * 128 * 4)
 #define SNK_CONV_F16S_FLAG_OFFSET (9 * 128 * 128 * 4 + 16)
 int snk_conv3x3_prepare_weights_f16s(const float *d_w_hwio, void *d_wS, float x_scale, void *stream);
-/* One word for all layers of a net: snk_guard_word_create allocates a host-mapped, coherent int32 (*h_word: the host address,
- * *d_word: the address kernels use); snk_conv3x3_f16s_set_guard_word stores d_word in bytes 24..31 of a weight image's tail
- * (snk_conv3x3_prepare_weights_f16s clears them: register again after every prepare; NULL unregisters).  A launch that clamps
- * then also stores 1 to that word, so after synchronising the stream the host reads *h_word -- no copy, no kernel -- and looks
- * at the per-layer flags only when it is non-zero (QNet.forward_guarded: widen the layer's x_scale, evaluate the batch again). */
-int snk_guard_word_create(int32_t **h_word, int32_t **d_word);
-int snk_guard_word_destroy(int32_t *h_word);
+/* One word for all layers of a net: snk_conv3x3_f16s_set_guard_word stores the address of a caller-owned DEVICE int32 in bytes
+ * 24..31 of a weight image's tail (snk_conv3x3_prepare_weights_f16s clears them: register again after every prepare; NULL
+ * unregisters).  A launch that clamps then also stores 1 to that word.  Two uses: (i) the kernels of a rollout tick that follow
+ * the leaf evaluation take the word as their gate (d_skip of snk_tt_set_priors, snk_mcts_select, snk_mcts_backup,
+ * snk_engine_step_active, snk_mcts_retire) and do nothing when it is non-zero, so a tick whose evaluation clamped leaves no
+ * trace; (ii) the host copies the one word back (asynchronously, read at its next synchronisation) and looks at the per-layer
+ * flags only when it is non-zero: widen that layer's x_scale, evaluate the batch again. */
 int snk_conv3x3_f16s_set_guard_word(void *d_wS, int32_t *d_word, void *stream);
 int snk_conv3x3_bn_f16s(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
                         const float *d_residual, float *d_out, int n_images, int height, int width, int relu,
@@ -320,8 +323,9 @@ int snk_tt_lookup_insert(snk_tt *t, const uint64_t *d_key, const uint8_t *d_acti
 int snk_tt_find(snk_tt *t, const uint64_t *d_key, int m, int now_turn, int max_age, uint32_t *d_entry,
                 float *d_stat7, void *stream);
 /* new entries (agent.py:193-201): total = d_q[j], visit = 1,1,1 for entry d_entry[d_idx ? d_idx[j] : j] */
+/* d_skip (here and in snk_mcts_select / _backup / _retire; optional): the rollout tick's gate, see snk_engine_step_active */
 int snk_tt_set_priors(snk_tt *t, const uint32_t *d_entry, const int32_t *d_idx, int n, const float *d_q,
-                      void *stream);
+                      const int32_t *d_skip, void *stream);
 /* d_q[i] = total/visit of entry d_entry[i * entry_stride]  (cached_values[first_key], agent.py:83-87) */
 int snk_tt_read_q(snk_tt *t, const uint32_t *d_entry, int entry_stride, int m, float *d_q, void *stream);
 
@@ -341,7 +345,7 @@ int snk_tt_read_q(snk_tt *t, const uint32_t *d_entry, int entry_stride, int m, f
 int snk_mcts_select(snk_tt *t, const uint32_t *d_entry, int m, float softmax_base, const double *d_tape_u,
                     const int32_t *d_rank, int64_t tape_base, uint64_t seed, uint32_t ctr0, uint32_t ctr1,
                     uint8_t *d_moves, float *d_est, float *d_pmf, uint32_t *d_path_entry,
-                    uint8_t *d_path_move, int32_t *d_path_len, int path_depth, void *stream);
+                    uint8_t *d_path_move, int32_t *d_path_len, int path_depth, const int32_t *d_skip, void *stream);
 /* The rollout loop's bookkeeping around a tick (mp_game_runner.py:99-113), one launch each:
  * snk_mcts_row_active: d_row_active[b * n_snakes + s] = snake s of sub-game b is alive AND the sub-game is still active
  *   (d_alive_rows: what snk_engine_alive wrote; d_sub_active: uint8[n_subgames]).
@@ -354,10 +358,10 @@ int snk_mcts_gather_rows(const int32_t *d_idx, int n, const int32_t *d_pairs, co
 int snk_mcts_row_active(const uint8_t *d_alive_rows, const uint8_t *d_sub_active, int n_subgames, int n_snakes,
                         uint8_t *d_row_active, void *stream);
 int snk_mcts_retire(uint8_t *d_sub_active, const uint8_t *d_done, const int32_t *d_sub_depth, int tick, int n_subgames,
-                    int64_t *d_sim_steps, void *stream);
+                    int64_t *d_sim_steps, const int32_t *d_skip, void *stream);
 int snk_mcts_backup(snk_tt *t, const uint32_t *d_entry, int m, const float *d_est, const float *d_pmf,
                     uint32_t *d_path_entry, uint8_t *d_path_move, int32_t *d_path_len, int path_depth,
-                    int sequential, void *stream);
+                    int sequential, const int32_t *d_skip, void *stream);
 int snk_mcts_terminal_backup(snk_tt *t, const int8_t *d_rewards, int m, uint32_t *d_path_entry,
                              uint8_t *d_path_move, int32_t *d_path_len, int path_depth, int sequential,
                              void *stream);

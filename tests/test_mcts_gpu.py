@@ -208,7 +208,7 @@ def test_transposition_table_semantics(env):
     e2, nw2 = lookup(2)
     assert nw2.sum() == 0 and np.array_equal(e2, e), "second sight: all hits"
     q = torch.arange(3000 * 3, dtype=torch.float32, device="cuda").reshape(3000, 3)
-    check(L.snk_tt_set_priors(tt.h, entry.data_ptr(), None, 3000, q.data_ptr(), st))
+    check(L.snk_tt_set_priors(tt.h, entry.data_ptr(), None, 3000, q.data_ptr(), None, st))
     # still present at now = touch + max_age + 1, evicted (a miss, re-created in place) one turn later
     e3, nw3 = lookup(2 + 9)
     assert nw3.sum() == 0
@@ -218,7 +218,7 @@ def test_transposition_table_semantics(env):
     key2 = torch.as_tensor(rng.randint(1, 1 << 62, size=(100, 2)).astype(np.int64), device="cuda")
     ent2 = torch.empty(100, dtype=torch.int32, device="cuda"); new2 = torch.empty(100, dtype=torch.uint8, device="cuda")
     check(L.snk_tt_lookup_insert(tt.h, key2.data_ptr(), None, 100, 40, 8, ent2.data_ptr(), new2.data_ptr(), st))
-    check(L.snk_tt_set_priors(tt.h, ent2.data_ptr(), None, 100, q.data_ptr(), st))
+    check(L.snk_tt_set_priors(tt.h, ent2.data_ptr(), None, 100, q.data_ptr(), None, st))
     assert tt.status()[1] == len(distinct) + 100
     tt.rebuild(1 << 12, 40, 8)
     assert tt.status()[1] == 100

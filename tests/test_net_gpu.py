@@ -520,6 +520,7 @@ def test_a_clamped_batch_is_evaluated_again_inside_the_search(env, monkeypatch):
     nn_a, a, good, e1a = play(False)
     nn_b, b, _, e1b = play(True)
     assert nn_a._qnet.guard_trips == 0 and nn_b._qnet.guard_trips >= 1
+    assert a._mcts.guard_redos == 0 and b._mcts.guard_redos == nn_b._qnet.guard_trips     # every trip: that tick's evaluation + tail run again
     assert good[3] <= nn_b._qnet.conv_x_scale[3] <= good[3] * 64.0 and nn_b._qnet.conv_x_scale[:3] == good[:3]
     assert e1a == e1b > 0 and len(a.cached_values) == len(b.cached_values) > e1a, "nothing was forgotten, both tables grew alike"
     assert a._mcts.stats == b._mcts.stats, (a._mcts.stats, b._mcts.stats)          # evaluations, rollout tics, ticks: no double count
@@ -533,6 +534,56 @@ def test_a_clamped_batch_is_evaluated_again_inside_the_search(env, monkeypatch):
     assert not nw._qnet.calibrated
     nw.calibrate(torch.zeros((1, 21, 21, 3), device="cuda"))
     assert nw._qnet.calibrated
+
+
+def test_gated_ticks_replay_a_clamped_evaluation_wherever_it_happens(env, monkeypatch):
+    """the search does not wait for the guard: the kernels of a rollout tick that follow the leaf evaluation are gated on the
+    Q-net's device guard word, the host reads the word's mirror at the next tick's read-back (or at the epoch's end) and runs
+    that tick's evaluation and tail again.  Activation scales are pushed out of range right before chosen forward calls --
+    the first of a root turn, early and middle ones, the very last of a turn's last epoch -- in searches with several ticks
+    per epoch (boards with 2-4 snakes, depth 8, two epochs): records, values, evaluation counts, draws and the table equal
+    those of an undisturbed twin run"""
+    torch, se, net = env
+    monkeypatch.setenv("SNK_CONV_ALGO", "f16s")
+    import random
+    from utils.agent import Agent
+    from utils.alpha_nnet import AlphaNNet
+    from utils.mp_game_runner import MPGameRunner
+    MPGameRunner.verbose = False
+    ws = net.glorot_uniform_weights((21, 21, 3), blocks=4, seed=2)
+
+    def play(trip_calls):
+        random.seed(12)
+        nn_ = AlphaNNet(input_shape=(21, 21, 3), _weights=ws)
+        alice = Agent(nn_, 2, True, 8, 16, seed=3)
+        gr = MPGameRunner(11, 11, 4, 1, 24, seed=5)
+        gr.run(alice, max_turns=8)                                      # calibrates; some snakes die: deeper rollouts
+        qn, calls, orig = nn_._qnet, [0], nn_._qnet.forward
+
+        def fwd(planes, mask=None, out=None):
+            calls[0] += 1
+            if calls[0] in trip_calls:
+                layer = calls[0] % 8
+                qn.set_x_scale(layer, qn.conv_x_scale[layer] * 2.0 ** 14)
+            return orig(planes, mask, out)
+        qn.forward = fwd
+        ticks0 = alice._mcts.stats["rollout_ticks"]
+        gr.run(alice, max_turns=3)
+        return nn_, alice, gr, calls[0], alice._mcts.stats["rollout_ticks"] - ticks0
+
+    nn_a, a, gr_a, n_calls, n_ticks = play(())
+    assert n_ticks > 3 * 2 * 2, "several ticks per epoch"
+    trips = {1, 2, 5, n_calls // 3, n_calls // 2, n_calls - 2, n_calls + 5}     # + 5: the twin's last call comes later (its repeats count)
+    nn_b, b, gr_b, n_calls_b, _ = play(trips)
+    assert nn_a._qnet.guard_trips == 0 and b._mcts.guard_redos == nn_b._qnet.guard_trips >= 4, nn_b._qnet.guard_trips
+    assert n_calls_b == n_calls + b._mcts.guard_redos
+    assert nn_b._qnet.range_flags() == [0] * 8 and not nn_b._qnet.guard_tripped()
+    assert a._mcts.stats == b._mcts.stats, (a._mcts.stats, b._mcts.stats)
+    assert a._mcts.draw_ctr == b._mcts.draw_ctr and len(a.cached_values) == len(b.cached_values)
+    assert gr_a.env_steps == gr_b.env_steps and len(a.records) == len(b.records)
+    assert all(x.tobytes() == y.tobytes() for x, y in zip(a.records[:], b.records[:]))
+    va, vb = np.array(a.values[:]), np.array(b.values[:])
+    assert np.abs(va - vb).max() <= TOL_Q, np.abs(va - vb).max()
 
 
 def test_f16_activation_tower_layer_and_net(env, monkeypatch):
