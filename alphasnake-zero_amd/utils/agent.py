@@ -211,7 +211,8 @@ class Agent:
     # ---- the net behind the search ------------------------------------------------------------------
     def _evaluate(self, planes, mask):
         nnet = self.nnet
-        if self._mcts is not None and self._mcts.guard is not None:      # gated ticks: no synchronisation per leaf batch
+        m = getattr(self, "_mcts", None)                               # (MCTSAgent has none: its evaluations wait for the guard)
+        if m is not None and m.guard is not None:                       # gated ticks: no synchronisation per leaf batch
             return nnet.v_device_unguarded(planes, mask)
         if hasattr(nnet, "v_device"):
             return nnet.v_device(planes, mask)
