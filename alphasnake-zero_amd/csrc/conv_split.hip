@@ -37,6 +37,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
 
 // the 16-bit activation type of the reduced-precision towers is f16 or (BF) bf16; both travel through the kernel as 16-bit
 // patterns typed _Float16 (staging copies them untouched), only the MFMA and these two conversions know the difference
@@ -56,9 +57,13 @@ template <bool BF> __device__ __forceinline__ _Float16 hs_to16(float v)
 #define HS_LDP 80                                        // bytes per LDS pixel: [hi k0-15 | lo k0-15] + 16 (16 x odd: conflict-free b128)
 #define HS_NPB 352                                       // pixels per LDS buffer
 #define HS_MLD 132                                       // epilogue row (floats): 528 bytes = 16 x 33
-#define HS_SMEM_STAGE (2 * HS_NPB * HS_LDP)              // 56 320 bytes
+#define HS_SMEM_STAGE (2 * HS_BUF16)                     // 65 536 bytes (split form: 2 x 352 x 80 = 56 320)
 #define HS_SMEM_EPI (2 * 64 * HS_MLD * 4)                // 67 584 bytes
+#ifdef HS_ONE_PER_CU      // development build only: a block alone on its compute unit (what does the co-resident block cost it?)
+#define HS_SMEM (96 * 1024)
+#else
 #define HS_SMEM (HS_SMEM_EPI > HS_SMEM_STAGE ? HS_SMEM_EPI : HS_SMEM_STAGE)
+#endif
 #define HS_WS_ELEMS (9 * HS_C * HS_C * 2)                // f16 numbers in the split weight image; four floats follow it
 #define HS_RING 3
 #define HS_AHEAD 2
@@ -66,6 +71,25 @@ template <bool BF> __device__ __forceinline__ _Float16 hs_to16(float v)
 #define HS_XLOAD_TAP 0                                   // the tap at whose start the next chunk's pixel loads are issued (A/B: make variant EXTRA=-DHS_XLOAD_TAP=1)
 #endif
 #define HS_NST 5                                         // staging items per thread and chunk: 64 pixels x 4 float4 each
+// the frame of the towers with 16-bit activations (IO16 bit 0; BASELINE configs[4]): a chunk is 32 input channels = two MFMA k
+// steps, so the 80-byte LDS pixel holds [channels 0-15 | 16-31] where the split form keeps [hi | lo]: half the chunks, barriers and
+// A-pipeline restarts per block, and a chunk's MFMAs (2 x 9 x NI) outlast the HBM latency of the next chunk's pixel loads even
+// when the block has the SIMDs to itself (with 16-channel chunks a block's chunk loop was bound by that latency: 3.7 k cycles per
+// chunk for 1.4 k of MFMA issue, profiles/r5_a16_stamps.log).  No lo parts: the same LDS bytes hold more pixels (8-tile blocks on a
+// 37-pixel-wide canvas) and a staging item is one 16-byte load and one ds_write_b128.
+#define HS_NST16 6                                       // 16-bit frame: staging items per thread and chunk (64 pixels x 4 pieces of 16 bytes each)
+#define HS_BUF16 32768                                   // 16-bit frame: bytes per LDS buffer.  Its rows are pitched in BYTES:
+//   80 W + 256 (whole images: the 256-byte gap holds the zero border on both sides) or 80 (w + 2) + 96 (sub-rectangles: real halo
+//   columns), so that stepping from a row's last pixel to the next row's first moves the address by 336 bytes = 21 bank quads = 5
+//   mod 16, exactly like a step inside a row: the sixteen lanes a ds_read_b128 serves together never share a bank quad.  (With
+//   rows pitched W + 1 pixels a lane group that straddles a row end spans 17 slots and two lanes collide: 37 % of this frame's
+//   LDS cycles were conflict cycles, profiles/r5_a16_sq_counters_before.json, and the LDS, which serves a fragment read per MFMA
+//   here, is what the co-resident block's epilogue and prologue wait for.)
+#define HS_GAP16_FULL 256
+#define HS_GAP16_RECT 96
+#ifndef HS_PRIO
+#define HS_PRIO 3
+#endif
 
 struct ConvHsArgs {
     const float *x;            // [n][Hd][Wd][128]
@@ -96,6 +120,9 @@ struct ConvHsArgs {
 __device__ unsigned long long hs_stamp_buf[16384 * 8];
 #define HS_STAMP(k) if (tid == 0 && blockIdx.x < 16384) hs_stamp_buf[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime();
 #define HS_STAMP_REAL(k) if (tid == 0 && blockIdx.x < 16384) hs_stamp_buf[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime();
+// where the block runs: HW_ID (hwreg 4: wave slot, SIMD, CU, SH, SE, workgroup slot) | XCC_ID (hwreg 20) << 32
+#define HS_STAMP_HWID(k) if (tid == 0 && blockIdx.x < 16384) hs_stamp_buf[blockIdx.x * 8 + (k)] = \
+        (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32;
 extern "C" int snk_dbg_conv_stamps(unsigned long long *h_out, int n_blocks)
 {
     SNK_CHECK_HIP(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(hs_stamp_buf), (size_t)n_blocks * 8 * sizeof(unsigned long long)));
@@ -104,6 +131,7 @@ extern "C" int snk_dbg_conv_stamps(unsigned long long *h_out, int n_blocks)
 #else
 #define HS_STAMP(k)
 #define HS_STAMP_REAL(k)
+#define HS_STAMP_HWID(k)
 #endif
 
 // NI: M tiles (of 32 GEMM rows) per block, <= 8.  MODE fixes the epilogue's options at compile time (no branches per row):
@@ -132,6 +160,12 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     static_assert(!BF || (IO16 & 1), "the bf16 form reads bf16 activations");
     constexpr bool IN16 = (IO16 & 1) != 0, OUT16 = (IO16 & 2) != 0;
     constexpr bool STATS = MODE == 4;
+    constexpr bool K32 = IN16;                             // the 16-bit frame: 32 input channels per chunk (two MFMA k steps)
+    constexpr bool TWO = SPLIT || K32;                     // two A fragments / two B fragments per (tap, M tile)
+    constexpr int KC = K32 ? 32 : HS_KC, NCHUNK = HS_C / KC;
+    constexpr int NST = K32 ? HS_NST16 : HS_NST, BUFB = K32 ? HS_BUF16 : HS_NPB * HS_LDP;
+    constexpr int PIECE = K32 ? 8 : 4;                     // channels of a staging item
+    constexpr bool P8 = IN16 && OUT16;                     // the epilogue handles 8 channels (16 bytes in and out) per thread and row
     const bool has_res = MODE == 0 ? p.res != nullptr : (MODE == 2 || MODE == 3);
     const bool has_head = MODE == 0 ? p.w1x1 != nullptr : MODE == 3;
     const bool has_out = MODE == 0 ? p.out != nullptr : MODE != 3;
@@ -143,7 +177,8 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     const int HW = RECT ? rh * rw : p.Hd * p.Wd;           // its pixels = GEMM rows
     const int HWc = p.Hd * p.Wd;                           // the canvas: what the tensors in HBM are pitched by
     const int m0 = 32 * tile0, m1 = min(32 * (tile0 + ntile), HW);      // the block's GEMM rows = pixels m0 .. m1 - 1 of the image
-    const int P = RECT ? Wr + 2 : Wr + 1;                  // padded pitch
+    const int P = RECT ? Wr + 2 : Wr + 1;                  // padded pitch (pixels)
+    const int PB = K32 ? (RECT ? (Wr + 2) * HS_LDP + HS_GAP16_RECT : Wr * HS_LDP + HS_GAP16_FULL) : P * HS_LDP;   // LDS row pitch (bytes)
     const float invW = 1.0f / (float)Wr;
     const int y_first = (int)(((float)m0 + 0.5f) * invW), y_last = (int)(((float)(m1 - 1) + 0.5f) * invW);
     // LDS row r holds image row y_first - 1 + r (zero when outside the canvas), LDS column x + 1 image column x
@@ -156,43 +191,45 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     const int ws = xb - xa + 1;
     const int npx = (yb - ya + 1) * ws;
     const float invWs = RECT ? 1.0f / (float)ws : invW;
-    const float *xrow = p.x + (((long)img * p.Hd + ya) * p.Wd + xa) * HS_C + 4 * (tid & 3);
-    const _Float16 *xrow16 = (const _Float16 *)p.x + (((long)img * p.Hd + ya) * p.Wd + xa) * HS_C + 4 * (tid & 3);
+    const float *xrow = p.x + (((long)img * p.Hd + ya) * p.Wd + xa) * HS_C + PIECE * (tid & 3);
+    const _Float16 *xrow16 = (const _Float16 *)p.x + (((long)img * p.Hd + ya) * p.Wd + xa) * HS_C + PIECE * (tid & 3);
     const int pix0 = tid >> 2;
     const float xs = p.wscale_inv[2];                      // activations are multiplied by this power of two before the split
-    unsigned ldo[HS_NST];                                  // LDS byte offset (inside a buffer) of the thread's items
-    unsigned gof[HS_NST];                                  // element offset of the items in x (chunk 0)
-    const float *gp[HS_NST];                               // RECT: the items' addresses (chunk 0): in x where the producing layer wrote
-    const _Float16 *gp16[HS_NST];                          //   (bounding box grown by grow_in), else in that layer's background image
+    unsigned ldo[NST];                                     // LDS byte offset (inside a buffer) of the thread's items
+    unsigned gof[NST];                                     // element offset of the items in x (chunk 0)
+    const float *gp[NST];                                  // RECT: the items' addresses (chunk 0): in x where the producing layer wrote
+    const _Float16 *gp16[NST];                             //   (bounding box grown by grow_in), else in that layer's background image
     const int by0 = bbox & 255, bx0 = (bbox >> 8) & 255, by1 = (bbox >> 16) & 255, bx1 = bbox >> 24;
     const bool sel_in = RECT && p.bg_in != nullptr;
     // items past the strip's last pixel repeat it (same value to the same LDS address): no predication, no branches
 #pragma unroll
-    for (int k = 0; k < HS_NST; ++k) {
+    for (int k = 0; k < NST; ++k) {
         const int pix_ = min(pix0 + 64 * k, npx - 1);
         const int r_ = (int)(((float)pix_ + 0.5f) * invWs), x_ = pix_ - r_ * ws;
-        ldo[k] = ((ry_lo + r_) * P + cx_lo + x_) * HS_LDP + (tid & 3) * 8;
+        ldo[k] = (ry_lo + r_) * PB + (cx_lo + x_) * HS_LDP + (tid & 3) * (K32 ? 16 : 8);
         gof[k] = (r_ * p.Wd + x_) * HS_C;
         if (RECT) {
             const int Y = ya + r_, X = xa + x_;
             const bool stale = sel_in && (Y < by0 - p.grow_in || Y > by1 + p.grow_in || X < bx0 - p.grow_in || X > bx1 + p.grow_in);
-            const long o_ = (long)(Y * p.Wd + X) * HS_C + 4 * (tid & 3);
+            const long o_ = (long)(Y * p.Wd + X) * HS_C + PIECE * (tid & 3);
             gp[k] = (stale ? p.bg_in : p.x + (long)img * HWc * HS_C) + o_;
             gp16[k] = (stale ? (const _Float16 *)p.bg_in : (const _Float16 *)p.x + (long)img * HWc * HS_C) + o_;
         }
     }
-    float4 st[HS_NST];
-    f16x4 st16[HS_NST];
+    float4 st[K32 ? 1 : NST];
+    f16x4 st16[K32 ? 1 : NST];
+    f16x8 st8[K32 ? NST : 1];                              // the 16-bit frame's items: eight channels, staged as they are
     f16x4 hi_t;
     float4 d_t;
     float amax = 0.f;                                      // largest |scaled input| this thread staged: 65504 = something was clamped
-#define HS_LOAD(c) _Pragma("unroll") for (int k_ = 0; k_ < HS_NST; ++k_) {                      \
-        if (IN16) st16[k_] = *(const f16x4 *)((RECT ? gp16[k_] : xrow16 + gof[k_]) + HS_KC * (c)); \
-        else st[k_] = *(const float4 *)((RECT ? gp[k_] : xrow + gof[k_]) + HS_KC * (c)); }
+#define HS_LOAD(c) _Pragma("unroll") for (int k_ = 0; k_ < NST; ++k_) {                         \
+        if (K32) st8[k_] = *(const f16x8 *)((RECT ? gp16[k_] : xrow16 + gof[k_]) + KC * (c));   \
+        else if (IN16) st16[k_] = *(const f16x4 *)((RECT ? gp16[k_] : xrow16 + gof[k_]) + KC * (c)); \
+        else st[k_] = *(const float4 *)((RECT ? gp[k_] : xrow + gof[k_]) + KC * (c)); }
 // split of one staged float4 in two halves that sit in different MFMA regions (a region hides about 15 VALU instructions):
 //   A: clamp to the f16 range, hi = f16(v), d = v - hi;   B: lo = f16(d), both written to LDS
 #define HS_SPLIT_A(kk)                                                                          \
-    if (IN16) { hi_t = st16[kk]; } else                                                         \
+    if (K32) { } else if (IN16) { hi_t = st16[kk]; } else                                       \
     {                                                                                           \
         float4 v_ = st[kk];                                                                     \
         v_.x *= xs; v_.y *= xs; v_.z *= xs; v_.w *= xs;                                         \
@@ -206,6 +243,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
         }                                                                                       \
     }
 #define HS_SPLIT_B(k_, bufoff)                                                                  \
+    if (K32) { *(f16x8 *)(smem + (bufoff) + ldo[k_]) = st8[k_]; } else                          \
     {                                                                                           \
         unsigned char *d_ = smem + (bufoff) + ldo[k_];                                          \
         *(f16x4 *)d_ = hi_t;                                                                    \
@@ -217,18 +255,19 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     }
 
     HS_STAMP(0)
+    HS_STAMP_HWID(7)
     const f16x8 *wl = p.wS + wn * 128 + lane;              // this wave's fragments of global step g = 9 chunk + tap: wl[g * 512 + {0 hi, 64 lo}]
     f16x8 Bq[HS_RING][2];
 #define HS_LOADB(slot, g)                                                                       \
     {                                                                                           \
         const f16x8 *w_ = wl + (long)(g) * 512;                                                 \
         Bq[slot][0] = w_[0];                                                                    \
-        if (SPLIT) Bq[slot][1] = w_[64];                                                        \
+        if (TWO) Bq[slot][1] = w_[64];                                                          \
     }
     HS_LOAD(0)
 #pragma unroll
     for (int s = 0; s < HS_AHEAD; ++s) HS_LOADB(s, s);
-    for (int o = tid * 16; o < HS_SMEM_STAGE; o += 256 * 16) *(uint4 *)(smem + o) = make_uint4(0u, 0u, 0u, 0u);   // borders stay zero
+    for (int o = tid * 16; o < 2 * BUFB; o += 256 * 16) *(uint4 *)(smem + o) = make_uint4(0u, 0u, 0u, 0u);   // borders stay zero
     f32x16 acc[NI];
 #pragma unroll
     for (int a = 0; a < NI; ++a)
@@ -236,7 +275,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < HS_NST; ++k) { HS_SPLIT_A(k) HS_SPLIT_B(k, 0) }
+    for (int k = 0; k < NST; ++k) { HS_SPLIT_A(k) HS_SPLIT_B(k, 0) }
     __syncthreads();
 
     unsigned la[NI];                                       // LDS byte address (buffer 0, centre tap) of the lane's pixel in M tile i
@@ -244,7 +283,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     for (int i = 0; i < NI; ++i) {
         const int m_ = min(m0 + 32 * i + l31, HW - 1);     // rows past the image repeat its last pixel (computed, never stored)
         const int y_ = (int)(((float)m_ + 0.5f) * invW), x_ = m_ - y_ * Wr;
-        la[i] = (unsigned)((y_ - (y_first - 1)) * P + x_ + 1) * HS_LDP + 16 * h;
+        la[i] = (unsigned)((y_ - (y_first - 1)) * PB + (x_ + 1) * HS_LDP) + 16 * h;
     }
 #define HS_LDS(off) (*(const f16x8 *)(smem + (off)))
 #define HS_MFMA(a, b, c) c = BF ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0) \
@@ -254,21 +293,21 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
 // sinks the reads to the MFMAs that consume them and the wave eats the LDS latency once per tile).  The tile sequence
 // runs across taps: tile t of the chunk is (tap t / NI, M tile t % NI).  Staging of the next chunk: HS_NST global
 // loads at tap 0, their split halves (A, B) in the chunk's last 2 HS_NST regions.
-#define HS_AOFF(t) (la[(t) % NI] + rb + (unsigned)((((t) / NI) / 3 - 1) * P + (((t) / NI) % 3 - 1)) * HS_LDP)
+#define HS_AOFF(t) (la[(t) % NI] + rb + (unsigned)((((t) / NI) / 3 - 1) * PB + (((t) / NI) % 3 - 1) * HS_LDP))
 #define HS_TAP(s, MORE)                                                                         \
         {                                                                                       \
             _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                    \
                 const int t2_ = (s) * NI + i + 2;                                               \
                 f16x8 nh = a1h, nl = a1l;                                                       \
-                if (t2_ < 9 * NI) { nh = HS_LDS(HS_AOFF(t2_)); if (SPLIT) nl = HS_LDS(HS_AOFF(t2_) + 32); } \
+                if (t2_ < 9 * NI) { nh = HS_LDS(HS_AOFF(t2_)); if (TWO) nl = HS_LDS(HS_AOFF(t2_) + 32); } \
                 __builtin_amdgcn_sched_barrier(0);                                              \
                 if (i == 0) {                                                                   \
                     if (MORE || (s) + HS_AHEAD < 9) { HS_LOADB(((s) + HS_AHEAD) % HS_RING, gnext + (s)); } \
                     if ((s) == HS_XLOAD_TAP && MORE) { HS_LOAD(c + 1) }                         \
                 }                                                                               \
                 {                                                                               \
-                    const int tl_ = (s) * NI + i - (9 * NI - 2 * HS_NST);                       \
-                    if (MORE && 9 * NI >= 2 * HS_NST && tl_ >= 0) {                             \
+                    const int tl_ = (s) * NI + i - (9 * NI - 2 * NST);                          \
+                    if (MORE && 9 * NI >= 2 * NST && tl_ >= 0) {                                \
                         if ((tl_ & 1) == 0) { HS_SPLIT_A((tl_ < 0 ? 0 : tl_ >> 1)) }            \
                         else { HS_SPLIT_B((tl_ < 0 ? 0 : tl_ >> 1), wb) }                       \
                     }                                                                           \
@@ -277,6 +316,8 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
                 if (SPLIT) {                                                                    \
                     HS_MFMA(a0h, Bq[(s) % HS_RING][1], acc[i]);                                 \
                     HS_MFMA(a0l, Bq[(s) % HS_RING][0], acc[i]);                                 \
+                } else if (K32) {                        /* the chunk's second k step: channels 16-31 */ \
+                    HS_MFMA(a0l, Bq[(s) % HS_RING][1], acc[i]);                                 \
                 }                                                                               \
                 a0h = a1h; a0l = a1l; a1h = nh; a1l = nl;                                       \
                 __builtin_amdgcn_sched_barrier(0);                                              \
@@ -284,26 +325,31 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
         }
 #define HS_CHUNK(MORE)                                                                          \
     {                                                                                           \
-        const unsigned rb = (unsigned)(c & 1) * (HS_NPB * HS_LDP);                              \
-        const unsigned wb = (unsigned)((c & 1) ^ 1) * (HS_NPB * HS_LDP);                        \
+        const unsigned rb = (unsigned)(c & 1) * BUFB;                                           \
+        const unsigned wb = (unsigned)((c & 1) ^ 1) * BUFB;                                     \
         const int gnext = c * 9 + HS_AHEAD;             /* global step the first prefetch of this chunk fetches */ \
         f16x8 a0h = HS_LDS(HS_AOFF(0)), a1h = HS_LDS(HS_AOFF(1)), a0l = a0h, a1l = a1h;         \
-        if (SPLIT) { a0l = HS_LDS(HS_AOFF(0) + 32); a1l = HS_LDS(HS_AOFF(1) + 32); }            \
+        if (TWO) { a0l = HS_LDS(HS_AOFF(0) + 32); a1l = HS_LDS(HS_AOFF(1) + 32); }              \
         HS_TAP(0, MORE) HS_TAP(1, MORE) HS_TAP(2, MORE) HS_TAP(3, MORE) HS_TAP(4, MORE)         \
         HS_TAP(5, MORE) HS_TAP(6, MORE) HS_TAP(7, MORE) HS_TAP(8, MORE)                         \
-        if (MORE && 9 * NI < 2 * HS_NST) {              /* too few regions to spread the split over: do it here */ \
-            _Pragma("unroll") for (int k = 0; k < HS_NST; ++k) { HS_SPLIT_A(k) HS_SPLIT_B(k, wb) } \
+        if (MORE && 9 * NI < 2 * NST) {                 /* too few regions to spread the split over: do it here */ \
+            _Pragma("unroll") for (int k = 0; k < NST; ++k) { HS_SPLIT_A(k) HS_SPLIT_B(k, wb) } \
         }                                                                                       \
         __syncthreads();                                                                        \
     }
     int c = 0;
     HS_STAMP(1)
+    // the chunk loop's waves go before the co-resident block's prologue / epilogue waves (16-bit frame: a third of the split form's
+    // MFMAs per block, so a block's frame is 30 % of its life and what it costs the partner's matrix stream shows: +2.5-3 %, A/B
+    // in one call, profiles/r5_a16_ab.log; the split form measured no gain in rounds 3-4)
+    if (K32) __builtin_amdgcn_s_setprio(HS_PRIO);
     HS_STAMP_REAL(5)
 #pragma unroll 1
-    for (; c < HS_C / HS_KC - 1; ++c) HS_CHUNK(true)
+    for (; c < NCHUNK - 1; ++c) HS_CHUNK(true)
     HS_STAMP(2)
     HS_CHUNK(false)                    // the last chunk stages nothing
     HS_STAMP(3)
+    if (K32) __builtin_amdgcn_s_setprio(0);
     // range guard: an input beyond the f16 range after scaling was clamped, the layer's result is then NOT float32-accurate.
     // The flag word sits behind the scales in the weight image (one per layer); the host reads it (QNet.check_range).
     // The same event is also stored to the device word tail[6..7] points to, when the caller registered one (ONE word for all
@@ -330,6 +376,89 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     //      handles float4 pieces of whole pixel rows: thread (rr0 = tid / 32, cq = tid % 32) takes rows rr0 + 8 j of the
     //      pass, outputs 4 cq .. 4 cq + 3.  The residual loads of pass k + 1 are issued before pass k is exchanged and
     //      stored; one block barrier per pass (the other block of the CU computes meanwhile).
+    if constexpr (P8) {
+        // ---- the 16-bit frame's epilogue: the same double-buffered exchange, but a thread takes EIGHT channels of a row (16 bytes of
+        //      shortcut in, 16 bytes out; 16 lanes per pixel row, rows rr0 + 16 j of the pass): half the memory instructions
+        const int cq = tid & 15, rr0 = tid >> 4;
+        const float winv = p.wscale_inv[0] * p.wscale_inv[3];
+        float4 scA = *(const float4 *)(p.scale + 8 * cq), scB = *(const float4 *)(p.scale + 8 * cq + 4);
+        const float4 shA = *(const float4 *)(p.shift + 8 * cq), shB = *(const float4 *)(p.shift + 8 * cq + 4);
+        scA.x *= winv; scA.y *= winv; scA.z *= winv; scA.w *= winv; scB.x *= winv; scB.y *= winv; scB.z *= winv; scB.w *= winv;
+        float *Ms = (float *)smem;                                      // [2][64 rows][HS_MLD]
+        constexpr int NPASS = (NI + 1) / 2;
+        f16x8 rv[NPASS][4];                 // ALL shortcut rows of the block are requested before the first pass: one HBM latency per
+        unsigned off[NPASS][4];             //   block instead of one per pass (the registers of the main loop's fragments are free by now)
+        // the output goes through a buffer descriptor of the image: rows past the block's pixels carry an offset beyond the image and
+        // the hardware's range check drops their stores.  No branch around a store: with branches the compiler cannot count the
+        // stores in flight and puts s_waitcnt vmcnt(0) before every use of a shortcut row -- each row then waits for the previous
+        // row's store to be acknowledged by HBM (16 round trips per block: 11 k of this epilogue's 16 k cycles, profiles/r5_a16_stamps.log)
+        const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((_Float16 *)p.out + (long)img * HWc * HS_C), 0, HWc * HS_C * 2, 0x00020000);
+        const bool sel_res = RECT && p.bg_res != nullptr;
+#define HS_ROWS(pass) (((pass) + 1 < NPASS ? 2 : NI - 2 * (NPASS - 1)) * 32)
+#define HS_EPI_PREP(pass)                 /* element offsets of this thread's rows (-1: past the block's pixels) + shortcut loads */ \
+        {                                                                                       \
+            _Pragma("unroll") for (int j = 0; j < HS_ROWS(pass) / 16; ++j) {                    \
+                const int m_ = m0 + 64 * (pass) + rr0 + 16 * j;                                 \
+                bool stale_ = false;                                                            \
+                if (RECT) {                                                                     \
+                    const int y_ = (int)(((float)m_ + 0.5f) * invW), x_ = m_ - y_ * Wr;         \
+                    off[pass][j] = m_ < m1 ? (unsigned)(((cy0 + y_) * p.Wd + cx0 + x_) * HS_C + 8 * cq) : 0x40000000u; \
+                    stale_ = sel_res && (cy0 + y_ < by0 - p.grow_res || cy0 + y_ > by1 + p.grow_res || \
+                                         cx0 + x_ < bx0 - p.grow_res || cx0 + x_ > bx1 + p.grow_res); \
+                } else off[pass][j] = m_ < m1 ? (unsigned)(m_ * HS_C + 8 * cq) : 0x40000000u;  \
+                if (has_res) {                                                                  \
+                    const _Float16 *rb_ = stale_ ? (const _Float16 *)p.bg_res : (const _Float16 *)p.res + (long)img * HWc * HS_C; \
+                    rv[pass][j] = *(const f16x8 *)(rb_ + (off[pass][j] < 0x40000000u ? off[pass][j] : 8u * cq)); \
+                }                                                                               \
+            }                                                                                   \
+        }
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) HS_EPI_PREP(pass)
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            float *Mb = Ms + (pass & 1) * (64 * HS_MLD);
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+                if (2 * pass + ii < NI) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        Mb[(32 * ii + (r & 3) + 8 * (r >> 2) + 4 * h) * HS_MLD + 32 * wn + l31] = acc[2 * pass + ii][r];
+                }
+            __syncthreads();
+            float4 mA[4], mB[4];
+#pragma unroll
+            for (int j = 0; j < HS_ROWS(pass) / 16; ++j) {
+                mA[j] = *(const float4 *)&Mb[(rr0 + 16 * j) * HS_MLD + 8 * cq];
+                mB[j] = *(const float4 *)&Mb[(rr0 + 16 * j) * HS_MLD + 8 * cq + 4];
+            }
+#pragma unroll
+            for (int j = 0; j < HS_ROWS(pass) / 16; ++j) {
+                float v[8] = {__builtin_fmaf(mA[j].x, scA.x, shA.x), __builtin_fmaf(mA[j].y, scA.y, shA.y),
+                              __builtin_fmaf(mA[j].z, scA.z, shA.z), __builtin_fmaf(mA[j].w, scA.w, shA.w),
+                              __builtin_fmaf(mB[j].x, scB.x, shB.x), __builtin_fmaf(mB[j].y, scB.y, shB.y),
+                              __builtin_fmaf(mB[j].z, scB.z, shB.z), __builtin_fmaf(mB[j].w, scB.w, shB.w)};
+                f16x8 o_;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t_ = v[e];
+                    if (has_res) t_ += hs_from16<BF>(rv[pass][j][e]);
+                    o_[e] = hs_to16<BF>(fmaxf(t_, relu_floor));
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o_), o_rsrc, 2u * off[pass][j], 0, 0);
+            }
+        }
+#undef HS_ROWS
+#undef HS_EPI_PREP
+        if (RECT && p.bg_out) {              // see the other frame's copy loop below: 16 lanes per pixel here
+            const float invF = 1.0f / (float)p.Wd;
+            for (int q = part * 16 + rr0; q < HWc; q += 16 * parts) {
+                const int y_ = (int)(((float)q + 0.5f) * invF), x_ = q - y_ * p.Wd;
+                if (y_ >= cy0 && y_ < cy0 + rh && x_ >= cx0 && x_ < cx0 + rw) continue;
+                const int o_ = (y_ * p.Wd + x_) * HS_C + 8 * cq;
+                *(f16x8 *)((_Float16 *)p.out + (long)img * HWc * HS_C + o_) = *(const f16x8 *)((const _Float16 *)p.bg_out + o_);
+            }
+        }
+    } else {
     const int cq = tid & 31, rr0 = tid >> 5;
     const float winv = p.wscale_inv[0] * p.wscale_inv[3];
     float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -446,6 +575,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
             else *(float4 *)(p.out + (long)img * HWc * HS_C + o_) = *(const float4 *)(p.bg_out + o_);
         }
     }
+    }      // the epilogue of the other frames
     HS_STAMP(4)
 }
 
@@ -532,8 +662,7 @@ __global__ void k_f16s_tail_from(const float *__restrict__ w_tail, const float *
 
 // Keras kernel (kh, kw, cin, cout) float32 -> split f16 fragments in the order the conv kernel's waves load them
 // FLIP: the kernel of the INPUT GRADIENT of the same layer -- taps mirrored, channel axes swapped: w'[tap][ci][co] = w[8 - tap][co][ci]
-// BF: the parts are written as bf16 patterns (the bf16 tower uses the hi parts only)
-template <bool FLIP, bool BF = false>
+template <bool FLIP>
 __global__ void k_f16s_weights(const float *__restrict__ w, _Float16 *__restrict__ wS, const float *__restrict__ tail)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;          // one f16x8 fragment piece
@@ -547,13 +676,28 @@ __global__ void k_f16s_weights(const float *__restrict__ w, _Float16 *__restrict
     for (int j = 0; j < 8; ++j) {
         const int cin = HS_KC * c + 8 * h + j;
         const float val = (FLIP ? w[(long)((8 - tap) * HS_C + cout) * HS_C + cin] : w[(long)(tap * HS_C + cin) * HS_C + cout]) * mul;
-        if (BF) {
-            const __bf16 hb = (__bf16)val;
-            wS[(long)v * 8 + j] = __builtin_bit_cast(_Float16, hl ? (__bf16)(val - (float)hb) : hb);
-            continue;
-        }
         const _Float16 hi = (_Float16)val;
         wS[(long)v * 8 + j] = hl ? (_Float16)(val - (float)hi) : hi;
+    }
+}
+
+// the 16-bit frame's weight image: [chunk of 32 input channels 4][tap 9][wn 4][k step 2][lane 64] x 8 values (f16, or bf16
+// patterns): the two fragments a wave loads per (chunk, tap) are the chunk's two MFMA k steps, where the split image keeps hi and lo
+template <bool BF>
+__global__ void k_a16_weights(const float *__restrict__ w, _Float16 *__restrict__ wS, const float *__restrict__ tail)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;          // one fragment piece of eight values
+    if (v >= 9 * HS_C * HS_C / 8) return;
+    const float mul = tail[1];
+    const int g = v / 512, rem = v - g * 512;
+    const int c = g / 9, tap = g - 9 * c;
+    const int wn = rem >> 7, ks = (rem >> 6) & 1, lane = rem & 63;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int cout = 32 * wn + l31;
+    for (int j = 0; j < 8; ++j) {
+        const int cin = 32 * c + 16 * ks + 8 * h + j;
+        const float val = w[(long)(tap * HS_C + cin) * HS_C + cout] * mul;
+        wS[(long)v * 8 + j] = BF ? __builtin_bit_cast(_Float16, (__bf16)val) : (_Float16)val;
     }
 }
 
@@ -586,7 +730,19 @@ extern "C" int snk_conv3x3_prepare_weights_bf16(const float *d_w_hwio, void *d_w
     SNK_REQUIRE(d_w_hwio && d_wS, "snk_conv3x3_prepare_weights_bf16: NULL argument");
     float *tail = (float *)((_Float16 *)d_wS + HS_WS_ELEMS);
     k_f16s_wscale<<<1, 1024, 0, (hipStream_t)stream>>>(d_w_hwio, tail, 1.0f);
-    k_f16s_weights<false, true><<<(HS_WS_ELEMS / 8 + 255) / 256, 256, 0, (hipStream_t)stream>>>(d_w_hwio, (_Float16 *)d_wS, tail);
+    k_a16_weights<true><<<(9 * HS_C * HS_C / 8 + 255) / 256, 256, 0, (hipStream_t)stream>>>(d_w_hwio, (_Float16 *)d_wS, tail);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// the weight image of the f16-activation tower (snk_conv3x3_bn_f16_act16): the same layout with f16 values (pre-scaled by the power of
+// two that brings max |w| to [256, 512); undone in the epilogue), activation scale 1
+extern "C" int snk_conv3x3_prepare_weights_f16_act16(const float *d_w_hwio, void *d_wS, void *stream)
+{
+    SNK_REQUIRE(d_w_hwio && d_wS, "snk_conv3x3_prepare_weights_f16_act16: NULL argument");
+    float *tail = (float *)((_Float16 *)d_wS + HS_WS_ELEMS);
+    k_f16s_wscale<<<1, 1024, 0, (hipStream_t)stream>>>(d_w_hwio, tail, 1.0f);
+    k_a16_weights<false><<<(9 * HS_C * HS_C / 8 + 255) / 256, 256, 0, (hipStream_t)stream>>>(d_w_hwio, (_Float16 *)d_wS, tail);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -619,6 +775,8 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
     SNK_REQUIRE(d_out != d_x, "snk_conv3x3_bn_f16s: in-place convolution is not possible (blocks read their neighbours' input rows)");
     if (n_images == 0) return 0;
     const int P = width + 1, HW = height * width;
+    const bool a16 = (io16 & 1) != 0;                      // the 16-bit frame: LDS rows pitched in bytes, six staging items
+    const int nst_px = 64 * (a16 ? HS_NST16 : HS_NST);
     // GEMM rows = the image's pixels in row-major order, 32 per M tile; an image is cut into n_blk blocks of at most 8 M
     // tiles whose input rows (those of its pixels + one above and below) fit the LDS buffer and the staging items
     const int T = (HW + 31) / 32;
@@ -627,7 +785,8 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
     for (;; ++n_blk) {
         tiles_max = (T + n_blk - 1) / n_blk;
         const int rows_out = min((tiles_max * 32 + width - 2) / width + 1, height);       // worst alignment of 32 tiles_max pixels
-        fits = (rows_out + 2) * P + 1 <= HS_NPB && min(rows_out + 2, height) * width <= 64 * HS_NST;
+        fits = (a16 ? (rows_out + 2) * (width * HS_LDP + HS_GAP16_FULL) <= HS_BUF16 : (rows_out + 2) * P + 1 <= HS_NPB) &&
+               min(rows_out + 2, height) * width <= nst_px;
         if (fits || tiles_max == 1) break;
     }
     SNK_REQUIRE(fits, "snk_conv3x3_bn_f16s: observation width %d not supported (max 80)", width);
@@ -664,22 +823,40 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
     // the three epilogue shapes the net wrapper uses get compile-time versions at the 21x21 tile count; everything else
     // takes the generic version
     if (!split && io16) {        // f16 activations in HBM (io16: 1 = f16 in, f32 out; 3 = f16 in and out)
+#define HS_LAUNCH_IO4(NI_, MODE_)                                                               \
+        if (bf && io16 == 3) k_conv3x3_f16s<NI_, MODE_, false, 3, true><<<grid, 256, 0, st>>>(a); \
+        else if (bf) k_conv3x3_f16s<NI_, MODE_, false, 1, true><<<grid, 256, 0, st>>>(a);       \
+        else if (io16 == 3) k_conv3x3_f16s<NI_, MODE_, false, 3><<<grid, 256, 0, st>>>(a);      \
+        else k_conv3x3_f16s<NI_, MODE_, false, 1><<<grid, 256, 0, st>>>(a);
+// the tower's two shapes (ReLU without / with shortcut) have compile-time epilogues; anything else takes the generic one
 #define HS_LAUNCH_IO(NI_)                                                                       \
     case NI_:                                                                                   \
-        if (bf && io16 == 3) k_conv3x3_f16s<NI_, 0, false, 3, true><<<grid, 256, 0, st>>>(a);   \
-        else if (bf) k_conv3x3_f16s<NI_, 0, false, 1, true><<<grid, 256, 0, st>>>(a);           \
-        else if (io16 == 3) k_conv3x3_f16s<NI_, 0, false, 3><<<grid, 256, 0, st>>>(a);          \
-        else k_conv3x3_f16s<NI_, 0, false, 1><<<grid, 256, 0, st>>>(a);                         \
+        if (relu && !d_residual) { HS_LAUNCH_IO4(NI_, 1) }                                      \
+        else if (relu) { HS_LAUNCH_IO4(NI_, 2) }                                                \
+        else { HS_LAUNCH_IO4(NI_, 0) }                                                          \
         break;
+        if (d_w1x1) {            // the tower's last layer with the head's 1x1 stage in its epilogue: no layer output
+            SNK_REQUIRE(io16 == 1 && relu && d_residual && !d_out && d_h1, "snk_conv3x3_bn_*_act16_head: the fused head closes a residual block");
+#define HS_LAUNCH_HEAD(NI_) case NI_: if (bf) k_conv3x3_f16s<NI_, 3, false, 1, true><<<grid, 256, 0, st>>>(a); \
+                                      else k_conv3x3_f16s<NI_, 3, false, 1><<<grid, 256, 0, st>>>(a); break;
+            switch (n_mt) {
+                HS_LAUNCH_HEAD(1) HS_LAUNCH_HEAD(2) HS_LAUNCH_HEAD(3) HS_LAUNCH_HEAD(4) HS_LAUNCH_HEAD(5) HS_LAUNCH_HEAD(6) HS_LAUNCH_HEAD(7)
+            default: if (bf) k_conv3x3_f16s<8, 3, false, 1, true><<<grid, 256, 0, st>>>(a);
+                     else k_conv3x3_f16s<8, 3, false, 1><<<grid, 256, 0, st>>>(a); break;
+            }
+#undef HS_LAUNCH_HEAD
+            SNK_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
         switch (n_mt) {
             HS_LAUNCH_IO(1) HS_LAUNCH_IO(2) HS_LAUNCH_IO(3) HS_LAUNCH_IO(4) HS_LAUNCH_IO(5) HS_LAUNCH_IO(6) HS_LAUNCH_IO(7)
         default:
-            if (bf && io16 == 3) k_conv3x3_f16s<8, 0, false, 3, true><<<grid, 256, 0, st>>>(a);
-            else if (bf) k_conv3x3_f16s<8, 0, false, 1, true><<<grid, 256, 0, st>>>(a);
-            else if (io16 == 3) k_conv3x3_f16s<8, 0, false, 3><<<grid, 256, 0, st>>>(a);
-            else k_conv3x3_f16s<8, 0, false, 1><<<grid, 256, 0, st>>>(a);
+            if (relu && !d_residual) { HS_LAUNCH_IO4(8, 1) }
+            else if (relu) { HS_LAUNCH_IO4(8, 2) }
+            else { HS_LAUNCH_IO4(8, 0) }
             break;
         }
+#undef HS_LAUNCH_IO4
 #undef HS_LAUNCH_IO
         SNK_CHECK_HIP(hipGetLastError());
         return 0;
@@ -724,15 +901,18 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
 // ---- planning of the sub-rectangle form ------------------------------------------------------------------------------
 // parts (blocks) a rectangle of hr x wr pixels is cut into and the M tiles of its largest part: the fewest parts of at most
 // 8 tiles whose strip (their rows, one above, one below, halo columns) fits the LDS buffer and the staging items
-__host__ __device__ static inline int hs_rect_parts(int hr, int wr, int Hd, int Wd, int *tiles_max)
+// (a16: the 16-bit towers' frame -- rows pitched in bytes with a gap, six staging items)
+__host__ __device__ static inline int hs_rect_parts(int hr, int wr, int Hd, int Wd, int *tiles_max, bool a16 = false)
 {
+    const int nst_px = 64 * (a16 ? HS_NST16 : HS_NST);
     const int T = (hr * wr + 31) / 32;
     for (int parts = (T + 7) / 8;; ++parts) {
         const int tm = (T + parts - 1) / parts;
         int rows_out = (tm * 32 + wr - 2) / wr + 1;                       // worst alignment of 32 tm pixels
         if (rows_out > hr) rows_out = hr;
         const int rows_in = rows_out + 2 < Hd ? rows_out + 2 : Hd, cols_in = wr + 2 < Wd ? wr + 2 : Wd;
-        const bool fits = (rows_out + 2) * (wr + 2) <= HS_NPB && rows_in * cols_in <= 64 * HS_NST;
+        const bool fits = (a16 ? (rows_out + 2) * ((wr + 2) * HS_LDP + HS_GAP16_RECT) <= HS_BUF16 : (rows_out + 2) * (wr + 2) <= HS_NPB) &&
+                          rows_in * cols_in <= nst_px;
         if (fits || tm == 1) { *tiles_max = tm; return fits ? parts : -1; }
     }
 }
@@ -772,6 +952,7 @@ struct RectPlanArgs {
     uint4 *desc;                           // [n_layers][max_blocks]
     long max_blocks;
     int *counts;                           // [n_layers][2]: descriptors written, M tiles they cover
+    bool a16;                              // the descriptors are cut for the 16-bit towers' block frame
 };
 
 // One workgroup per layer: every image's rectangle -> its parts -> block descriptors, largest blocks first (bins by the
@@ -789,7 +970,7 @@ __global__ __launch_bounds__(1024) void k_rect_plan(const unsigned *__restrict__
         const int y0 = max((int)(b & 255) - g, 0), x0 = max((int)((b >> 8) & 255) - g, 0);
         const int y1 = min((int)((b >> 16) & 255) + g, Hd - 1), x1 = min((int)(b >> 24) + g, Wd - 1);
         int tm;
-        const int parts = hs_rect_parts(y1 - y0 + 1, x1 - x0 + 1, Hd, Wd, &tm);
+        const int parts = hs_rect_parts(y1 - y0 + 1, x1 - x0 + 1, Hd, Wd, &tm, a.a16);
         atomicAdd(&cnt[tm], parts);
         tiles += ((y1 - y0 + 1) * (x1 - x0 + 1) + 31) / 32;
     }
@@ -809,7 +990,7 @@ __global__ __launch_bounds__(1024) void k_rect_plan(const unsigned *__restrict__
         const int y1 = min((int)((b >> 16) & 255) + g, Hd - 1), x1 = min((int)(b >> 24) + g, Wd - 1);
         const int hr = y1 - y0 + 1, wr = x1 - x0 + 1;
         int tm;
-        const int parts = hs_rect_parts(hr, wr, Hd, Wd, &tm);
+        const int parts = hs_rect_parts(hr, wr, Hd, Wd, &tm, a.a16);
         const int T = (hr * wr + 31) / 32, base = T / parts, rem = T % parts;
         const unsigned rect = (unsigned)y0 | (unsigned)x0 << 8 | (unsigned)hr << 16 | (unsigned)wr << 24;
         const int slot = atomicAdd(&cur[tm], parts);
@@ -820,35 +1001,40 @@ __global__ __launch_bounds__(1024) void k_rect_plan(const unsigned *__restrict__
     }
 }
 
-static int rect_max_parts(int height, int width)
+static int rect_max_parts(int height, int width, bool act16)
 {
-    static int cache_h = 0, cache_w = 0, cache_v = 0;
-    if (cache_h == height && cache_w == width) return cache_v;
+    static int cache_h[2] = {0, 0}, cache_w[2] = {0, 0}, cache_v[2] = {0, 0};
+    const int f = act16 ? 1 : 0;
+    if (cache_h[f] == height && cache_w[f] == width) return cache_v[f];
     int worst = 1;
     for (int hr = 1; hr <= height; ++hr)
         for (int wr = 1; wr <= width; ++wr) {
             int tm;
-            const int parts = hs_rect_parts(hr, wr, height, width, &tm);
+            const int parts = hs_rect_parts(hr, wr, height, width, &tm, act16);
             if (parts < 0) return -1;
             if (parts > worst) worst = parts;
         }
-    cache_h = height; cache_w = width; cache_v = worst;
+    cache_h[f] = height; cache_w[f] = width; cache_v[f] = worst;
     return worst;
 }
 
-extern "C" long snk_conv_rect_max_blocks(int n_images, int height, int width)
+static long rect_max_blocks(int n_images, int height, int width, bool act16)
 {
     if (n_images < 0 || height < 3 || width < 3 || height > 80 || width > 80) return -1;
-    const int mp = rect_max_parts(height, width);
+    const int mp = rect_max_parts(height, width, act16);
     return mp < 0 ? -1 : (long)n_images * mp;
 }
 
-extern "C" int snk_conv_rect_plan(const float *d_planes, float b0, float b1, float b2, int n_images, int height, int width,
-                                  int n_layers, const int *grow, void *d_bbox, void *d_desc, int *d_counts, void *stream)
+extern "C" long snk_conv_rect_max_blocks(int n_images, int height, int width) { return rect_max_blocks(n_images, height, width, false); }
+// the towers with 16-bit activations cut rectangles for their own block frame (more pixels per LDS buffer and per staging pass)
+extern "C" long snk_conv_rect_max_blocks_act16(int n_images, int height, int width) { return rect_max_blocks(n_images, height, width, true); }
+
+static int rect_plan(const float *d_planes, float b0, float b1, float b2, int n_images, int height, int width,
+                     int n_layers, const int *grow, void *d_bbox, void *d_desc, int *d_counts, void *stream, bool act16)
 {
     SNK_REQUIRE(d_planes && grow && d_bbox && d_desc && d_counts, "snk_conv_rect_plan: NULL argument");
     SNK_REQUIRE(n_layers >= 1 && n_layers <= HS_RECT_MAX_LAYERS, "snk_conv_rect_plan: %d layers (at most %d)", n_layers, HS_RECT_MAX_LAYERS);
-    const long mb = snk_conv_rect_max_blocks(n_images, height, width);
+    const long mb = rect_max_blocks(n_images, height, width, act16);
     SNK_REQUIRE(mb >= 0 && mb < (1l << 31), "snk_conv_rect_plan: bad shape %d x %d x %d", n_images, height, width);
     if (n_images == 0) return 0;
     RectPlanArgs a;
@@ -858,11 +1044,25 @@ extern "C" int snk_conv_rect_plan(const float *d_planes, float b0, float b1, flo
         a.grow[i] = grow[i];
     }
     a.desc = (uint4 *)d_desc; a.max_blocks = mb; a.counts = d_counts;
+    a.a16 = act16;
     hipStream_t st = (hipStream_t)stream;
     k_obs_bbox<<<(n_images + 3) / 4, 256, 0, st>>>(d_planes, n_images, height, width, b0, b1, b2, (unsigned *)d_bbox);
     k_rect_plan<<<n_layers, 1024, 0, st>>>((const unsigned *)d_bbox, n_images, height, width, a);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int snk_conv_rect_plan(const float *d_planes, float b0, float b1, float b2, int n_images, int height, int width,
+                                  int n_layers, const int *grow, void *d_bbox, void *d_desc, int *d_counts, void *stream)
+{
+    return rect_plan(d_planes, b0, b1, b2, n_images, height, width, n_layers, grow, d_bbox, d_desc, d_counts, stream, false);
+}
+
+// the plan of the towers with 16-bit activations (descriptor array: snk_conv_rect_max_blocks_act16 per layer)
+extern "C" int snk_conv_rect_plan_act16(const float *d_planes, float b0, float b1, float b2, int n_images, int height, int width,
+                                        int n_layers, const int *grow, void *d_bbox, void *d_desc, int *d_counts, void *stream)
+{
+    return rect_plan(d_planes, b0, b1, b2, n_images, height, width, n_layers, grow, d_bbox, d_desc, d_counts, stream, true);
 }
 
 static int conv_f16s_rect_launch(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
@@ -873,7 +1073,7 @@ static int conv_f16s_rect_launch(const float *d_x, const void *d_wS, const float
     SNK_REQUIRE(grow_in >= 0 && grow_in < 128 && grow_res >= 0 && grow_res < 128, "snk_conv3x3_bn_f16s_rect: grow_in %d, grow_res %d", grow_in, grow_res);
     SNK_REQUIRE(d_x && d_wS && d_scale && d_shift && d_out && d_desc && d_count, "snk_conv3x3_bn_f16s_rect: NULL argument");
     SNK_REQUIRE(d_out != d_x, "snk_conv3x3_bn_f16s_rect: in-place convolution is not possible");
-    const long mb = snk_conv_rect_max_blocks(n_images, height, width);
+    const long mb = rect_max_blocks(n_images, height, width, act16);
     SNK_REQUIRE(mb >= 0 && mb < (1l << 31) && (long)height * width * HS_C < (1l << 31), "snk_conv3x3_bn_f16s_rect: bad shape %d x %d x %d",
                 n_images, height, width);
     if (n_images == 0) return 0;
@@ -998,4 +1198,26 @@ extern "C" int snk_conv3x3_bn_bf16_act16(const void *d_x16, const void *d_wS, co
     SNK_REQUIRE(d_x16 && d_wS && d_scale && d_shift && d_out, "snk_conv3x3_bn_bf16_act16: NULL argument");
     return conv_f16s_launch((const float *)d_x16, d_wS, d_scale, d_shift, (const float *)d_residual16, (float *)d_out, nullptr, 0.f,
                             0.f, nullptr, n_images, height, width, relu, false, stream, out_bf16 ? 3 : 1, nullptr, nullptr, nullptr, true);
+}
+
+// The last layer of the towers with 16-bit activations with the head's 1x1 stage in its epilogue (alpha_nnet.py:46-50), as
+// snk_conv3x3_bn_f16s_head does for the float32 tower: d_h1[n][height * width] = relu(dot(relu(bn(conv) + shortcut)[pixel][:],
+// w1x1) * bn_scale + bn_shift); the layer's own output never goes to HBM (in float32 it would be twice the bytes of every other
+// activation of these towers).  snk_head_dense_f32 finishes AlphaNNet.v from d_h1.
+extern "C" int snk_conv3x3_bn_f16_act16_head(const void *d_x16, const void *d_wS, const float *d_scale, const float *d_shift,
+                                             const void *d_residual16, const float *d_w1x1, float bn_scale, float bn_shift,
+                                             float *d_h1, int n_images, int height, int width, void *stream)
+{
+    SNK_REQUIRE(d_x16 && d_wS && d_scale && d_shift && d_residual16 && d_w1x1 && d_h1, "snk_conv3x3_bn_f16_act16_head: NULL argument");
+    return conv_f16s_launch((const float *)d_x16, d_wS, d_scale, d_shift, (const float *)d_residual16, nullptr, d_w1x1, bn_scale,
+                            bn_shift, d_h1, n_images, height, width, 1, false, stream, 1);
+}
+
+extern "C" int snk_conv3x3_bn_bf16_act16_head(const void *d_x16, const void *d_wS, const float *d_scale, const float *d_shift,
+                                              const void *d_residual16, const float *d_w1x1, float bn_scale, float bn_shift,
+                                              float *d_h1, int n_images, int height, int width, void *stream)
+{
+    SNK_REQUIRE(d_x16 && d_wS && d_scale && d_shift && d_residual16 && d_w1x1 && d_h1, "snk_conv3x3_bn_bf16_act16_head: NULL argument");
+    return conv_f16s_launch((const float *)d_x16, d_wS, d_scale, d_shift, (const float *)d_residual16, nullptr, d_w1x1, bn_scale,
+                            bn_shift, d_h1, n_images, height, width, 1, false, stream, 1, nullptr, nullptr, nullptr, true);
 }

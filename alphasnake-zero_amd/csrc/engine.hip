@@ -23,7 +23,7 @@ void snk_set_error(const char *fmt, ...)
     va_end(ap);
 }
 extern "C" const char *snk_last_error(void) { return g_err; }
-extern "C" int snk_version(void) { return 100; }
+extern "C" int snk_version(void) { return SNK_ABI_VERSION; }
 
 #define WAVES_PER_BLOCK 4
 #define BLOCK_THREADS (WAVES_PER_BLOCK * 64)

@@ -776,8 +776,8 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs p)
 // The head behind a fused 1x1 stage (snk_conv3x3_bn_f16s_head wrote h1 = relu(bn(conv1x1)) [n][HW]):
 // Flatten -> Dense(128) + ReLU -> Dense(3) + tanh -> obstacle overwrite.  16 states per block, so the 226 KB Dense
 // kernel is read once per 16 states instead of once per state; thread (j = tid % 128, half = tid / 128) accumulates
-// output j of 8 states.
-#define HD_S 16
+// output j of 8 states.  (HD_S = 8 or 4 states per block where sixteen states' h1 do not fit 64 KB of LDS: 37 x 37.)
+template <int HD_S>
 __global__ __launch_bounds__(256) void k_head_dense(HeadArgs p, const float *__restrict__ h1g)
 {
     extern __shared__ float sm[];
@@ -1019,10 +1019,12 @@ extern "C" int snk_head_dense_f32(const float *d_h1, const float *d_fc1_w, const
 {
     SNK_REQUIRE(d_h1 && d_fc1_w && d_fc1_b && d_fc2_w && d_fc2_b && d_q, "snk_head_dense_f32: NULL argument");
     if (n_images <= 0) return 0;
-    const size_t lds = (size_t)HD_S * (height * width + 128) * sizeof(float);
-    SNK_REQUIRE(lds <= 64 * 1024, "snk_head_dense_f32: %d x %d observation too large", height, width);
+    const size_t per_state = (size_t)(height * width + 128) * sizeof(float);
+    SNK_REQUIRE(4 * per_state <= 64 * 1024, "snk_head_dense_f32: %d x %d observation too large", height, width);
     HeadArgs a = {nullptr, nullptr, 0.f, 0.f, d_fc1_w, d_fc1_b, d_fc2_w, d_fc2_b, d_mask, d_q, n_images, height * width};
-    k_head_dense<<<(n_images + HD_S - 1) / HD_S, 256, lds, (hipStream_t)stream>>>(a, d_h1);
+    if (16 * per_state <= 64 * 1024) k_head_dense<16><<<(n_images + 15) / 16, 256, 16 * per_state, (hipStream_t)stream>>>(a, d_h1);
+    else if (8 * per_state <= 64 * 1024) k_head_dense<8><<<(n_images + 7) / 8, 256, 8 * per_state, (hipStream_t)stream>>>(a, d_h1);
+    else k_head_dense<4><<<(n_images + 3) / 4, 256, 4 * per_state, (hipStream_t)stream>>>(a, d_h1);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }

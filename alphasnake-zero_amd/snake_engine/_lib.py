@@ -6,6 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SNK_LIB_PATH") or os.path.join(_HERE, "libsnake_engine.so")      # SNK_LIB_PATH: a variant build (A/B runs)
 
 MAX_SNAKES, MAX_CELLS, MAX_NODES = 8, 361, 384
+ABI_VERSION = 110        # SNK_ABI_VERSION of include/snake_engine.h these prototypes were written against
 
 
 class EngineError(RuntimeError):
@@ -56,6 +57,11 @@ PROTOTYPES = {
     "snk_conv3x3_prepare_weights": (i32, [vp, vp, vp]),
     "snk_conv3x3_bn_f32": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "snk_conv3x3_prepare_weights_bf16": (i32, [vp, vp, vp]),
+    "snk_conv3x3_prepare_weights_f16_act16": (i32, [vp, vp, vp]),
+    "snk_conv3x3_bn_f16_act16_head": (i32, [vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, i32, i32, i32, vp]),
+    "snk_conv3x3_bn_bf16_act16_head": (i32, [vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, i32, i32, i32, vp]),
+    "snk_conv_rect_max_blocks_act16": (C.c_long, [i32, i32, i32]),
+    "snk_conv_rect_plan_act16": (i32, [vp, C.c_float, C.c_float, C.c_float, i32, i32, i32, i32, C.POINTER(i32), vp, vp, vp, vp]),
     "snk_conv3x3_bn_bf16_act16": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "snk_conv3x3_bn_bf16_act16_rect": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, i32, i32, i32, vp]),
     "snk_stem_conv_bn_relu_bf16out": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
@@ -147,6 +153,10 @@ def lib():
                 f"{LIB_PATH} is missing: build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
         L = C.CDLL(LIB_PATH)
+        _bind(L, {"snk_version": PROTOTYPES["snk_version"]})
+        if L.snk_version() != ABI_VERSION:      # argument lists changed between versions: a stale library would take shifted arguments
+            raise EngineError(f"{LIB_PATH} reports ABI version {L.snk_version()}, these bindings are written for {ABI_VERSION}; "
+                              "rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
         _bind(L, PROTOTYPES)
         _lib = L
     return _lib

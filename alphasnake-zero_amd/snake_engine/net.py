@@ -190,9 +190,11 @@ class QNet:
                 self.conv_x_scale[i] = 1.0
                 wT = self._wimg[i]
                 check(self.L.snk_conv3x3_prepare_weights_bf16(t[base].contiguous().data_ptr(), wT.data_ptr(), st))
-            elif self.conv_algo in ("f16s", "f16", "f16a"):
-                if self.conv_algo == "f16a":
-                    self.conv_x_scale[i] = 1.0               # f16 activations are staged as they are
+            elif self.conv_algo == "f16a":
+                self.conv_x_scale[i] = 1.0                   # f16 activations are staged as they are
+                wT = self._wimg[i]
+                check(self.L.snk_conv3x3_prepare_weights_f16_act16(t[base].contiguous().data_ptr(), wT.data_ptr(), st))
+            elif self.conv_algo in ("f16s", "f16"):
                 wT = self._wimg[i]
                 check(self.L.snk_conv3x3_prepare_weights_f16s(t[base].contiguous().data_ptr(), wT.data_ptr(),
                                                               self.conv_x_scale[i], st))
@@ -378,21 +380,24 @@ class QNet:
         L = self.L
         if self.conv_algo == "bf16":
             return (L.snk_stem_conv_bn_relu_bf16out, L.snk_stem_conv_bn_relu_bf16out_rect, L.snk_conv3x3_bn_bf16_act16,
-                    L.snk_conv3x3_bn_bf16_act16_rect)
+                    L.snk_conv3x3_bn_bf16_act16_rect, L.snk_conv3x3_bn_bf16_act16_head)
         return (L.snk_stem_conv_bn_relu_f16out, L.snk_stem_conv_bn_relu_f16out_rect, L.snk_conv3x3_bn_f16_act16,
-                L.snk_conv3x3_bn_f16_act16_rect)
+                L.snk_conv3x3_bn_f16_act16_rect, L.snk_conv3x3_bn_f16_act16_head)
 
     def _forward_chunk_f16a(self, planes, mask, out, s0, m, k):
         """the tower with f16 / bf16 activations in HBM: stem -> 16 bit, every layer 16 -> 16 bit, the last one 16 bit -> float32"""
         st = torch.cuda.current_stream().cuda_stream
         L, h, w = self.L, self.h, self.w
-        stem16, stem16_rect, conv16, conv16_rect = self._fn16()
+        stem16, stem16_rect, conv16, conv16_rect, conv16_head = self._fn16()
+        # the last layer's epilogue does the head's 1x1 stage (its float32 output -- twice the bytes of any other activation of
+        # this tower -- never goes to HBM); SNK_HEAD_FUSE=0: the separate head kernel on the layer's float32 output
+        fused_head = self._head_fits() and os.environ.get("SNK_HEAD_FUSE", "1") != "0"
         key = ("a16", k)
         if self._ws is None:
             self._ws = {}
-        if key not in self._ws or self._ws[key][0].shape[0] < m:
+        if key not in self._ws or self._ws[key][0].shape[0] < m or (self._ws[key][3] is None) != fused_head:
             bufs = [torch.empty((m, h, w, 128), dtype=self.act16, device=self.device) for _ in range(3)]
-            bufs.append(torch.empty((m, h, w, 128), dtype=torch.float32, device=self.device))
+            bufs.append(None if fused_head else torch.empty((m, h, w, 128), dtype=torch.float32, device=self.device))
             self._ws[key] = bufs
         bufs = self._ws[key]
         a, b, c, last = bufs
@@ -411,7 +416,10 @@ class QNet:
             if tm is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(torch.cuda.current_stream())
-            if plan is not None and i < self.n_rect:       # a sub-rectangle layer is never the last one: f16 output
+            if dst is None:                                # the last layer with the fused head: dst_h1 instead of a layer output
+                check(conv16_head(xin.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(), self.conv_sh[i].data_ptr(),
+                                  res.data_ptr(), self.head_w.data_ptr(), self.head_s, self.head_b, h1.data_ptr(), m, h, w, st))
+            elif plan is not None and i < self.n_rect:     # a sub-rectangle layer is never the last one: f16 output
                 check(conv16_rect(xin.data_ptr(), self.conv_wT[i].data_ptr(), self.conv_sc[i].data_ptr(),
                                   self.conv_sh[i].data_ptr(), None if res is None else res.data_ptr(),
                                   dst.data_ptr(), *self._rect_args(i, plan, res), m, h, w, st))
@@ -422,6 +430,7 @@ class QNet:
             if tm is not None:
                 e1.record(torch.cuda.current_stream())
                 tm.append((e0, e1, 2.0 * m * h * w * 9 * 128 * 128))
+        h1 = self._h1_workspace(m, k) if fused_head else None
         for blk in range(self.blocks):
             conv(2 * blk, cur, None, t1, True)
             if blk == self.blocks - 1:
@@ -430,6 +439,10 @@ class QNet:
                 conv(2 * blk + 1, t1, cur, t2, True)
                 cur, t2 = t2, cur
         mk = None if mask is None else mask[s0:s0 + m]
+        if fused_head:
+            check(L.snk_head_dense_f32(h1.data_ptr(), self.fc1_w.data_ptr(), self.fc1_b.data_ptr(), self.fc2_w.data_ptr(),
+                                       self.fc2_b.data_ptr(), 0 if mk is None else mk.data_ptr(), out[s0:s0 + m].data_ptr(), m, h, w, st))
+            return
         check(L.snk_head_f32(last.data_ptr(), self.head_w.data_ptr(), self.head_s, self.head_b,
                              self.fc1_w.data_ptr(), self.fc1_b.data_ptr(), self.fc2_w.data_ptr(), self.fc2_b.data_ptr(),
                              0 if mk is None else mk.data_ptr(), out[s0:s0 + m].data_ptr(), m, h, w, st))
@@ -452,7 +465,7 @@ class QNet:
                                               self.stem_sh.data_ptr(), a.data_ptr(), m, h, w, st))
         cur, t1, t2 = a, b, c
         # the last layer's epilogue also does the head's 1x1 stage (snk_head_dense_f32 keeps 16 states' h1 in 64 KB of LDS)
-        fused_head = self.conv_algo == "f16s" and self.blocks > 0 and 16 * (h * w + 128) * 4 <= 64 * 1024
+        fused_head = self.conv_algo == "f16s" and self.blocks > 0 and self._head_fits()
         for blk in range(self.blocks):
             i0, i1 = 2 * blk, 2 * blk + 1
             self._conv(i0, cur, None, t1, m, st, plan=plan)
@@ -470,6 +483,10 @@ class QNet:
         check(L.snk_head_f32(cur.data_ptr(), self.head_w.data_ptr(), self.head_s, self.head_b,
                              self.fc1_w.data_ptr(), self.fc1_b.data_ptr(), self.fc2_w.data_ptr(), self.fc2_b.data_ptr(),
                              0 if mk is None else mk.data_ptr(), out[s0:s0 + m].data_ptr(), m, h, w, st))
+
+    def _head_fits(self):
+        """snk_head_dense_f32 keeps the h1 rows of 16, 8 or 4 states in 64 KB of LDS"""
+        return 4 * (self.h * self.w + 128) * 4 <= 64 * 1024
 
     def _h1_workspace(self, n, k=0):
         key = ("h1", k)
@@ -529,7 +546,8 @@ class QNet:
     def _rect_plan(self, x, m, k, st):
         """descriptors of this chunk's sub-rectangle layers: (descriptor tensor [n_rect][max_blocks][4], counts [n_rect][2])"""
         bg = self.backgrounds()
-        mb = int(self.L.snk_conv_rect_max_blocks(m, self.h, self.w))
+        a16 = self.act16 is not None          # the 16-bit towers cut rectangles for their own block frame
+        mb = int((self.L.snk_conv_rect_max_blocks_act16 if a16 else self.L.snk_conv_rect_max_blocks)(m, self.h, self.w))
         if mb < 0:
             raise EngineError(f"sub-rectangle convolution: shape {m} x {self.h} x {self.w} not supported")
         key = ("rect", k)
@@ -549,8 +567,8 @@ class QNet:
         # the descriptor array of layer l starts at l * max_blocks(m): the tensor may be wider (an earlier, larger chunk)
         desc_m = desc if desc.shape[1] == mb else desc.view(-1)[:self.n_rect * mb * 4].view(self.n_rect, mb, 4)
         b0, b1, b2 = self.background
-        check(self.L.snk_conv_rect_plan(x.data_ptr(), b0, b1, b2, m, self.h, self.w, self.n_rect, grow,
-                                        bbox.data_ptr(), desc_m.data_ptr(), counts.data_ptr(), st))
+        check((self.L.snk_conv_rect_plan_act16 if a16 else self.L.snk_conv_rect_plan)(
+            x.data_ptr(), b0, b1, b2, m, self.h, self.w, self.n_rect, grow, bbox.data_ptr(), desc_m.data_ptr(), counts.data_ptr(), st))
         return desc_m, counts, bg, bbox
 
     def _conv(self, i, x, res, out, m, st, h1=None, plan=None):

@@ -50,6 +50,8 @@ typedef struct {
 } snk_game_state;
 
 const char *snk_last_error(void);
+#define SNK_ABI_VERSION 110 /* 100: rounds 1-3; 110: round 5 (the gate argument d_skip of the tick kernels, round 4; the 16-bit
+                             * towers' own weight image and rectangle plan, round 5): a caller compares it with snk_version() */
 int snk_version(void);
 
 /* ---- engine lifetime -------------------------------------------------------------------
@@ -236,6 +238,12 @@ int snk_conv_rect_plan(const float *d_planes, float b0, float b1, float b2, int 
 int snk_stem_conv_bn_relu_f32_rect(const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,
                                    float *d_out, const void *d_bbox, int grow, int n_images, int height, int width,
                                    void *stream);
+/* The plan of the towers with 16-bit activations (snk_conv3x3_bn_f16_act16_rect / _bf16_act16_rect): their block frame holds
+ * more pixels per LDS buffer (no lo parts), so a rectangle is cut into fewer, larger blocks; same arguments and descriptor
+ * format, the descriptor array of a layer has snk_conv_rect_max_blocks_act16(n, height, width) entries. */
+long snk_conv_rect_max_blocks_act16(int n_images, int height, int width);
+int snk_conv_rect_plan_act16(const float *d_planes, float b0, float b1, float b2, int n_images, int height, int width,
+                             int n_layers, const int *grow, void *d_bbox, void *d_desc, int *d_counts, void *stream);
 /* the same two for the reduced-precision tower with f16 activations (snk_stem_conv_bn_relu_f16out, snk_conv3x3_bn_f16_act16 with
  * relu = 1 and f16 output; f16 background images) */
 int snk_stem_conv_bn_relu_f16out_rect(const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,
@@ -259,8 +267,12 @@ int snk_conv3x3_bn_f16s_head(const float *d_x, const void *d_wS, const float *d_
                              float bn_shift, float *d_h1, int n_images, int height, int width, void *stream);
 /* Reduced precision with f16 ACTIVATIONS in HBM (BASELINE configs[4], "bf16-class MFMA conv"; outside the 1e-5
  * tolerance, never the default): d_x16 / d_residual16 are f16 [n][H][W][128] arrays, the output is f16 (out_f16 != 0:
- * every tower layer but the last) or float32 (the layer the head reads); weights = snk_conv3x3_prepare_weights_f16s
- * with x_scale 1.  snk_stem_conv_bn_relu_f16out is the stem that feeds it.                                       */
+ * every tower layer but the last) or float32 (the layer the head reads); weights = snk_conv3x3_prepare_weights_f16_act16
+ * (f16 values in the 16-bit towers' image: [chunk of 32 input channels][tap][32-output tile][k step][lane] x 8, pre-scaled by
+ * a power of two that the epilogue undoes).  snk_stem_conv_bn_relu_f16out is the stem that feeds it.  The block frame of
+ * these towers works in chunks of 32 input channels (two MFMA k steps per LDS pixel) and its epilogue moves 16 bytes per
+ * thread and row in and out.                                                                                      */
+int snk_conv3x3_prepare_weights_f16_act16(const float *d_w_hwio, void *d_wS, void *stream);
 int snk_conv3x3_bn_f16_act16(const void *d_x16, const void *d_wS, const float *d_scale, const float *d_shift,
                              const void *d_residual16, void *d_out, int out_f16, int n_images, int height, int width,
                              int relu, void *stream);
@@ -268,8 +280,8 @@ int snk_stem_conv_bn_relu_f16out(const float *d_x, const float *d_w, const float
                                  void *d_out16, int n_images, int height, int width, void *stream);
 /* BASELINE.json configs[4] AS IT IS WORDED -- "bf16 MFMA conv" (outside the 1e-5 tolerance, never the default): the same block
  * body instantiated for bf16.  Activations are bf16 [n][H][W][128] arrays in HBM (d_x16 / d_residual16; the output is bf16 when
- * out_bf16 != 0, float32 for the layer the head reads), weights are bf16 in the split image's layout
- * (snk_conv3x3_prepare_weights_bf16: SNK_CONV_F16S_WEIGHT_BYTES bytes, hi parts used), products run on
+ * out_bf16 != 0, float32 for the layer the head reads), weights are bf16 in the 16-bit towers' image
+ * (snk_conv3x3_prepare_weights_bf16: a SNK_CONV_F16S_WEIGHT_BYTES buffer, first half used), products run on
  * v_mfma_f32_32x32x16_bf16 with float32 accumulation; batch norm, shortcut and ReLU in float32.  bf16 has float32's exponent
  * range: no activation scale, no clamp, no range flag.  snk_stem_conv_bn_relu_bf16out is the stem that feeds it; the
  * sub-rectangle forms (_rect) take bf16 background images.  (Rounds 1-3 had an im2col kernel with float32 activations under
@@ -282,6 +294,15 @@ int snk_conv3x3_bn_bf16_act16_rect(const void *d_x16, const void *d_wS, const fl
                                    const void *d_residual16, void *d_out16, const void *d_desc, const int *d_count,
                                    const void *d_bg_in16, int grow_in, const void *d_bg_res16, int grow_res,
                                    const void *d_bg_out16, int n_images, int height, int width, void *stream);
+/* The last tower layer of the two towers with 16-bit activations with the head's 1x1 stage fused into its epilogue
+ * (alpha_nnet.py:46-50; what snk_conv3x3_bn_f16s_head is to the float32 tower): d_h1[n][height * width], no layer output;
+ * snk_head_dense_f32 finishes AlphaNNet.v from d_h1. */
+int snk_conv3x3_bn_f16_act16_head(const void *d_x16, const void *d_wS, const float *d_scale, const float *d_shift,
+                                  const void *d_residual16, const float *d_w1x1, float bn_scale, float bn_shift,
+                                  float *d_h1, int n_images, int height, int width, void *stream);
+int snk_conv3x3_bn_bf16_act16_head(const void *d_x16, const void *d_wS, const float *d_scale, const float *d_shift,
+                                   const void *d_residual16, const float *d_w1x1, float bn_scale, float bn_shift,
+                                   float *d_h1, int n_images, int height, int width, void *stream);
 int snk_stem_conv_bn_relu_bf16out(const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,
                                   void *d_out16, int n_images, int height, int width, void *stream);
 int snk_stem_conv_bn_relu_bf16out_rect(const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,

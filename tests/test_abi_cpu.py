@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"libsnake_engine.so lacks {name}"
         assert name in _lib.PROTOTYPES, f"no ctypes prototype for {name}"
     assert set(_lib.PROTOTYPES) <= syms, set(_lib.PROTOTYPES) - syms
-    assert L.snk_version() >= 100
+    assert L.snk_version() == _lib.ABI_VERSION == int(re.search(r"#define SNK_ABI_VERSION (\d+)", open(os.path.join(REPO, "include", "snake_engine.h")).read()).group(1))
 
 
 def test_no_cpu_fallback():

@@ -390,6 +390,21 @@ def test_bf16_conv_layer_and_net(env, monkeypatch):
     ref32 = net_ref.forward(ws, states)
     assert np.abs(got - ref16).max() <= 3e-2, np.abs(got - ref16).max()
     assert np.abs(got - ref32).max() <= 1e-1, np.abs(got - ref32).max()
+    # the same net on all 53 recorded 19x19 observations (above the sub-rectangle threshold: 12 of the 20 layers convolve rectangles):
+    # the sub-rectangle form equals the full form bit for bit at this shape too, and the head fused into the last layer's epilogue
+    # (no float32 activation in HBM) equals the separate head kernel up to the float32 summation order of its 128-channel dot product
+    x53 = torch.as_tensor(s19["raw"], device="cuda")
+    q = {}
+    for rect, fuse in (("1", "1"), ("0", "1"), ("1", "0")):
+        monkeypatch.setenv("SNK_CONV_RECT", rect)
+        monkeypatch.setenv("SNK_HEAD_FUSE", fuse)
+        qn = net.QNet(ws, (37, 37, 3))
+        assert qn.n_rect == (12 if rect == "1" else 0)
+        q[rect, fuse] = qn.forward(x53).cpu().numpy()
+    assert np.array_equal(q["1", "1"], q["0", "1"]), "19x19 / 10 blocks: sub-rectangle form != full form"
+    assert 0 < np.abs(q["1", "1"] - q["1", "0"]).max() <= 2e-6, np.abs(q["1", "1"] - q["1", "0"]).max()
+    monkeypatch.setenv("SNK_CONV_RECT", "1")
+    monkeypatch.setenv("SNK_HEAD_FUSE", "1")
 
 
 # ---- range guard of the split-f16 kernel ------------------------------------------------------------------------------
@@ -608,7 +623,7 @@ def test_f16_activation_tower_layer_and_net(env, monkeypatch):
         ref = (ref * sc.double() + sh.double() + r.double()).clamp_min(0)
         xd, rd, wd, scd, shd = x.cuda(), r.cuda(), w.cuda().contiguous(), sc.cuda(), sh.cuda()
         wS = torch.empty(F16S_WEIGHT_BYTES, dtype=torch.uint8, device="cuda")
-        check(L.snk_conv3x3_prepare_weights_f16s(wd.data_ptr(), wS.data_ptr(), C.c_float(1.0), _st()))
+        check(L.snk_conv3x3_prepare_weights_f16_act16(wd.data_ptr(), wS.data_ptr(), _st()))
         o32 = torch.full((n, hw, hw, 128), float("nan"), device="cuda")
         check(L.snk_conv3x3_bn_f16_act16(xd.data_ptr(), wS.data_ptr(), scd.data_ptr(), shd.data_ptr(), rd.data_ptr(),
                                          o32.data_ptr(), 0, n, hw, hw, 1, _st()))

@@ -18,7 +18,7 @@ if algo in ("f16a", "bf16"):      # f16 / bf16 activations in HBM: time only (te
         if bf:
             check(L.snk_conv3x3_prepare_weights_bf16(w.data_ptr(), U.data_ptr(), st))
         else:
-            check(L.snk_conv3x3_prepare_weights_f16s(w.data_ptr(), U.data_ptr(), 1.0, st))
+            check(L.snk_conv3x3_prepare_weights_f16_act16(w.data_ptr(), U.data_ptr(), st))
         f = lambda: check((L.snk_conv3x3_bn_bf16_act16 if bf else L.snk_conv3x3_bn_f16_act16)(x.data_ptr(), U.data_ptr(), sc.data_ptr(), sh.data_ptr(), x.data_ptr(), o.data_ptr(), 1, n, H, H, 1, st))
         for _ in range(3): f()
         torch.cuda.synchronize()
