@@ -90,6 +90,10 @@ template <bool BF> __device__ __forceinline__ _Float16 hs_to16(float v)
 #ifndef HS_PRIO
 #define HS_PRIO 3
 #endif
+#ifndef HS_RING16
+#define HS_RING16 3                                      // 16-bit frame: B-fragment ring (A/B: make variant EXTRA="-DHS_RING16=4 -DHS_AHEAD16=3")
+#define HS_AHEAD16 2
+#endif
 
 struct ConvHsArgs {
     const float *x;            // [n][Hd][Wd][128]
@@ -160,7 +164,8 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     static_assert(!BF || (IO16 & 1), "the bf16 form reads bf16 activations");
     constexpr bool IN16 = (IO16 & 1) != 0, OUT16 = (IO16 & 2) != 0;
     constexpr bool STATS = MODE == 4;
-    constexpr bool K32 = IN16;                             // the 16-bit frame: 32 input channels per chunk (two MFMA k steps)
+    constexpr bool K32 = IN16;
+    constexpr int RING = K32 ? HS_RING16 : HS_RING, AHEAD = K32 ? HS_AHEAD16 : HS_AHEAD;      // B-fragment register ring: slots (a divisor of 9), taps ahead
     constexpr bool TWO = SPLIT || K32;                     // two A fragments / two B fragments per (tap, M tile)
     constexpr int KC = K32 ? 32 : HS_KC, NCHUNK = HS_C / KC;
     constexpr int NST = K32 ? HS_NST16 : HS_NST, BUFB = K32 ? HS_BUF16 : HS_NPB * HS_LDP;
@@ -257,7 +262,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     HS_STAMP(0)
     HS_STAMP_HWID(7)
     const f16x8 *wl = p.wS + wn * 128 + lane;              // this wave's fragments of global step g = 9 chunk + tap: wl[g * 512 + {0 hi, 64 lo}]
-    f16x8 Bq[HS_RING][2];
+    f16x8 Bq[RING][2];
 #define HS_LOADB(slot, g)                                                                       \
     {                                                                                           \
         const f16x8 *w_ = wl + (long)(g) * 512;                                                 \
@@ -266,7 +271,24 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     }
     HS_LOAD(0)
 #pragma unroll
-    for (int s = 0; s < HS_AHEAD; ++s) HS_LOADB(s, s);
+    for (int s = 0; s < AHEAD; ++s) HS_LOADB(s, s);
+    if (K32) {
+        // the 16-bit frame zeroes only what is read and never staged (both buffers): per LDS row the left border / halo slot and the
+        // 176 bytes from slot Wr + 1 to the end of the row (the right border; a halo column inside the canvas is staged over it
+        // after the barrier), and the rows above / below the canvas -- 4-6 stores per thread instead of 16
+        const int R = y_last - y_first + 3;
+        for (int i = tid; i < 2 * 16 * R; i += 256) {
+            const int b = i >= 16 * R, j = i - b * 16 * R, r = j >> 4, q = j & 15;
+            *(uint4 *)(smem + b * BUFB + r * PB + (q < 5 ? q * 16 : (Wr + 1) * HS_LDP + (q - 5) * 16)) = make_uint4(0u, 0u, 0u, 0u);
+        }
+        const bool top = ry_lo > 0, bot = cy0 + y_last + 1 > p.Hd - 1;
+        if (top || bot)
+            for (int i = tid; i < 2 * (PB >> 4); i += 256) {
+                const int b = i >= (PB >> 4), q = i - b * (PB >> 4);
+                if (top) *(uint4 *)(smem + b * BUFB + q * 16) = make_uint4(0u, 0u, 0u, 0u);
+                if (bot) *(uint4 *)(smem + b * BUFB + (R - 1) * PB + q * 16) = make_uint4(0u, 0u, 0u, 0u);
+            }
+    } else
     for (int o = tid * 16; o < 2 * BUFB; o += 256 * 16) *(uint4 *)(smem + o) = make_uint4(0u, 0u, 0u, 0u);   // borders stay zero
     f32x16 acc[NI];
 #pragma unroll
@@ -302,7 +324,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
                 if (t2_ < 9 * NI) { nh = HS_LDS(HS_AOFF(t2_)); if (TWO) nl = HS_LDS(HS_AOFF(t2_) + 32); } \
                 __builtin_amdgcn_sched_barrier(0);                                              \
                 if (i == 0) {                                                                   \
-                    if (MORE || (s) + HS_AHEAD < 9) { HS_LOADB(((s) + HS_AHEAD) % HS_RING, gnext + (s)); } \
+                    if (MORE || (s) + AHEAD < 9) { HS_LOADB(((s) + AHEAD) % RING, gnext + (s)); } \
                     if ((s) == HS_XLOAD_TAP && MORE) { HS_LOAD(c + 1) }                         \
                 }                                                                               \
                 {                                                                               \
@@ -312,12 +334,12 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
                         else { HS_SPLIT_B((tl_ < 0 ? 0 : tl_ >> 1), wb) }                       \
                     }                                                                           \
                 }                                                                               \
-                HS_MFMA(a0h, Bq[(s) % HS_RING][0], acc[i]);                                     \
+                HS_MFMA(a0h, Bq[(s) % RING][0], acc[i]);                                     \
                 if (SPLIT) {                                                                    \
-                    HS_MFMA(a0h, Bq[(s) % HS_RING][1], acc[i]);                                 \
-                    HS_MFMA(a0l, Bq[(s) % HS_RING][0], acc[i]);                                 \
+                    HS_MFMA(a0h, Bq[(s) % RING][1], acc[i]);                                 \
+                    HS_MFMA(a0l, Bq[(s) % RING][0], acc[i]);                                 \
                 } else if (K32) {                        /* the chunk's second k step: channels 16-31 */ \
-                    HS_MFMA(a0l, Bq[(s) % HS_RING][1], acc[i]);                                 \
+                    HS_MFMA(a0l, Bq[(s) % RING][1], acc[i]);                                 \
                 }                                                                               \
                 a0h = a1h; a0l = a1l; a1h = nh; a1l = nl;                                       \
                 __builtin_amdgcn_sched_barrier(0);                                              \
@@ -327,7 +349,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     {                                                                                           \
         const unsigned rb = (unsigned)(c & 1) * BUFB;                                           \
         const unsigned wb = (unsigned)((c & 1) ^ 1) * BUFB;                                     \
-        const int gnext = c * 9 + HS_AHEAD;             /* global step the first prefetch of this chunk fetches */ \
+        const int gnext = c * 9 + AHEAD;             /* global step the first prefetch of this chunk fetches */ \
         f16x8 a0h = HS_LDS(HS_AOFF(0)), a1h = HS_LDS(HS_AOFF(1)), a0l = a0h, a1l = a1h;         \
         if (TWO) { a0l = HS_LDS(HS_AOFF(0) + 32); a1l = HS_LDS(HS_AOFF(1) + 32); }              \
         HS_TAP(0, MORE) HS_TAP(1, MORE) HS_TAP(2, MORE) HS_TAP(3, MORE) HS_TAP(4, MORE)         \
@@ -393,6 +415,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
         // stores in flight and puts s_waitcnt vmcnt(0) before every use of a shortcut row -- each row then waits for the previous
         // row's store to be acknowledged by HBM (16 round trips per block: 11 k of this epilogue's 16 k cycles, profiles/r5_a16_stamps.log)
         const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((_Float16 *)p.out + (long)img * HWc * HS_C), 0, HWc * HS_C * 2, 0x00020000);
+        const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((_Float16 *)(has_res ? p.res : p.out) + (long)img * HWc * HS_C), 0, HWc * HS_C * 2, 0x00020000);
         const bool sel_res = RECT && p.bg_res != nullptr;
 #define HS_ROWS(pass) (((pass) + 1 < NPASS ? 2 : NI - 2 * (NPASS - 1)) * 32)
 #define HS_EPI_PREP(pass)                 /* element offsets of this thread's rows (-1: past the block's pixels) + shortcut loads */ \
@@ -406,7 +429,9 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
                     stale_ = sel_res && (cy0 + y_ < by0 - p.grow_res || cy0 + y_ > by1 + p.grow_res || \
                                          cx0 + x_ < bx0 - p.grow_res || cx0 + x_ > bx1 + p.grow_res); \
                 } else off[pass][j] = m_ < m1 ? (unsigned)(m_ * HS_C + 8 * cq) : 0x40000000u;  \
-                if (has_res) {                                                                  \
+                if (has_res && !RECT) {       /* whole images: the shortcut through the image's descriptor too (one offset register per row) */ \
+                    rv[pass][j] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, 2u * off[pass][j], 0, 0)); \
+                } else if (has_res) {                                                           \
                     const _Float16 *rb_ = stale_ ? (const _Float16 *)p.bg_res : (const _Float16 *)p.res + (long)img * HWc * HS_C; \
                     rv[pass][j] = *(const f16x8 *)(rb_ + (off[pass][j] < 0x40000000u ? off[pass][j] : 8u * cq)); \
                 }                                                                               \
@@ -592,7 +617,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f16s(ConvHsArgs p)
         else { img = b / p.n_blk; blk = b - img * p.n_blk; }
     }
     const int tile0 = blk * p.tiles_base + min(blk, p.tiles_rem), ntile = p.tiles_base + (blk < p.tiles_rem ? 1 : 0);
-    hs_block<NI, MODE, SPLIT, IO16, false, BF>(p, smem, img, tile0, ntile, 0, 0, 0, 0, 0u, 0, 1);
+    // an image whose tile count is not a multiple of its block count has blocks of NI - 1 tiles: the 16-bit towers' kernel carries
+    // that body too (37 x 37: 43 tiles = one block of 8 + five of 7, which all ran the 8-tile body before: a ninth of the full
+    // layers' MFMAs computed rows nobody stored); the choice is wave-uniform
+    if constexpr (IO16 != 0 && NI > 1) {
+        switch (ntile) {
+        case NI - 1: hs_block<NI - 1, MODE, SPLIT, IO16, false, BF>(p, smem, img, tile0, ntile, 0, 0, 0, 0, 0u, 0, 1); break;
+        default: hs_block<NI, MODE, SPLIT, IO16, false, BF>(p, smem, img, tile0, ntile, 0, 0, 0, 0, 0u, 0, 1); break;
+        }
+    } else hs_block<NI, MODE, SPLIT, IO16, false, BF>(p, smem, img, tile0, ntile, 0, 0, 0, 0, 0u, 0, 1);
 }
 
 // The sub-rectangle form.  The reference's observation (game.py:215-257) is one background pixel (0, WALL, 0) everywhere
