@@ -23,6 +23,8 @@
 // GEMM's k range follow the real pixels more closely (32 k-steps per 21 x 21 image instead of 35).
 // The image groups' partial results are summed in a fixed order by k_wgrad_fold (float64): a run repeats bit for bit.
 #include "common.h"
+#include <stdlib.h>
+#include <string.h>
 
 typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
 typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
@@ -231,12 +233,249 @@ __global__ __launch_bounds__(512) void k_wgrad_f16s(WgArgs p)
     }
 }
 
+// the groups' partial results, summed in a fixed order (float64): 64 outputs per block, four wavefronts take a quarter of the groups
+// each (the window form writes 128 partials: one thread per output walked them in 36 us, a twentieth of the kernel it follows)
 __global__ __launch_bounds__(256) void k_wgrad_fold(const float *__restrict__ part, int groups, float *__restrict__ dw)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;      // 9 * 128 * 128 outputs
+    __shared__ double red[4][64];
+    const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o;                 // 9 * 128 * 128 outputs
+    const int per = (groups + 3) / 4, g0 = q * per, g1 = min(g0 + per, groups);
     double acc = 0.0;
-    for (int g = 0; g < groups; ++g) acc += (double)part[(long)g * (9 * 128 * 128) + i];
-    dw[i] = (float)acc;
+#pragma unroll 8
+    for (int g = g0; g < g1; ++g) acc += (double)part[(long)g * (9 * 128 * 128) + i];
+    red[q][o] = acc;
+    __syncthreads();
+    if (q == 0) dw[i] = (float)(((red[0][o] + red[1][o]) + red[2][o]) + red[3][o]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 5: the form the training step runs (k_wgrad_f16s above stays selectable, SNK_WGRAD=slabs, as the A/B partner).
+//
+// What the slab form lost (SQ counters, profiles/r4_wgrad_sq_counters.json: matrix pipes busy 67 % of the SIMD cycles): its four
+// MFMA wavefronts split a slab's k-steps four ways, so a slab costs ceil(nk / 4) k-step times (16 for 14), each of them is the only
+// MFMA wavefront of its SIMD (nothing covers an LDS wait), and per-image slabs round 441 pixels up to 480 slots.  Here
+//   * every wavefront owns its OWN output tiles and runs ALL k-steps: a block = 64 input channels x all 128 output channels x nine
+//     taps, wavefront wv = (32 ci: wv & 1) x (32 co: wv >> 1), nine 32 x 32 accumulators -- nothing is split along k, nothing is
+//     summed across wavefronts at the end;
+//   * all eight wavefronts stage AND multiply (two MFMA wavefronts per SIMD: one's LDS waits are the other's MFMA time); a
+//     wavefront's share of the next window's split-and-store work is spread over its (k-step, dy) groups;
+//   * the reduction runs over ONE slot stream per image group: image i, row y, column x sits at slot (i (H + 1) + y) (W + 1) + x,
+//     with a zero column behind every row and a zero row behind every image (they are the taps' zero padding: the dx = +-1 / dy = +-1
+//     neighbour of an edge pixel is such a slot), and the block works through the stream in windows of NK k-steps whatever the image
+//     boundaries: 441 pixels cost 484 slots, nothing is rounded per image or per slab.  A slot's place in HBM comes from two
+//     divisions per staged item; slots that are padding get an offset beyond the group's buffer descriptor, which returns zeros.
+// LDS per buffer: X as two 32-channel planes x (hi, lo) of 16 NK + 2 P + 16 rows, dY as four planes x (hi, lo) of 16 NK rows, 64-byte
+// rows read with ds_read_b64_tr_b16 exactly as above; two buffers; one barrier per window.  256 blocks = 2 channel halves x 128 image
+// groups (the two halves of a group read the same dY: neighbours on one XCD); partial results are folded in a fixed order.
+#define WG2_GROUPS 128
+
+#ifdef WG_STAMPS        // development build only: s_memtime / s_memrealtime at the block's start, first window and end
+__device__ unsigned long long wg_stamp_buf[512 * 8];
+#define WG_STAMP(k, v) if (tid == 0) wg_stamp_buf[blockIdx.x * 8 + (k)] = (v);
+extern "C" int snk_dbg_wgrad_stamps(unsigned long long *h_out)
+{
+    SNK_CHECK_HIP(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(wg_stamp_buf), sizeof(unsigned long long) * 512 * 8));
+    return 0;
+}
+#else
+#define WG_STAMP(k, v)
+#endif
+
+// two transposing reads -> one MFMA operand, as a vector concatenation (the union of wg_join costs the window form a v_mov per half)
+typedef short wg_s8 __attribute__((ext_vector_type(8)));
+__device__ static inline wg_f16x8 wg_cat(wg_s4 a, wg_s4 b)
+{
+    return __builtin_bit_cast(wg_f16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+struct Wg2Args {
+    const float *x, *dy;
+    float *part;
+    const float *x_tail, *dy_tail;
+    int n_images, H, W, per_group, rows_x, nxs;      // nxs: X slots a window stages = 16 NK + 2 P + 2
+};
+
+// WT: the image width as a compile-time constant (0: read from the arguments): with it every tap's LDS offset is an immediate
+template <int NK, int MAXX, int WT>
+__global__ __launch_bounds__(512) void k_wgrad2_f16s(Wg2Args p)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int wa = wv & 1, wb = wv >> 1;                                  // this wavefront's 32 input / 32 output channels of the block's 64 x 128
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int half = local & 1, grp = (local >> 1) * 8 + xcd;             // the two halves of a group are 8 blocks apart: one XCD, one L2
+    const int W = WT ? WT : p.W, H = WT ? WT : p.H, P = W + 1, SR = H + 1;      // (square images when WT is given)
+    const int n0 = grp * p.per_group, n1 = min(n0 + p.per_group, p.n_images), nimg = max(n1 - n0, 0);
+    const int S = nimg * SR * P;                                          // slots of this group's stream
+    const int T = (S + 16 * NK - 1) / (16 * NK);                          // windows
+    const int plane_x = (WT ? 16 * NK + WG_GX + 2 * (WT + 1) + 8 : p.rows_x) * 64, plane_y = 16 * NK * 64;
+    const int buf_bytes = 4 * plane_x + 8 * plane_y;                      // XH0 XH1 XL0 XL1 | YH0..3 YL0..3
+    for (int o = tid * 16; o < 2 * buf_bytes; o += 512 * 16) *(uint4 *)(smem + o) = make_uint4(0u, 0u, 0u, 0u);
+
+    // ---- staging: item j of this thread = (slot, four channels) of the window; X first, then dY
+    const float sx = p.x_tail[2], sy = p.dy_tail[2];
+    const int nxs = WT ? 16 * NK + 2 * (WT + 1) + 2 : p.nxs;
+    const float invP = 1.0f / (float)P, invSR = 1.0f / (float)SR;
+    // X item j: slot row (tid >> 4) + 32 j of the window's nxs (rows past the last repeat it: same value, same address), channels
+    // 4 (tid & 15) ..; dY item j: slot row (tid >> 5) + 16 j of 16 NK (exactly NK items per thread), channels 4 (tid & 31) ..
+    const int xr0 = tid >> 4, xc4 = tid & 15, yr0 = tid >> 5, yc4 = tid & 31;
+    const int xl0 = (xc4 >> 3) * plane_x + (WG_GX - 1) * 64 + 8 * (xc4 & 7), xcb = (64 * half + 4 * xc4) * 4;   // LDS (hi image) / channel byte offsets
+    const int yl0 = (yc4 >> 3) * plane_y + 8 * (yc4 & 7), ycb = 16 * yc4;
+    const long grp_elems = (long)n0 * H * W * 128;
+    const unsigned grp_bytes = (unsigned)((long)nimg * H * W * 128 * 4);
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + grp_elems), 0, grp_bytes, 0x00020000);
+    const auto ry = __builtin_amdgcn_make_buffer_rsrc((void *)(p.dy + grp_elems), 0, grp_bytes, 0x00020000);
+    // byte offset of stream slot s in the group's tensor, or an offset no descriptor covers (zero column, zero row, outside the stream)
+    auto slot_off = [&](int s) -> unsigned {
+        // (24-bit multiplies: full rate, and every operand here is far below 2^24 -- the launcher checks the group's size)
+        const int r = (int)(((float)s + 0.5f) * invP), x = s - __mul24(r, P);     // stream row, column
+        const int i = (int)(((float)r + 0.5f) * invSR), y = r - __mul24(i, SR);   // image, row
+        const bool ok = s >= 0 && s < S && x < W && y < H;
+        return ((unsigned)(__mul24(__mul24(i, H) + y, W) + x) << 9) | (ok ? 0u : 0x80000000u);      // (no branch: a select of two constants)
+    };
+    float4 xv[MAXX], yv[NK];
+    auto fetch_x = [&](int j, int t) {                                    // item j of window t -> registers
+        xv[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, slot_off(t * 16 * NK - (P + 1) + min(xr0 + 32 * j, nxs - 1)) + xcb, 0, 0));
+    };
+    auto fetch_y = [&](int j, int t) {
+        yv[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ry, slot_off(t * 16 * NK + yr0 + 16 * j) + ycb, 0, 0));
+    };
+    auto fetch = [&](int t) {                                             // a whole window (the prologue's two)
+#pragma unroll
+        for (int j = 0; j < MAXX; ++j) {
+            fetch_x(j, t);
+            __builtin_amdgcn_sched_barrier(0);                            // one item's address arithmetic at a time: its temporaries die with the load
+        }
+#pragma unroll
+        for (int j = 0; j < NK; ++j) {
+            fetch_y(j, t);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto store_x = [&](int j, unsigned char *B) {
+        uint2 hi, lo;
+        wg_split4(xv[j], sx, hi, lo);
+        unsigned char *d = B + xl0 + min(xr0 + 32 * j, nxs - 1) * 64;
+        *(uint2 *)d = hi; *(uint2 *)(d + 2 * plane_x) = lo;
+    };
+    auto store_y = [&](int j, unsigned char *B) {
+        uint2 hi, lo;
+        wg_split4(yv[j], sy, hi, lo);
+        unsigned char *d = B + 4 * plane_x + yl0 + (yr0 + 16 * j) * 64;
+        *(uint2 *)d = hi; *(uint2 *)(d + 4 * plane_y) = lo;
+    };
+
+    // ---- MFMA side (addressing as in k_wgrad_f16s): a transposing read of rows R .. R + 3
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const int lane_off = (i16 >> 2) * 64 + (16 * (g4 & 1) + 4 * (i16 & 3)) * 2;
+    const int xoff = WG_GX + P;                                           // X row of the pixel at dY row 0 of the window
+    wg_f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    WG_STAMP(0, __builtin_amdgcn_s_memtime())
+    WG_STAMP(4, __builtin_amdgcn_s_memrealtime())
+    if (T > 0) fetch(0);
+    __syncthreads();                                                      // the zero fill is complete
+    if (T > 0) {
+#pragma unroll
+        for (int j = 0; j < MAXX; ++j) store_x(j, smem);
+#pragma unroll
+        for (int j = 0; j < NK; ++j) store_y(j, smem);
+    }
+    if (T > 1) fetch(1);
+    __syncthreads();                                                      // window 0 is in buffer 0
+    WG_STAMP(1, __builtin_amdgcn_s_memtime())
+    for (int t = 0; t < T; ++t) {
+        unsigned char *B = smem + (t & 1) * buf_bytes, *Bn = smem + ((t + 1) & 1) * buf_bytes;
+        const unsigned char *XH = B + wa * plane_x, *XL = XH + 2 * plane_x;
+        const unsigned char *YH = B + 4 * plane_x + wb * plane_y, *YL = YH + 4 * plane_y;
+        // the registers hold window t + 1: group g lays item g into the other buffer and requests the same item of window t + 2 into the
+        // registers that just became free (a whole window ahead of its use; its address arithmetic sits in the shadow of the MFMAs)
+
+#define WG_SB() __builtin_amdgcn_sched_barrier(0)
+        // Software pipeline inside the wavefront, without a second fragment set: the three MFMAs of tap (dy, dx) are followed at once
+        // by the reads of tap (next dy, dx) into the registers they have just consumed, so a fragment is requested two taps (192+
+        // matrix cycles) before its use and the wavefront never sits between a read burst and its data.  (A group of twelve reads
+        // in front of nine MFMAs, the first form of this kernel, left each wavefront ~300 cycles per group without an MFMA to
+        // issue -- more than its partner's 288-cycle burst covers: 12.1 k cycles per window against 8.6 k of MFMAs.)
+        wg_f16x8 ah[3], al[3], bh, bl;
+#define WG2_LOADA(dxi, ks_, dyi_)                                                               \
+        {                                                                                       \
+            const int Rx = 16 * (ks_) + 8 * h + xoff + ((dyi_) - 1) * P + ((dxi) - 1);          \
+            ah[dxi] = wg_cat(WG_TR(XH + Rx * 64 + lane_off), WG_TR(XH + (Rx + 4) * 64 + lane_off)); \
+            al[dxi] = wg_cat(WG_TR(XL + Rx * 64 + lane_off), WG_TR(XL + (Rx + 4) * 64 + lane_off)); \
+        }
+#define WG2_LOADB(ks_)                                                                          \
+        {                                                                                       \
+            const int R = 16 * (ks_) + 8 * h;                                                   \
+            bh = wg_cat(WG_TR(YH + R * 64 + lane_off), WG_TR(YH + (R + 4) * 64 + lane_off));    \
+            bl = wg_cat(WG_TR(YL + R * 64 + lane_off), WG_TR(YL + (R + 4) * 64 + lane_off));    \
+        }
+        WG2_LOADB(0)
+        WG2_LOADA(0, 0, 0) WG2_LOADA(1, 0, 0) WG2_LOADA(2, 0, 0)
+        WG_SB();
+#pragma unroll
+        for (int g = 0; g < 3 * NK; ++g) {
+            const int ks = g / 3, dyi = g - 3 * ks;
+            const int gn = g + 1, ksn = gn / 3, dyn = gn - 3 * ksn;      // the next group of this window
+            // this group's share of the staging work: item g of window t + 1 into the other buffer, the same item of window t + 2 requested
+            // into the registers that have just become free (its address arithmetic runs in the shadow of the MFMAs)
+            // (unconditionally: past the stream's end the store writes a buffer nobody reads and the request is answered with zeros --
+            // a branch here would make the compiler wait for EVERY load in flight before each store, vmcnt(0), i.e. for the request
+            // of the group before: one HBM latency per group)
+            static_assert(3 * NK >= MAXX + NK, "a window has a (k-step, dy) group per staged item");
+            if (g < MAXX) { store_x(g, Bn); fetch_x(g, t + 2); }
+            else if (g < MAXX + NK) { store_y(g - MAXX, Bn); fetch_y(g - MAXX, t + 2); }
+            WG_SB();
+#pragma unroll
+            for (int dxi = 0; dxi < 3; ++dxi) {
+                const int tp = 3 * dyi + dxi;
+                acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[dxi], bh, acc[tp], 0, 0, 0);
+                acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[dxi], bl, acc[tp], 0, 0, 0);
+                acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[dxi], bh, acc[tp], 0, 0, 0);
+                if (gn < 3 * NK) {
+                    if (dxi == 2 && dyn == 0) WG2_LOADB(ksn)             // the k-step's last MFMA has been issued: its dY fragments may go
+                    WG2_LOADA(dxi, ksn, dyn)
+                }
+                WG_SB();
+            }
+        }
+#undef WG2_LOADA
+#undef WG2_LOADB
+#undef WG_SB
+        __syncthreads();
+    }
+    WG_STAMP(2, __builtin_amdgcn_s_memtime())
+    WG_STAMP(5, __builtin_amdgcn_s_memrealtime())
+    WG_STAMP(6, (unsigned long long)T)
+    // every wavefront owns its tiles: straight to the group's partial result, 128-byte rows
+    const float inv = p.x_tail[3] * p.dy_tail[3];
+    float *out = p.part + ((long)grp * 9 * 128 + 64 * half + 32 * wa) * 128 + 32 * wb + l31;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            out[((long)t * 128 + (r & 3) + 8 * (r >> 2) + 4 * h) * 128] = acc[t][r] * inv;
+}
+
+struct Wg2Shape { int nk, rows_x, nxs, lds, maxx; };
+static bool wg2_shape(int h, int w, Wg2Shape &s)
+{
+    if (h < 1 || w < 3) return false;
+    const int P = w + 1;
+    static const int nk_max = getenv("SNK_WGRAD_NK") ? atoi(getenv("SNK_WGRAD_NK")) : 5;      // development: SNK_WGRAD_NK=4
+    for (s.nk = nk_max >= 5 ? 5 : 4; s.nk >= 4; --s.nk) {
+        s.nxs = 16 * s.nk + 2 * P + 2;
+        s.rows_x = 16 * s.nk + WG_GX + 2 * P + 8;
+        s.lds = 2 * (4 * s.rows_x * 64 + 8 * 16 * s.nk * 64);
+        s.maxx = (s.nxs * 16 + 511) / 512;
+        if (s.maxx <= 5 && s.lds <= 158 * 1024) return true;
+    }
+    return false;
 }
 
 struct WgShape { int P, RB, n_slabs, nk, rows_x, lds, nx_items, ny_items; };
@@ -260,24 +499,64 @@ static bool wg_shape(int h, int w, WgShape &s)
     return false;
 }
 
+// which form runs: the window form (k_wgrad2_f16s) wherever the shape fits it, unless SNK_WGRAD=slabs asks for the slab form
+static bool wg_use_windows(int height, int width)
+{
+    static const bool slabs = getenv("SNK_WGRAD") && !strcmp(getenv("SNK_WGRAD"), "slabs");
+    Wg2Shape s2;
+    return !slabs && wg2_shape(height, width, s2);
+}
+
 extern "C" long snk_conv3x3_wgrad_partials(int height, int width)
 {
     WgShape s;
-    if (!wg_shape(height, width, s)) return -1;
-    return (long)WG_GROUPS * 9 * 128 * 128;
+    Wg2Shape s2;
+    const bool a = wg_shape(height, width, s), b = wg2_shape(height, width, s2);
+    if (!a && !b) return -1;
+    return (long)(b ? WG2_GROUPS : WG_GROUPS) * 9 * 128 * 128;             // the larger of the two forms' needs
 }
 
 extern "C" int snk_conv3x3_wgrad_f16s(const float *d_x, const float *d_dy, const float *d_x_tail, const float *d_dy_tail,
                                       float *d_partials, float *d_dw, int n_images, int height, int width, void *stream)
 {
     SNK_REQUIRE(d_x && d_dy && d_x_tail && d_dy_tail && d_partials && d_dw && n_images > 0, "snk_conv3x3_wgrad_f16s: bad argument");
+    SNK_REQUIRE((long)n_images * height * width * 128 < (1l << 40), "snk_conv3x3_wgrad_f16s: batch too large");
+    if (wg_use_windows(height, width)) {
+        Wg2Shape s2;
+        wg2_shape(height, width, s2);
+        const int per_group = (n_images + WG2_GROUPS - 1) / WG2_GROUPS;
+        SNK_REQUIRE((long)per_group * height * width * 512 < (1l << 31) && (long)per_group * (height + 1) * (width + 1) < (1l << 22),
+                    "snk_conv3x3_wgrad_f16s: %d images per group do not fit a buffer descriptor", per_group);
+        Wg2Args a2 = {d_x, d_dy, d_partials, d_x_tail, d_dy_tail, n_images, height, width, per_group, s2.rows_x, s2.nxs};
+        const dim3 g2(2 * WG2_GROUPS);
+        const int wt = height == width && (width == 21 || width == 37) ? width : 0;      // the two canvases of the BASELINE configs
+#define WG2_LAUNCH(NK_, MX_, WT_)                                                               \
+        {                                                                                       \
+            static bool attr_ = false;       /* more than 64 KB of dynamic LDS needs the attribute */ \
+            if (!attr_) {                                                                       \
+                SNK_CHECK_HIP(hipFuncSetAttribute((const void *)k_wgrad2_f16s<NK_, MX_, WT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                attr_ = true;                                                                   \
+            }                                                                                   \
+            k_wgrad2_f16s<NK_, MX_, WT_><<<g2, 512, s2.lds, (hipStream_t)stream>>>(a2);         \
+        }
+        if (wt == 21 && s2.nk == 5 && s2.maxx <= 4) WG2_LAUNCH(5, 4, 21)
+        else if (wt == 21 && s2.nk == 4 && s2.maxx <= 4) WG2_LAUNCH(4, 4, 21)
+        else if (wt == 37 && s2.nk == 4 && s2.maxx <= 5) WG2_LAUNCH(4, 5, 37)
+        else if (s2.nk == 5 && s2.maxx <= 4) WG2_LAUNCH(5, 4, 0)
+        else if (s2.nk == 5) WG2_LAUNCH(5, 5, 0)
+        else if (s2.maxx <= 4) WG2_LAUNCH(4, 4, 0)
+        else WG2_LAUNCH(4, 5, 0)
+#undef WG2_LAUNCH
+        k_wgrad_fold<<<9 * 128 * 128 / 64, 256, 0, (hipStream_t)stream>>>(d_partials, WG2_GROUPS, d_dw);
+        SNK_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     WgShape s;
     SNK_REQUIRE(wg_shape(height, width, s), "snk_conv3x3_wgrad_f16s: %d x %d images are not supported (width 3 .. 96)", height, width);
-    SNK_REQUIRE((long)n_images * height * width * 128 < (1l << 40), "snk_conv3x3_wgrad_f16s: batch too large");
     WgArgs a = {d_x, d_dy, d_partials, d_x_tail, d_dy_tail, n_images, height, width, s.P, s.RB, s.n_slabs, s.nk, s.rows_x,
                 (n_images + WG_GROUPS - 1) / WG_GROUPS, s.nx_items, s.ny_items};
     k_wgrad_f16s<<<16 * WG_GROUPS, 512, s.lds, (hipStream_t)stream>>>(a);
-    k_wgrad_fold<<<9 * 128 * 128 / 256, 256, 0, (hipStream_t)stream>>>(d_partials, WG_GROUPS, d_dw);
+    k_wgrad_fold<<<9 * 128 * 128 / 64, 256, 0, (hipStream_t)stream>>>(d_partials, WG_GROUPS, d_dw);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
