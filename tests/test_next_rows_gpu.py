@@ -166,6 +166,27 @@ def test_trainer_flow_train_copy_save_load(tmp_path, monkeypatch):
         AlphaNNet(model_name="models/t2.h5")
 
 
+def test_alpha_nnet_loads_a_keras_shaped_file(tmp_path):
+    """alpha_nnet.py:12: `AlphaNNet(model_name)` on a file laid out the way Keras 2.2.4-tf + h5py write `v_net.save` (variable-length
+    string attributes, empty float64 weight_names of the weightless layers, optimizer_weights, training_config; written with libhdf5
+    by tests/test_checkpoint_cpu.py, not by this build's writer) evaluates like a net made from the same weights; a truncated copy
+    raises the OSError pit.py:58 waits on"""
+    from test_checkpoint_cpu import _weights, _write_keras_style
+    from utils.alpha_nnet import AlphaNNet
+    ws = _weights((21, 21, 3), 4, seed=9)
+    path = str(tmp_path / "gen7.h5")
+    _write_keras_style(path, ws, (21, 21, 3), True)
+    X = list(load_golden("states_11x11x4.npz")["raw"][:24])
+    a = AlphaNNet(model_name=path)
+    b = AlphaNNet(input_shape=(21, 21, 3), _weights=ws)
+    assert a.input_shape == (21, 21, 3) and np.array_equal(a.v(X), b.v(X))
+    assert all(u.tobytes() == v.tobytes() for u, v in zip(a.v_net.get_weights(), ws))
+    blob = open(path, "rb").read()
+    open(path, "wb").write(blob[:len(blob) // 3])
+    with pytest.raises(OSError):
+        AlphaNNet(model_name=path)
+
+
 def test_alpha_snake_zero_trainer_two_generations(tmp_path, monkeypatch):
     """utils.alpha_snake_zero_trainer.AlphaSnakeZeroTrainer driven exactly as train.py drives it (train.py:32-40), for two
     generations: log.csv gets the reference's header and one row of six per-game averages per generation, the learning rate
