@@ -415,6 +415,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
         // stores in flight and puts s_waitcnt vmcnt(0) before every use of a shortcut row -- each row then waits for the previous
         // row's store to be acknowledged by HBM (16 round trips per block: 11 k of this epilogue's 16 k cycles, profiles/r5_a16_stamps.log)
         const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((_Float16 *)p.out + (long)img * HWc * HS_C), 0, HWc * HS_C * 2, 0x00020000);
+        float omax = 0.f;                   // f16 tower: the largest |output| this thread wrote (65504 = it was saturated)
         const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((_Float16 *)(has_res ? p.res : p.out) + (long)img * HWc * HS_C), 0, HWc * HS_C * 2, 0x00020000);
         const bool sel_res = RECT && p.bg_res != nullptr;
 #define HS_ROWS(pass) (((pass) + 1 < NPASS ? 2 : NI - 2 * (NPASS - 1)) * 32)
@@ -467,13 +468,21 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
                 for (int e = 0; e < 8; ++e) {
                     float t_ = v[e];
                     if (has_res) t_ += hs_from16<BF>(rv[pass][j][e]);
-                    o_[e] = hs_to16<BF>(fmaxf(t_, relu_floor));
+                    t_ = fmaxf(t_, relu_floor);
+                    if (!BF && off[pass][j] < 0x40000000u) omax = fmaxf(omax, fabsf(t_));      // f16 activations saturate at 65504: seen, not silent
+                    o_[e] = hs_to16<BF>(t_);
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, o_), o_rsrc, 2u * off[pass][j], 0, 0);
             }
         }
 #undef HS_ROWS
 #undef HS_EPI_PREP
+        if (!BF && omax >= 65504.f) {        // the f16 tower's range guard: the same flag word and guard word as the split form's clamp
+            int *t = (int *)const_cast<float *>(p.wscale_inv);
+            atomicOr(t + 4, 1);
+            int *shared = *(int *const *)(t + 6);
+            if (shared) __hip_atomic_store(shared, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (RECT && p.bg_out) {              // see the other frame's copy loop below: 16 lanes per pixel here
             const float invF = 1.0f / (float)p.Wd;
             for (int q = part * 16 + rr0; q < HWc; q += 16 * parts) {

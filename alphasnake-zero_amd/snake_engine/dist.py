@@ -31,19 +31,49 @@ def sample_plan(n_records_all_ranks, world=1):
     return wanted, batch_size, wanted // world
 
 
-def sample_share(n_local_records, total_samples, world, rng):
-    """indices of this rank's share of the `total_samples` training rows (trainer.py:63-74 draws
-    sample(range(len(records)), samples) from one pool; here every rank draws total/world from its own)"""
+def gather_counts(n_local_records, group=None, single_rank_collective=False):
+    """(every rank's record count, a seed all ranks share): one small all-gather.  The counts decide how many rows each rank
+    contributes (share_counts); the seed is rank 0's draw, so that every rank computes the same split."""
+    seed = int(np.random.randint(1 << 31))
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not single_rank_collective):
+        return [int(n_local_records)], seed
+    world = dist.get_world_size(group)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    mine = torch.tensor([int(n_local_records), seed], dtype=torch.int64, device=dev)
+    out = torch.empty((world * 2,), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    out = out.cpu().numpy().reshape(world, 2)
+    return [int(v) for v in out[:, 0]], int(out[0, 1])
+
+
+def share_counts(counts, total_samples, seed):
+    """rows every rank contributes to the `total_samples` training rows, the same list on every rank.  trainer.py:71 draws
+    sample(range(len(records)), samples) from ONE pool, without replacement; here every rank draws from its own records:
+    total // world each wherever a rank holds that many.  A rank that holds fewer gives all it has, and the shortfall is drawn
+    from what the other ranks have left, as one sample without replacement from the union of those leftovers (the per-rank
+    counts of such a sample are multivariate hypergeometric) -- no row is ever used twice.  (Until round 4 a short rank repeated
+    its rows.)"""
+    world = len(counts)
+    counts = np.asarray(counts, np.int64)
+    assert total_samples <= int(counts.sum()), (total_samples, counts)
     share = total_samples // world
-    if n_local_records == 0:
-        return np.zeros(0, np.int64), share
-    if n_local_records >= share:
-        return rng.choice(n_local_records, size=share, replace=False), share
-    return np.resize(rng.permutation(n_local_records), share), share
+    k = np.minimum(counts, share)
+    short = int(total_samples - k.sum())
+    if short:
+        left = counts - k
+        k = k + np.random.Generator(np.random.PCG64(seed)).multivariate_hypergeometric(left, short)
+    return [int(v) for v in k]
 
 
-def all_gather_samples(X, V, group=None, single_rank_collective=False):
-    """X [k, h, w, 3] float32, V [k, 3] float32 with the same k on every rank -> concatenation over ranks.
+def sample_share(n_local_records, rows, rng):
+    """indices of `rows` of this rank's records, without replacement"""
+    assert rows <= n_local_records, (rows, n_local_records)
+    return rng.choice(n_local_records, size=rows, replace=False) if rows else np.zeros(0, np.int64)
+
+
+def all_gather_samples(X, V, rows_per_rank=None, group=None, single_rank_collective=False):
+    """X [k, h, w, 3] float32, V [k, 3] float32 -> concatenation over ranks.  `rows_per_rank` (share_counts): the ranks' k when
+    they differ -- the exchange then moves max(k) rows per rank (short ranks pad) and the padding is dropped on arrival.
     With one rank there is nothing to exchange; `single_rank_collective` runs the collectives anyway (the RCCL calls
     themselves can then be exercised on a one-GPU box, tests/test_bench_gpu.py)."""
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not single_rank_collective):
@@ -52,10 +82,17 @@ def all_gather_samples(X, V, group=None, single_rank_collective=False):
     dev = X.device
     if dist.get_backend(group) == "gloo" and X.is_cuda:      # rehearsal backend: stage through host memory
         X, V = X.cpu(), V.cpu()
-    Xo = torch.empty((world * X.shape[0],) + tuple(X.shape[1:]), dtype=X.dtype, device=X.device)
-    Vo = torch.empty((world * V.shape[0],) + tuple(V.shape[1:]), dtype=V.dtype, device=V.device)
+    kmax = X.shape[0] if rows_per_rank is None else max(rows_per_rank)
+    if X.shape[0] < kmax:
+        X = torch.cat([X, X.new_zeros((kmax - X.shape[0],) + tuple(X.shape[1:]))])
+        V = torch.cat([V, V.new_zeros((kmax - V.shape[0],) + tuple(V.shape[1:]))])
+    Xo = torch.empty((world * kmax,) + tuple(X.shape[1:]), dtype=X.dtype, device=X.device)
+    Vo = torch.empty((world * kmax,) + tuple(V.shape[1:]), dtype=V.dtype, device=V.device)
     dist.all_gather_into_tensor(Xo, X.contiguous(), group=group)
     dist.all_gather_into_tensor(Vo, V.contiguous(), group=group)
+    if rows_per_rank is not None and min(rows_per_rank) < kmax:
+        keep = torch.cat([torch.arange(r * kmax, r * kmax + k) for r, k in enumerate(rows_per_rank)]).to(Xo.device)
+        Xo, Vo = Xo[keep], Vo[keep]
     return Xo.to(dev), Vo.to(dev)
 
 

@@ -170,6 +170,13 @@ class DeviceMCTS:
         epochs = self.max_breadth // par                        # agent.py:37
         tt = self.tt.h
         seq = int(self.sequential)
+        if self.guard is not None:
+            # a guard word left set by somebody else (a direct QNet.forward / activation_report that clamped, a search that raised)
+            # would make the device skip the tail of every tick that evaluates nothing, unseen: start from a clear word
+            self.guard.guard_post()
+            torch.cuda.current_stream().synchronize()
+            if self.guard.guard_tripped():
+                self.guard.guard_recover()
         for ep in range(epochs):
             t_epoch = time()
             root.clone_to(self.roll, src_slots=live_slots, n=G, fanout=par)       # game.subgame (agent.py:46-50)
@@ -225,6 +232,9 @@ class DeviceMCTS:
                 redone = False
                 while pend is not None and guard.guard_tripped():
                     if pend["redos"] >= 4:
+                        # the tick's new entries have no priors and the word is set: leave neither behind for a caller that catches this
+                        guard.guard_recover()
+                        self.clear()
                         raise EngineError("the Q-net's range guard tripped four times on the same batch; use SNK_CONV_ALGO=winograd")
                     guard.guard_recover()
                     pend["redos"] += 1

@@ -305,7 +305,7 @@ class QNet:
     @property
     def guard_ptr(self):
         """address of the net's device guard word (0: this net has no range to watch): the gate of the rollout tick's kernels"""
-        return self._guard[0].data_ptr() if self._guard is not None and self.conv_algo == "f16s" else 0
+        return self._guard[0].data_ptr() if self._guard is not None and self.conv_algo in ("f16s", "f16", "f16a") else 0
 
     def guard_post(self):
         """after a forward: copy the guard word to its pinned host mirror, asynchronously -- `guard_tripped` is valid once the
@@ -318,6 +318,11 @@ class QNet:
     def guard_recover(self):
         """a launch clamped: lower the flagged layers' activation scales by 2^6, clear the flags and the word"""
         bad = [i for i, f in enumerate(self.range_flags()) if f]      # also clears the word and its mirror
+        if bad and self.conv_algo == "f16a":
+            # f16 activations in HBM have no scale to lower: an output beyond 65 504 was saturated and nothing can evaluate the batch
+            # exactly in this form -- say so instead of handing on values computed from saturated activations
+            raise EngineError(f"f16-activation tower: outputs of tower layer(s) {bad} exceeded the f16 range and were saturated; "
+                              "use SNK_CONV_ALGO=bf16 (float32's exponent range) or the float32-accurate default")
         self.widen(bad)
         self.guard_trips += 1
         return bad
@@ -325,9 +330,10 @@ class QNet:
     def forward_guarded(self, planes, mask=None, out=None, tries=4):
         """forward() whose result is float32-accurate or an error, for callers that can wait: after the batch the guard word is
         copied back and the stream synchronised; a layer that clamped an input gets its activation scale lowered by 2^6 and
-        the WHOLE batch is evaluated again, so the caller never sees a Q value computed from clamped activations.  (f16s
-        only; the other algorithms have no range to watch and return forward() as it is.  The search does not wait: its
-        tick kernels are gated on the word instead, snake_engine/mcts.py.)"""
+        the WHOLE batch is evaluated again, so the caller never sees a Q value computed from clamped activations.  (f16s and
+        f16: scaled float32 inputs; f16a: an f16 output that saturated raises, there is no scale to lower; winograd, direct and
+        bf16 have no range to watch and return forward() as it is.  The search does not wait: its tick kernels are gated on
+        the word instead, snake_engine/mcts.py.)"""
         if not self.guard_ptr:                 # no range to watch / a net without tower layers
             return self.forward(planes, mask, out)
         bad = []

@@ -106,21 +106,21 @@ class AlphaSnakeZeroTrainer:
             V = [alice.values[i] for i in picked]
         else:                                  # every rank contributes its share of the rows, all ranks get all rows
             import torch
-            from snake_engine.dist import sample_share, all_gather_samples
+            from snake_engine.dist import gather_counts, share_counts, sample_share, all_gather_samples
             world = dist.get_world_size()
-            # [records of all ranks, ranks without a record]: the batch count comes from ALL records (trainer.py:64-68), and a rank
-            # that has nothing to sample from is every rank's error -- decided from the reduced tensor, so that all ranks raise
-            # together instead of one raising while its peers wait inside the all-gather
-            t = torch.tensor([n, int(n == 0)], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(t)
-            n_all, n_empty = (int(v) for v in t.tolist())
+            # every rank's record count: the batch count comes from ALL records (trainer.py:64-68), and a rank that has nothing to
+            # sample from is every rank's error -- decided from the gathered counts, so that all ranks raise together instead of
+            # one raising while its peers wait inside the all-gather
+            counts, seed = gather_counts(n)
+            n_all, n_empty = sum(counts), sum(c == 0 for c in counts)
             if n_empty:
                 raise RuntimeError(f"{n_empty} of {world} ranks recorded no state to sample from (this rank: {n} records)")
             wanted, batch_size, _ = sample_plan(n_all, world)
-            idx, share = sample_share(n, wanted, world, np.random.RandomState(np.random.randint(1 << 31)))
+            rows = share_counts(counts, wanted, seed)          # equal shares; a rank short of its share is topped up by the others
+            idx = sample_share(n, rows[dist.get_rank()], np.random.RandomState(np.random.randint(1 << 31)))
             Xd = alice.records.fetch_device(idx)
             Vd = torch.as_tensor(alice._values_host()[idx], device=Xd.device)
-            Xg, Vg = all_gather_samples(Xd, Vd)
+            Xg, Vg = all_gather_samples(Xd, Vd, rows)
             X, V = list(Xg.cpu().numpy()), list(Vg.cpu().numpy())
         alice.clear()
         X += self.mirror_states(X)

@@ -144,7 +144,7 @@ class _Net:
             h = self._conv_bn(h, i + 5, train, residual=sc)
             i += 10
         h = self._conv_bn(h, i, train)
-        h = h.permute(0, 2, 3, 1).reshape(h.shape[0], -1)
+        h = h.permute(0, 2, 3, 1).reshape(h.shape[0], h.shape[1] * h.shape[2] * h.shape[3])      # (explicit: a rank's slice may be empty)
         h = F.relu(h @ self.t[i + 5] + self.t[i + 6])
         return torch.tanh(h @ self.t[i + 7] + self.t[i + 8])
 
@@ -222,10 +222,13 @@ def fit(weights, input_shape, X, Y, epochs=32, batch_size=2048, lr_schedule=None
         cnt = 0
         for s0 in range(0, n, batch_size):
             idx_all = perm[s0:s0 + batch_size]
-            if len(idx_all) < world:
-                # every rank sees the same permutation, so every rank takes this branch: nobody is left inside the batch-norm
-                # or gradient all-reduces of a batch that another rank refused
+            if len(idx_all) < world and native is not None:
+                # the kernels of the native step take at least one row.  Every rank sees the same permutation, so every rank takes
+                # this branch: nobody is left inside the batch-norm or gradient all-reduces of a batch that another rank refused.
+                # (The trainer never gets here: snake_engine.dist.sample_plan yields whole batches.)
                 raise RuntimeError(f"fit: a trailing batch of {len(idx_all)} rows cannot be split over {world} ranks")
+            # Keras' fit trains on a short trailing batch like on any other; a rank whose slice of it is empty still joins every
+            # all-reduce of the step with sums over no rows (zeros) and its share of the l2 term
             idx = idx_all[rank::world]
             lr = lr_at(step, lr_schedule)
             if native is not None:

@@ -386,20 +386,16 @@ def main():
     cpu_play = time.process_time() - cpu0      # user + system cpu seconds of this rank's process over the self-play steps
     # iteration-end exchange (trainer.py:63-75 across ranks): the row count comes from the records of ALL ranks, every rank
     # sends its share of the sampled rows (all-gather), the six log counters are all-reduced
-    n_rec = torch.tensor([len(alice.records)], dtype=torch.int64, device=coll_dev)
-    if world > 1:
-        dist.all_reduce(n_rec)
-    wanted, _, share = sdist.sample_plan(max(int(n_rec.item()), world), world)
-    rng = np.random.RandomState(rank)
-    idx, share = sdist.sample_share(len(alice.records), wanted, world, rng)
-    X = alice.records.fetch_device(idx) if len(idx) else torch.zeros((share, OBS, OBS, 3), dtype=torch.float32, device="cuda")
-    if X.shape[0] < share:
-        X = torch.cat([X, X.new_zeros((share - X.shape[0], OBS, OBS, 3))])
-    Vs = torch.as_tensor(alice._values_host()[idx] if len(idx) else np.zeros((share, 3), np.float32), device="cuda")
-    if Vs.shape[0] < share:
-        Vs = torch.cat([Vs, Vs.new_zeros((share - Vs.shape[0], 3))])
+    counts, seed = sdist.gather_counts(len(alice.records))
+    wanted, _, share = sdist.sample_plan(max(sum(counts), world), world)
+    wanted = min(wanted, sum(counts) // world * world)          # (a run too short to have recorded `world` rows samples what there is)
+    rows = sdist.share_counts(counts, wanted, seed)             # equal shares; a rank short of its share is topped up by the others
+    share = max(rows)
+    idx = sdist.sample_share(len(alice.records), rows[rank], np.random.RandomState(rank))
+    X = alice.records.fetch_device(idx) if len(idx) else torch.zeros((0, OBS, OBS, 3), dtype=torch.float32, device="cuda")
+    Vs = torch.as_tensor(alice._values_host()[idx] if len(idx) else np.zeros((0, 3), np.float32), device="cuda")
     t1 = sync_clock()
-    Xg, Vg = sdist.all_gather_samples(X, Vs)
+    Xg, Vg = sdist.all_gather_samples(X, Vs, rows)
     t2 = sync_clock()
     sdist.all_reduce_counters(gr.engine.sum_counters(), args.games, "cuda")
     t3 = sync_clock()

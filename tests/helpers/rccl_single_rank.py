@@ -28,6 +28,8 @@ sums_ref = sums.clone()
 dist.all_reduce(sums)
 n_rec = torch.tensor([4711], dtype=torch.int64, device="cuda")                    # record counts of all ranks -> the sample plan
 dist.all_reduce(n_rec)
+counts, seed = sdist.gather_counts(4711, single_rank_collective=True)             # ncclAllGather int64 [records, seed]
+assert counts == [4711] and sdist.share_counts(counts, 4096, seed) == [4096]
 mine = torch.arange(8, dtype=torch.float64, device="cuda")                        # bench.py's per-rank row
 rows = torch.empty(8, dtype=torch.float64, device="cuda")
 dist.all_gather_into_tensor(rows, mine)

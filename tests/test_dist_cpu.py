@@ -31,7 +31,12 @@ def _worker(rank, world, port, out_dir):
         # each rank "self-plays" its shard: records are tagged with (rank, index)
         n_local = 37 + 5 * rank
         rng = np.random.RandomState(rank)
-        idx, share = sdist.sample_share(n_local, 64, world, rng)
+        counts, seed = sdist.gather_counts(n_local)
+        assert counts == [37, 42]
+        rows = sdist.share_counts(counts, 64, seed)
+        assert rows == [32, 32]
+        share = rows[rank]
+        idx = sdist.sample_share(n_local, share, rng)
         assert share == 32 and len(idx) == 32 and len(set(idx.tolist())) == 32 and idx.max() < n_local
         X = torch.zeros((share, 3, 3, 3))
         X[:, 0, 0, 0] = rank
@@ -62,6 +67,61 @@ def test_two_rank_exchange(tmp_path):
     assert torch.equal(res[0]["Xg"], res[1]["Xg"])
 
 
+def _uneven_worker(rank, world, port, out_dir):
+    """rank 0 recorded 40 states, rank 1 recorded 4 000: the plan wants 2 048 rows (one batch of ALL records)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [repo, os.path.join(repo, "alphasnake-zero_amd")]
+    from snake_engine import dist as sdist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_local = 40 if rank == 0 else 4000
+        counts, seed = sdist.gather_counts(n_local)
+        wanted, batch, _ = sdist.sample_plan(sum(counts), world)
+        rows = sdist.share_counts(counts, wanted, seed)
+        idx = sdist.sample_share(n_local, rows[rank], np.random.RandomState(100 + rank))
+        X = torch.zeros((len(idx), 3, 3, 3))
+        X[:, 0, 0, 0] = rank
+        X[:, 0, 0, 1] = torch.as_tensor(idx, dtype=torch.float32)
+        V = torch.full((len(idx), 3), float(rank))
+        Xg, Vg = sdist.all_gather_samples(X, V, rows)
+        torch.save(dict(counts=counts, wanted=wanted, batch=batch, rows=rows, Xg=Xg, Vg=Vg), os.path.join(out_dir, f"u{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_rank_short_of_its_share_is_topped_up_without_repeating_a_row(tmp_path):
+    """trainer.py:71 samples WITHOUT replacement from all records.  With very uneven shards (40 / 4 000 records, 2 048 rows wanted)
+    the short rank gives all it has and the other rank makes up the difference: 2 048 distinct rows arrive on every rank, none
+    twice (until round 4 the short rank repeated its 40 rows 25 times)"""
+    world, port = 2, _free_port()
+    mp.spawn(_uneven_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f"u{r}.pt", weights_only=False) for r in range(world)]
+    for r in res:
+        assert r["counts"] == [40, 4000] and (r["wanted"], r["batch"]) == (2048, 2048) and r["rows"] == [40, 2008]
+        Xg, Vg = r["Xg"], r["Vg"]
+        assert Xg.shape == (2048, 3, 3, 3) and Vg.shape == (2048, 3)
+        tags = {(int(a), int(b)) for a, b in zip(Xg[:, 0, 0, 0].tolist(), Xg[:, 0, 0, 1].tolist())}
+        assert len(tags) == 2048, "a row was used twice"
+        assert sum(1 for a, _ in tags if a == 0) == 40 and (Vg[:40] == 0).all() and (Vg[40:] == 1).all()
+    assert torch.equal(res[0]["Xg"], res[1]["Xg"])
+
+
+def test_share_counts_split():
+    """equal shares wherever every rank can afford them; otherwise the shortfall comes from the others' leftovers, the same split on
+    every rank (same seed), never more than a rank holds"""
+    from snake_engine.dist import share_counts
+    assert share_counts([5000, 5000, 5000, 5000], 8192, 1) == [2048] * 4
+    for seed in range(20):
+        k = share_counts([10, 3000, 50, 9000], 8192, seed)
+        assert sum(k) == 8192 and k[0] == 10 and k[2] == 50 and 2048 <= k[1] <= 3000 and 2048 <= k[3] <= 9000
+        assert k == share_counts([10, 3000, 50, 9000], 8192, seed)
+    assert share_counts([1, 1, 1, 8189], 8192, 7) == [1, 1, 1, 8189]
+    ks = {tuple(share_counts([10, 3000, 50, 9000], 8192, s)) for s in range(20)}
+    assert len(ks) > 1, "the top-up is a draw, not a fixed rule"
+
+
 def _collect_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import sys
@@ -81,29 +141,42 @@ def _collect_worker(rank, world, port, out_dir):
         except RuntimeError as e:
             what = str(e)
         open(os.path.join(out_dir, f"c{rank}.txt"), "w").write(what)
-        # fit: a trailing batch smaller than the world is refused by EVERY rank (same permutation on all of them)
+        # fit: a trailing batch smaller than the world (5 rows, batch 4, 2 ranks: one row) is trained on like any other batch
+        # (Keras' fit does): the rank whose slice of it is empty joins the step's all-reduces with sums over no rows
         from utils import trainer_torch
         from snake_engine.net import glorot_uniform_weights
         ws = glorot_uniform_weights((5, 5, 3), blocks=1, seed=0)
-        X = np.zeros((5, 5, 5, 3), np.float32); Y = np.zeros((5, 3), np.float32)
-        try:
-            trainer_torch.fit(ws, (5, 5, 3), X, Y, epochs=1, batch_size=4, lr_schedule=None, device="cpu", seed=0, verbose=False)
-            what = "returned"
-        except RuntimeError as e:
-            what = str(e)
-        open(os.path.join(out_dir, f"f{rank}.txt"), "w").write(what)
+        rs = np.random.RandomState(3)
+        X = rs.rand(5, 5, 5, 3).astype(np.float32); Y = np.tanh(rs.randn(5, 3)).astype(np.float32)
+        out = trainer_torch.fit(ws, (5, 5, 3), X, Y, epochs=2, batch_size=4, lr_schedule=([100], [1e-3, 0.0]), device="cpu", seed=0,
+                                verbose=False, dtype=torch.float64)
+        np.savez(os.path.join(out_dir, f"f{rank}.npz"), *out)
     finally:
         dist.destroy_process_group()
 
 
-def test_a_rank_without_records_and_an_unsplittable_batch_fail_on_every_rank(tmp_path):
+def test_a_rank_without_records_fails_on_every_rank_and_a_short_trailing_batch_is_trained_on(tmp_path):
     """a rank that cannot contribute must not raise alone while its peers wait inside a collective: both ranks raise the same
-    error, decided from the all-reduced counts (iteration-end sampling) or from what every rank sees (the fit's trailing batch)"""
+    error, decided from the gathered counts (iteration-end sampling).  The fit's trailing batch of fewer rows than ranks is an
+    ordinary optimizer step (Keras trains on it): both ranks end with the same weights, and those equal the one-process fit"""
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [p for p in (repo, os.path.join(repo, "alphasnake-zero_amd")) if p not in sys.path]
     world, port = 2, _free_port()
     mp.spawn(_collect_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert "1 of 2 ranks recorded no state" in open(tmp_path / f"c{r}.txt").read()
-        assert "trailing batch of 1 rows cannot be split over 2 ranks" in open(tmp_path / f"f{r}.txt").read()
+    got = [[z[k] for k in z.files] for z in (np.load(tmp_path / f"f{r}.npz") for r in range(world))]
+    from utils import trainer_torch
+    from snake_engine.net import glorot_uniform_weights
+    ws = glorot_uniform_weights((5, 5, 3), blocks=1, seed=0)
+    rs = np.random.RandomState(3)
+    X = rs.rand(5, 5, 5, 3).astype(np.float32); Y = np.tanh(rs.randn(5, 3)).astype(np.float32)
+    one = trainer_torch.fit(ws, (5, 5, 3), X, Y, epochs=2, batch_size=4, lr_schedule=([100], [1e-3, 0.0]), device="cpu", seed=0,
+                            verbose=False, dtype=torch.float64)
+    assert any(np.abs(a - b).max() > 1e-6 for a, b in zip(one, ws)), "the fit moved nothing"
+    for a, b, c in zip(got[0], got[1], one):
+        assert np.array_equal(a, b) and np.abs(a - c).max() <= 1e-9 * max(1.0, np.abs(c).max())
 
 
 def test_shard_range_partitions_everything():
@@ -114,10 +187,11 @@ def test_shard_range_partitions_everything():
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
-    idx, share = sample_share(5, 64, 2, np.random.RandomState(0))     # fewer local records than the share: wraps
-    assert share == 32 and len(idx) == 32 and set(idx.tolist()) == set(range(5))
-    idx, share = sample_share(0, 64, 2, np.random.RandomState(0))
-    assert share == 32 and len(idx) == 0
+    idx = sample_share(5, 5, np.random.RandomState(0))                # all of a short rank's records, each once
+    assert sorted(idx.tolist()) == list(range(5))
+    assert len(sample_share(0, 0, np.random.RandomState(0))) == 0
+    with pytest.raises(AssertionError):
+        sample_share(5, 32, np.random.RandomState(0))                 # more rows than records: share_counts never asks for that
 
 
 def test_bench_launcher_reports_a_failed_rank_and_does_not_hang():

@@ -499,14 +499,16 @@ def test_agent_calibrates_new_weights_and_checks_the_range_every_turn(env, monke
     assert nn_._qnet.calibrated and nn_._qnet.range_flags() == [0] * 8 and gr.env_steps == 16
 
 
-def test_a_clamped_batch_is_evaluated_again_inside_the_search(env, monkeypatch):
-    """scales that are far too large for the activations (set after the calibration, as a weight update would leave them): the
+@pytest.mark.parametrize("algo", ["f16s", "f16"])
+def test_a_clamped_batch_is_evaluated_again_inside_the_search(env, monkeypatch, algo):
+    """(f16: the reduced-precision form with scaled float32 inputs clamps in the same staging code and is guarded the same way)
+    scales that are far too large for the activations (set after the calibration, as a weight update would leave them): the
     first batch of the next root turn clamps, AlphaNNet.v_device (QNet.forward_guarded) widens the layer's scale and evaluates
     THAT BATCH again before anything reaches the transposition table -- the search runs once, the table keeps the statistics of
     the earlier turns (the reference keeps them until Agent.clear, agent.py:140-147), and records, values and counts equal
     those of an undisturbed twin run"""
     torch, se, net = env
-    monkeypatch.setenv("SNK_CONV_ALGO", "f16s")
+    monkeypatch.setenv("SNK_CONV_ALGO", algo)
     from utils.agent import Agent
     from utils.alpha_nnet import AlphaNNet
     from utils.mp_game_runner import MPGameRunner
@@ -542,7 +544,7 @@ def test_a_clamped_batch_is_evaluated_again_inside_the_search(env, monkeypatch):
     assert a._mcts.draw_ctr == b._mcts.draw_ctr and a._mcts.now == b._mcts.now == 3
     assert len(a.records) == len(b.records) and all(x.tobytes() == y.tobytes() for x, y in zip(a.records[:], b.records[:]))
     va, vb = np.array(a.values[:]), np.array(b.values[:])
-    assert np.abs(va - vb).max() <= TOL_Q, np.abs(va - vb).max()
+    assert np.abs(va - vb).max() <= TOL_Q, np.abs(va - vb).max()      # (a power-of-two scale does not move an f16 rounding point)
     # a net without a range to watch is "calibrated" at once: no observation pass per root turn
     monkeypatch.setenv("SNK_CONV_ALGO", "winograd")
     nw = AlphaNNet(input_shape=(21, 21, 3), _weights=ws)
@@ -574,23 +576,40 @@ def test_gated_ticks_replay_a_clamped_evaluation_wherever_it_happens(env, monkey
         gr = MPGameRunner(11, 11, 4, 1, 24, seed=5)
         gr.run(alice, max_turns=8)                                      # calibrates; some snakes die: deeper rollouts
         qn, calls, orig = nn_._qnet, [0], nn_._qnet.forward
+        # how far every tower layer's input is from the f16 limit on mid-game observations: a disturbance is sized from it, so that
+        # it CLAMPS on any batch whose largest activation is within 8x of these (scaled maximum 8x beyond the limit) and FITS
+        # again after the guard's one widening by 2^-6 (8x below the limit): every scheduled site bites, and bites once
+        eng_planes = torch.as_tensor(np.stack([alice.records[i] for i in range(0, len(alice.records), 7)][:96]), device="cuda")
+        amax = [r[0] for r in qn.activation_report(eng_planes)]
+        qn.range_flags()
+        fired = []
 
         def fwd(planes, mask=None, out=None):
             calls[0] += 1
             if calls[0] in trip_calls:
                 layer = calls[0] % 8
-                qn.set_x_scale(layer, qn.conv_x_scale[layer] * 2.0 ** 14)
+                headroom = 65504.0 / (amax[layer] * qn.conv_x_scale[layer])
+                factor = 2.0 ** (int(np.ceil(np.log2(headroom))) + 3)
+                qn.set_x_scale(layer, qn.conv_x_scale[layer] * factor)
+                fired.append((calls[0], layer, factor, qn.guard_trips))
             return orig(planes, mask, out)
         qn.forward = fwd
         ticks0 = alice._mcts.stats["rollout_ticks"]
         gr.run(alice, max_turns=3)
-        return nn_, alice, gr, calls[0], alice._mcts.stats["rollout_ticks"] - ticks0
+        return nn_, alice, gr, calls[0], alice._mcts.stats["rollout_ticks"] - ticks0, fired
 
-    nn_a, a, gr_a, n_calls, n_ticks = play(())
+    nn_a, a, gr_a, n_calls, n_ticks, _ = play(())
     assert n_ticks > 3 * 2 * 2, "several ticks per epoch"
-    trips = {1, 2, 5, n_calls // 3, n_calls // 2, n_calls - 2, n_calls + 5}     # + 5: the twin's last call comes later (its repeats count)
-    nn_b, b, gr_b, n_calls_b, _ = play(trips)
-    assert nn_a._qnet.guard_trips == 0 and b._mcts.guard_redos == nn_b._qnet.guard_trips >= 4, nn_b._qnet.guard_trips
+    # the first call of a root turn, the next one (the repeat of the first: a repeat that clamps again), an early one, two in the
+    # middle, the last but one, and one past the undisturbed run's last call (+ 5: the twin's repeats are calls too)
+    trips = {1, 2, 5, n_calls // 3, n_calls // 2, n_calls - 2, n_calls + 5}
+    nn_b, b, gr_b, n_calls_b, _, fired = play(trips)
+    assert len(fired) == len(trips) == 7, f"not every scheduled call happened: {[f[0] for f in fired]} of {sorted(trips)}"
+    after = [f[3] for f in fired[1:]] + [nn_b._qnet.guard_trips]
+    dead = [(call, layer, factor) for (call, layer, factor, before), aft in zip(fired, after) if aft == before]
+    assert not dead, f"scheduled disturbances that did not clamp (call, layer, factor): {dead}"
+    assert nn_a._qnet.guard_trips == 0 and b._mcts.guard_redos == nn_b._qnet.guard_trips == len(fired), (
+        b._mcts.guard_redos, nn_b._qnet.guard_trips, fired)
     assert n_calls_b == n_calls + b._mcts.guard_redos
     assert nn_b._qnet.range_flags() == [0] * 8 and not nn_b._qnet.guard_tripped()
     assert a._mcts.stats == b._mcts.stats, (a._mcts.stats, b._mcts.stats)
@@ -599,6 +618,33 @@ def test_gated_ticks_replay_a_clamped_evaluation_wherever_it_happens(env, monkey
     assert all(x.tobytes() == y.tobytes() for x, y in zip(a.records[:], b.records[:]))
     va, vb = np.array(a.values[:]), np.array(b.values[:])
     assert np.abs(va - vb).max() <= TOL_Q, np.abs(va - vb).max()
+
+
+def test_f16_activation_tower_reports_a_saturated_activation(env, monkeypatch):
+    """`SNK_CONV_ALGO=f16a` keeps activations as f16 in HBM and saturates an output beyond 65 504 instead of writing an infinity: that
+    is a gross error, not f16 rounding, so the tower layer sets its range flag and the net's guard word (as the split form's clamp
+    does) -- callers that can wait get an EngineError from forward_guarded / AlphaNNet.v, the search's gate sees the word -- and the
+    bf16 tower, which has float32's range, evaluates the same weights without complaint"""
+    torch, se, net = env
+    from snake_engine import EngineError
+    s = load_golden("states_11x11x4.npz")
+    x = torch.as_tensor(s["raw"][:64], device="cuda")
+    ws = _adversarial_bn(net)
+    ws[5 + 5 * 6 + 3] = np.full(128, -2.0e5, np.float32)          # tower layer 6's moving mean: its output is ~2e5, beyond the f16 range
+    monkeypatch.setenv("SNK_CONV_ALGO", "f16a")
+    qn = net.QNet(ws, (21, 21, 3))
+    assert qn.guard_ptr != 0
+    q = qn.forward(x).cpu().numpy()                                # the unguarded forward: saturated, finite ...
+    assert np.isfinite(q).all() and qn.range_flags(clear=False)[6] == 1      # ... and flagged on the layer that saturated
+    with pytest.raises(EngineError, match="saturated"):
+        qn.forward_guarded(x)
+    assert qn.range_flags() == [0] * 8 and not qn.guard_tripped()  # the raise leaves no flag behind
+    good = net.QNet(net.glorot_uniform_weights((21, 21, 3), blocks=4, seed=0), (21, 21, 3))
+    good.forward_guarded(x)
+    assert good.guard_trips == 0 and good.range_flags() == [0] * 8
+    monkeypatch.setenv("SNK_CONV_ALGO", "bf16")
+    qb = net.QNet(ws, (21, 21, 3))
+    assert qb.guard_ptr == 0 and np.isfinite(qb.forward_guarded(x).cpu().numpy()).all()
 
 
 def test_f16_activation_tower_layer_and_net(env, monkeypatch):

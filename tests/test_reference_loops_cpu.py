@@ -69,7 +69,7 @@ def test_c_self_play_replays_the_generations_of_the_reference_trainer(oracle, ta
 
 def test_sample_plan_is_the_reference_arithmetic_for_any_world_size():
     """rows sampled = 2048 * min(5, len(records) // 2048) whatever the number of ranks (trainer.py:63-72 on ALL records)"""
-    from snake_engine.dist import sample_plan, sample_share
+    from snake_engine.dist import sample_plan, sample_share, share_counts
     for n in (2048, 2049, 4095, 4096, 10239, 10240, 51200, 1_000_000):
         ref_batches = min(5, n // 2048)
         for world in (1, 2, 4, 8):
@@ -77,8 +77,9 @@ def test_sample_plan_is_the_reference_arithmetic_for_any_world_size():
             assert (wanted, batch, share * world) == (2048 * ref_batches, 2048, 2048 * ref_batches)
             # eight ranks with ~n/8 records each still gather the single-process row count
             per_rank = [n // world + (1 if r < n % world else 0) for r in range(world)]
-            got = sum(len(sample_share(k, wanted, world, np.random.RandomState(r))[0]) for r, k in enumerate(per_rank))
-            assert got == wanted
+            rows = share_counts(per_rank, wanted, seed=n + world)
+            got = sum(len(sample_share(k, rows[r], np.random.RandomState(r))) for r, k in enumerate(per_rank))
+            assert got == wanted and all(v == wanted // world for v in rows)
     # fewer than one batch of records: everything is one batch (the reference fails in `flip` here)
     assert sample_plan(1000, 1) == (1000, 1000, 1000)
     assert sample_plan(1001, 2) == (1000, 1000, 500)
