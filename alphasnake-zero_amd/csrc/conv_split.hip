@@ -118,6 +118,10 @@ struct ConvHsArgs {
     const float *bg_in;        // or NULL; the input's background image: x is valid on the bounding box grown by grow_in (cut to the
     const float *bg_res;       //   canvas) and stale outside, where the producing layer's constant is read instead; the same for res
     int grow_in, grow_res;
+    // MODE 5 (training step, input gradient): the batch-norm backward sums of the layer whose output gradient this launch produces
+    const float *g_y;          // that layer's pre-batch-norm output [n][Hd][Wd][128]
+    const unsigned char *g_mask;   // its ReLU bits, one byte per quad of channels (csrc/train.hip)
+    const float *g_inv;        // its 1 / sigma per channel (center = its batch mean)
 };
 
 #ifdef HS_STAMPS       // development build only (tools/conv_stamps.py): s_memtime at the phase boundaries of every block
@@ -142,6 +146,9 @@ extern "C" int snk_dbg_conv_stamps(unsigned long long *h_out, int n_blocks)
 //   0 all read from the arguments; 1 ReLU, no residual; 2 ReLU + residual; 3 ReLU + residual + fused head, no layer output;
 //   4 the training step's forward pass: the bare convolution (no scale / shift / ReLU / residual) plus the per-channel sums its
 //     batch norm needs, taken from the values on their way out (one pass over the activation less per layer and step)
+//   5 the training step's input gradient: the bare convolution (+ the shortcut's gradient as residual) = the gradient at the previous
+//     layer's output, plus the two per-channel sums that layer's batch-norm backward needs -- sum(g), sum(g xhat), g = the gradient
+//     where the layer's ReLU let the value through -- taken from the values on their way out (snk_bn_train_grad_sums_f64's pass saved)
 #define hs_dpp(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
 // SPLIT = false: the reduced-precision form for BASELINE configs[4] ("bf16 MFMA conv"): the same kernel with the hi parts
 //   only, one MFMA per product instead of three (f16 operands: 11 significand bits against bf16's 8, float32 accumulate).
@@ -163,7 +170,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     static_assert(IO16 == 0 || !SPLIT, "f16 activations only exist in the reduced-precision form");
     static_assert(!BF || (IO16 & 1), "the bf16 form reads bf16 activations");
     constexpr bool IN16 = (IO16 & 1) != 0, OUT16 = (IO16 & 2) != 0;
-    constexpr bool STATS = MODE == 4;
+    constexpr bool STATS = MODE == 4, GSTATS = MODE == 5, BARE = STATS || GSTATS;
     constexpr bool K32 = IN16;
     constexpr int RING = K32 ? HS_RING16 : HS_RING, AHEAD = K32 ? HS_AHEAD16 : HS_AHEAD;      // B-fragment register ring: slots (a divisor of 9), taps ahead
     constexpr bool TWO = SPLIT || K32;                     // two A fragments / two B fragments per (tap, M tile)
@@ -171,10 +178,10 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     constexpr int NST = K32 ? HS_NST16 : HS_NST, BUFB = K32 ? HS_BUF16 : HS_NPB * HS_LDP;
     constexpr int PIECE = K32 ? 8 : 4;                     // channels of a staging item
     constexpr bool P8 = IN16 && OUT16;                     // the epilogue handles 8 channels (16 bytes in and out) per thread and row
-    const bool has_res = MODE == 0 ? p.res != nullptr : (MODE == 2 || MODE == 3);
+    const bool has_res = (MODE == 0 || GSTATS) ? p.res != nullptr : (MODE == 2 || MODE == 3);
     const bool has_head = MODE == 0 ? p.w1x1 != nullptr : MODE == 3;
     const bool has_out = MODE == 0 ? p.out != nullptr : MODE != 3;
-    const float relu_floor = ((MODE != 0 && MODE != 4) || (MODE == 0 && p.relu)) ? 0.f : -__builtin_inff();
+    const float relu_floor = ((MODE != 0 && !BARE) || (MODE == 0 && p.relu)) ? 0.f : -__builtin_inff();
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;        // wave wn owns outputs 32 wn .. 32 wn + 31
     const int h = lane >> 5, l31 = lane & 31;
     const int Wr = RECT ? rw : p.Wd;                       // width of the GEMM's image
@@ -496,10 +503,12 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     const int cq = tid & 31, rr0 = tid >> 5;
     const float winv = p.wscale_inv[0] * p.wscale_inv[3];
     float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!STATS) { sc4 = *(const float4 *)(p.scale + 4 * cq); sh4 = *(const float4 *)(p.shift + 4 * cq); }
+    if (!BARE) { sc4 = *(const float4 *)(p.scale + 4 * cq); sh4 = *(const float4 *)(p.shift + 4 * cq); }
     sc4.x *= winv; sc4.y *= winv; sc4.z *= winv; sc4.w *= winv;
     float4 cen4 = make_float4(0.f, 0.f, 0.f, 0.f), st_s = cen4, st_q = cen4;
-    if (STATS && p.center) cen4 = *(const float4 *)(p.center + 4 * cq);
+    if (BARE && p.center) cen4 = *(const float4 *)(p.center + 4 * cq);
+    float4 iv4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (GSTATS) iv4 = *(const float4 *)(p.g_inv + 4 * cq);
     float *Ms = (float *)smem;                                      // [2][64 rows][HS_MLD]
     const long obase = (long)img * HWc * HS_C + 4 * cq;
     float4 wh = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -560,6 +569,15 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
                 v.x += r_.x; v.y += r_.y; v.z += r_.z; v.w += r_.w;
             }
             v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
+            if (GSTATS && off[pass & 1][j] >= 0) {
+                const long e_ = obase + off[pass & 1][j];
+                const unsigned mb_ = p.g_mask[e_ >> 2];
+                const float4 y_ = *(const float4 *)(p.g_y + e_);
+                const float gx = (mb_ & 1u) ? v.x : 0.f, gy = (mb_ & 2u) ? v.y : 0.f, gz = (mb_ & 4u) ? v.z : 0.f, gw = (mb_ & 8u) ? v.w : 0.f;
+                st_s.x += gx; st_s.y += gy; st_s.z += gz; st_s.w += gw;
+                st_q.x += gx * ((y_.x - cen4.x) * iv4.x); st_q.y += gy * ((y_.y - cen4.y) * iv4.y);
+                st_q.z += gz * ((y_.z - cen4.z) * iv4.z); st_q.w += gw * ((y_.w - cen4.w) * iv4.w);
+            }
             if (STATS && off[pass & 1][j] >= 0) {
                 const float ex = v.x - cen4.x, ey = v.y - cen4.y, ez = v.z - cen4.z, ew = v.w - cen4.w;
                 st_s.x += ex; st_s.y += ey; st_s.z += ez; st_s.w += ew;
@@ -584,7 +602,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     }
 #undef HS_ROWS
 #undef HS_EPI_PREP
-    if (STATS) {                           // the eight row lanes' sums of a channel quad are added through LDS, in a fixed order
+    if (BARE) {                            // the eight row lanes' sums of a channel quad are added through LDS, in a fixed order
         __syncthreads();
         float4 *R = (float4 *)smem;        // [2][8][32]
         R[rr0 * 32 + cq] = st_s;
@@ -811,7 +829,8 @@ extern "C" int snk_conv3x3_prepare_weights_f16s_train(const float *d_w_hwio, voi
 static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
                             const float *d_residual, float *d_out, const float *d_w1x1, float s1, float b1, float *d_h1,
                             int n_images, int height, int width, int relu, bool split, void *stream, int io16 = 0,
-                            const float *d_center = nullptr, float *d_stat_part = nullptr, int *grid_out = nullptr, bool bf = false)
+                            const float *d_center = nullptr, float *d_stat_part = nullptr, int *grid_out = nullptr, bool bf = false,
+                            const float *d_gy = nullptr, const unsigned char *d_gmask = nullptr, const float *d_ginv = nullptr)
 {
     SNK_REQUIRE(n_images >= 0 && height >= 1 && width >= 3, "snk_conv3x3_bn_f16s: bad shape %d x %d x %d", n_images, height, width);
     SNK_REQUIRE(d_out != d_x, "snk_conv3x3_bn_f16s: in-place convolution is not possible (blocks read their neighbours' input rows)");
@@ -844,10 +863,24 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
     SNK_REQUIRE((long)n_images * n_blk < (1l << 31) && (long)HW * HS_C < (1l << 31), "snk_conv3x3_bn_f16s: batch too large");
     ConvHsArgs a = {d_x, (const f16x8 *)d_wS, (const float *)((const _Float16 *)d_wS + HS_WS_ELEMS), d_scale, d_shift,
                     d_residual, d_out, d_w1x1, d_h1, s1, b1, height, width, n_blk, tiles_base, tiles_rem, relu, (n_images / 8) * 8,
-                    d_center, d_stat_part, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+                    d_center, d_stat_part, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, d_gy, d_gmask, d_ginv};
     const int n_mt = tiles_max, grid = n_images * n_blk;
     hipStream_t st = (hipStream_t)stream;
     if (grid_out) *grid_out = grid;
+    if (d_stat_part && a.g_y) {          // the training step's input gradient + the previous layer's batch-norm backward sums
+        switch (n_mt) {
+        case 1: k_conv3x3_f16s<1, 5><<<grid, 256, 0, st>>>(a); break;
+        case 2: k_conv3x3_f16s<2, 5><<<grid, 256, 0, st>>>(a); break;
+        case 3: k_conv3x3_f16s<3, 5><<<grid, 256, 0, st>>>(a); break;
+        case 4: k_conv3x3_f16s<4, 5><<<grid, 256, 0, st>>>(a); break;
+        case 5: k_conv3x3_f16s<5, 5><<<grid, 256, 0, st>>>(a); break;
+        case 6: k_conv3x3_f16s<6, 5><<<grid, 256, 0, st>>>(a); break;
+        case 7: k_conv3x3_f16s<7, 5><<<grid, 256, 0, st>>>(a); break;
+        default: k_conv3x3_f16s<8, 5><<<grid, 256, 0, st>>>(a); break;
+        }
+        SNK_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     if (d_stat_part) {                   // the training step's forward pass: bare convolution + batch-norm sums
         switch (n_mt) {
         case 1: k_conv3x3_f16s<1, 4><<<grid, 256, 0, st>>>(a); break;
@@ -1121,7 +1154,7 @@ static int conv_f16s_rect_launch(const float *d_x, const void *d_wS, const float
     if (n_images == 0) return 0;
     ConvHsArgs a = {d_x, (const f16x8 *)d_wS, (const float *)((const _Float16 *)d_wS + HS_WS_ELEMS), d_scale, d_shift,
                     d_residual, d_out, nullptr, nullptr, 0.f, 0.f, height, width, 1, 0, 0, 1, 0, nullptr, nullptr,
-                    (const uint4 *)d_desc, d_count, d_bg_out, d_bg_in, d_residual ? d_bg_res : nullptr, grow_in, grow_res};
+                    (const uint4 *)d_desc, d_count, d_bg_out, d_bg_in, d_residual ? d_bg_res : nullptr, grow_in, grow_res, nullptr, nullptr, nullptr};
     if (act16 && bf) {
         if (d_residual) k_conv3x3_f16s_rect<2, false, 3, true><<<(int)mb, 256, 0, (hipStream_t)stream>>>(a);
         else k_conv3x3_f16s_rect<1, false, 3, true><<<(int)mb, 256, 0, (hipStream_t)stream>>>(a);
@@ -1262,4 +1295,24 @@ extern "C" int snk_conv3x3_bn_bf16_act16_head(const void *d_x16, const void *d_w
     SNK_REQUIRE(d_x16 && d_wS && d_scale && d_shift && d_residual16 && d_w1x1 && d_h1, "snk_conv3x3_bn_bf16_act16_head: NULL argument");
     return conv_f16s_launch((const float *)d_x16, d_wS, d_scale, d_shift, (const float *)d_residual16, nullptr, d_w1x1, bn_scale,
                             bn_shift, d_h1, n_images, height, width, 1, false, stream, 1, nullptr, nullptr, nullptr, true);
+}
+
+// The training step's INPUT-GRADIENT convolution with the next batch-norm backward's sums in its epilogue: d_out = conv3x3_same(d_x,
+// mirrored kernel) (+ d_residual, the shortcut's gradient) is the gradient at the output of the layer below; from the same values
+// on their way out d_sums[0..127] = sum(g), d_sums[128..255] = sum(g * (y - mean) * inv) with g = d_out where that layer's ReLU bit
+// is set (d_mask: one byte per quad of channels, as snk_bn_train_apply writes them; d_y: its pre-batch-norm output) -- what
+// snk_bn_train_grad_sums_f64 computes from d_out in a pass of its own.  d_partials: snk_conv3x3_stats_partials floats.
+extern "C" int snk_conv3x3_f16s_igrad_stats(const float *d_x, const void *d_wS, const float *d_residual, float *d_out, const float *d_y,
+                                            const uint8_t *d_mask, const float *d_mean, const float *d_inv, float *d_partials,
+                                            double *d_sums, int n_images, int height, int width, void *stream)
+{
+    SNK_REQUIRE(d_x && d_wS && d_out && d_y && d_mask && d_mean && d_inv && d_partials && d_sums && n_images > 0,
+                "snk_conv3x3_f16s_igrad_stats: bad argument");
+    int grid = 0;
+    const int rc = conv_f16s_launch(d_x, d_wS, nullptr, nullptr, d_residual, d_out, nullptr, 0.f, 0.f, nullptr, n_images, height, width, 0,
+                                    true, stream, 0, d_mean, d_partials, &grid, false, d_y, d_mask, d_inv);
+    if (rc) return rc;
+    tf_fold<double>(d_partials, grid, 256, 256, 1.0, d_sums, (double *)(d_partials + (long)grid * 256), (hipStream_t)stream);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
 }

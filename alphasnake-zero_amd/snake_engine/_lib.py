@@ -111,6 +111,7 @@ PROTOTYPES = {
     "snk_stem_conv_f32": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "snk_conv3x3_stats_partials": (C.c_long, [i32, i32, i32]),
     "snk_conv3x3_f16s_stats": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "snk_conv3x3_f16s_igrad_stats": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "snk_stem_wgrad_partials": (C.c_long, [i32, i32, i32]),
     "snk_stem_wgrad_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "snk_bn_train_sums_f64": (i32, [vp, C.c_long, vp, vp, vp, vp]),

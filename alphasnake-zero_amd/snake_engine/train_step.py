@@ -32,6 +32,7 @@ from ._lib import check, lib
 from .net import F16S_WEIGHT_BYTES
 
 _CONV_STATS = os.environ.get("SNK_TRAIN_CONV_STATS", "1") != "0"      # 0: batch-norm sums in a pass of their own (A/B runs)
+_IGRAD_STATS = os.environ.get("SNK_TRAIN_IGRAD_STATS", "1") != "0"    # 0: the batch-norm BACKWARD sums in a pass of their own
 BN_EPS, BN_MOMENTUM, L2_C = 1e-3, 0.99, 1e-5
 ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-7
 C = 128
@@ -186,12 +187,13 @@ class TrainStep:
         return self.q[:3 * n].view(n, 3)
 
     # ---- backward --------------------------------------------------------------------------------------------------
-    def _bn_backward(self, l, n, count, want_res, tail):
+    def _bn_backward(self, l, n, count, want_res, tail, have_sums=False):
         L, st, rows, k = self.L, self._st(), n * self.hw, self._k(l)
         sign = self.mask_override.get(l)                          # tests: a tensor whose sign replaces the recorded ReLU mask
         bits = None if sign is not None else self.relu_mask[l]
-        check(L.snk_bn_train_grad_sums_f64(_p(self.dA), _p(sign), _p(bits), _p(self.y[l]), _p(self.mean[l]), _p(self.inv[l]), rows, 1,
-                                           _p(self.partials), _p(self.sums), st))
+        if not have_sums:                                         # the input-gradient convolution above took them on its way out
+            check(L.snk_bn_train_grad_sums_f64(_p(self.dA), _p(sign), _p(bits), _p(self.y[l]), _p(self.mean[l]), _p(self.inv[l]), rows, 1,
+                                               _p(self.partials), _p(self.sums), st))
         local = self.sums
         if self.dist is not None:
             self.sums_local.copy_(self.sums)
@@ -225,14 +227,22 @@ class TrainStep:
                                            _p(self.gview[kh + 2]), 1, st))
         check(L.snk_head_conv1x1_bwd(_p(self.g1), _p(self.z), _p(self.h_mean_inv), _p(self.h_abc), _p(self.out[-1]), _p(self.view[kh]),
                                      _p(self.dA), _p(self.gview[kh]), _p(self.partials), rows, st))
+        have_sums = False
         for l in range(self.n_layers - 1, 0, -1):
             k, second = self._k(l), l % 2 == 0
-            self._bn_backward(l, n, count, want_res=second, tail=self.tail_dy)         # dA -> dY (+ gres: the shortcut's gradient)
+            self._bn_backward(l, n, count, want_res=second, tail=self.tail_dy, have_sums=have_sums)   # dA -> dY (+ gres: the shortcut's gradient)
             check(L.snk_conv3x3_wgrad_f16s(_p(self.out[l - 1]), _p(self.dY), _p(self.tail_out[l - 1]), _p(self.tail_dy),
                                            _p(self.wg_partials), _p(self.gview[k]), n, self.h, self.w, st))
             check(L.snk_conv3x3_prepare_weights_f16s_train(_p(self.view[k]), _p(self.img_b), _p(self.tail_dy), 1, _p(self.img_f[l]), st))
-            self._conv(self.dY, self.img_b, None if second else self.gres, self.dA, n)  # gradient at out[l - 1]
-        self._bn_backward(0, n, count, want_res=False, tail=None)
+            # gradient at out[l - 1]; its epilogue also takes the two sums the batch-norm backward of layer l - 1 starts with
+            have_sums = _IGRAD_STATS and (l - 1) not in self.mask_override
+            if have_sums:
+                check(L.snk_conv3x3_f16s_igrad_stats(_p(self.dY), _p(self.img_b), _p(None if second else self.gres), _p(self.dA),
+                                                     _p(self.y[l - 1]), _p(self.relu_mask[l - 1]), _p(self.mean[l - 1]), _p(self.inv[l - 1]),
+                                                     _p(self.cv_partials), _p(self.sums), n, self.h, self.w, st))
+            else:
+                self._conv(self.dY, self.img_b, None if second else self.gres, self.dA, n)
+        self._bn_backward(0, n, count, want_res=False, tail=None, have_sums=have_sums)
         check(L.snk_stem_wgrad_f32(_p(self.x0), _p(self.dY), _p(self.sw_partials), _p(self.gview[0]), n, self.h, self.w, st))
 
     # ---- the two kinds of step ----------------------------------------------------------------------------------------

@@ -472,6 +472,14 @@ int snk_stem_conv_f32(const float *d_x, const float *d_w, float *d_out, int n_im
 long snk_conv3x3_stats_partials(int n_images, int height, int width);
 int snk_conv3x3_f16s_stats(const float *d_x, const void *d_wS, float *d_out, const float *d_center, float *d_partials,
                            double *d_sums, int n_images, int height, int width, void *stream);
+/* The INPUT-GRADIENT convolution of the training step with the next batch-norm backward's two sums in its epilogue (what
+ * snk_bn_train_grad_sums_f64 would compute from d_out in a pass of its own): d_out = conv3x3_same(d_x, mirrored kernel image)
+ * (+ d_residual: the shortcut's gradient) = the gradient at the output of the layer below; d_sums[0..127] = sum(g),
+ * d_sums[128..255] = sum(g * (y - mean) * inv), g = d_out where that layer's ReLU bit (d_mask, snk_bn_train_apply's bytes) is
+ * set, d_y its pre-batch-norm output.  d_partials: snk_conv3x3_stats_partials floats.  (alpha_nnet.py:58-59: Keras fit) */
+int snk_conv3x3_f16s_igrad_stats(const float *d_x, const void *d_wS, const float *d_residual, float *d_out, const float *d_y,
+                                 const uint8_t *d_mask, const float *d_mean, const float *d_inv, float *d_partials,
+                                 double *d_sums, int n_images, int height, int width, void *stream);
 long snk_stem_wgrad_partials(int n_images, int height, int width);
 int snk_stem_wgrad_f32(const float *d_x, const float *d_dy, float *d_partials, float *d_dw, int n_images, int height, int width,
                        void *stream);

@@ -318,6 +318,47 @@ def test_steps_at_learning_rate_zero_are_forward_only_and_change_nothing_else(to
     assert min(moved[j] for j in (3, 4)) > 0                # moving statistics did move
 
 
+@pytest.mark.parametrize("n,blocks,hw", [(24, 2, 21), (6, 1, 37), (10, 2, 13)])
+def test_batch_norm_backward_sums_in_the_input_gradient_epilogue_change_nothing_but_rounding(torch_gpu, monkeypatch, n, blocks, hw):
+    """round 5: the input-gradient convolution of layer l also takes the two sums layer l - 1's batch-norm backward starts with
+    (snk_conv3x3_f16s_igrad_stats) instead of snk_bn_train_grad_sums_f64 reading the gradient, the pre-batch-norm tensor and the
+    mask bits again.  The gradient tensor it writes is bit-identical to the plain launch's; the sums agree with the separate pass up
+    to float32 summation order, and so does every parameter gradient of a whole step (alpha_nnet.py:58-59)"""
+    torch = torch_gpu
+    from snake_engine import net, train_step
+    from snake_engine._lib import lib, check
+    rs = np.random.RandomState(n)
+    X = torch.as_tensor(rs.rand(n, hw, hw, 3).astype(np.float32), device="cuda")
+    Y = torch.as_tensor(np.tanh(rs.randn(n, 3)).astype(np.float32), device="cuda")
+    ws = net.glorot_uniform_weights((hw, hw, 3), blocks=blocks, seed=4)
+    grads = {}
+    for fused in (True, False):
+        monkeypatch.setattr(train_step, "_IGRAD_STATS", fused)
+        ts = train_step.TrainStep(ws, (hw, hw, 3), n, "cuda")
+        ts.forward(X, Y, n)
+        ts.backward(Y, n)
+        grads[fused] = ts.gradients()
+    for j in grads[True]:
+        a, b = grads[True][j], grads[False][j]
+        assert np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-12), (j, np.abs(a - b).max(), np.abs(b).max())
+    # the entry point by itself: same gradient tensor, same sums as the separate pass
+    L, st = lib(), torch.cuda.current_stream().cuda_stream
+    l = 2                                              # the launch that produces the gradient at out[1] (no shortcut gradient) ...
+    from snake_engine.train_step import _p
+    dA1, dA2 = torch.empty_like(ts.dA), torch.empty_like(ts.dA)
+    sums = torch.zeros(256, dtype=torch.float64, device="cuda")
+    ref = torch.zeros(256, dtype=torch.float64, device="cuda")
+    for res in (None, ts.gres):                        # ... and with one
+        check(L.snk_conv3x3_bn_f16s(_p(ts.dY), _p(ts.img_b), _p(ts.ones), _p(ts.zeros), _p(res), _p(dA1), n, hw, hw, 0, st))
+        check(L.snk_conv3x3_f16s_igrad_stats(_p(ts.dY), _p(ts.img_b), _p(res), _p(dA2), _p(ts.y[l - 1]), _p(ts.relu_mask[l - 1]),
+                                             _p(ts.mean[l - 1]), _p(ts.inv[l - 1]), _p(ts.cv_partials), _p(sums), n, hw, hw, st))
+        check(L.snk_bn_train_grad_sums_f64(_p(dA1), None, _p(ts.relu_mask[l - 1]), _p(ts.y[l - 1]), _p(ts.mean[l - 1]), _p(ts.inv[l - 1]),
+                                           n * hw * hw, 1, _p(ts.partials), _p(ref), st))
+        assert torch.equal(dA1[:n * hw * hw * 128], dA2[:n * hw * hw * 128])
+        err = (sums - ref).abs().max().item()
+        assert err <= 1e-5 * max(ref.abs().max().item(), 1e-12), (err, ref.abs().max().item())
+
+
 def test_fit_on_the_kernels_tracks_fit_with_library_operators(torch_gpu):
     """utils.trainer_torch.fit on the same rows and shuffle order on this library's kernels and with every operator from
     PyTorch / MIOpen (SNK_TRAIN_CONV=torch).  Adam's first steps move every weight by about lr * sign(gradient), so weights
