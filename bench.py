@@ -182,7 +182,7 @@ def engine_kernel_rooflines(se, n=32768):
     return out
 
 
-def conv_traffic_profile(L, algo, n_rect, flops_per_launch, profiles_dir=None):
+def conv_traffic_profile(L, algo, n_rect, flops_per_launch, profiles_dir=None, board=11):
     """(HBM bytes per average conv launch, profile file) from the newest profiles/*conv*traffic.json that was measured on the
     kernel sources the loaded library was built from and on the same form; (None, reason) otherwise"""
     import glob
@@ -194,12 +194,13 @@ def conv_traffic_profile(L, algo, n_rect, flops_per_launch, profiles_dir=None):
         except (OSError, ValueError):
             continue
         if d.get("source_sha256") == have and d.get("conv_algo") == algo and d.get("rect_layers") == n_rect \
-                and "hbm_bytes_per_state_layer" in d:
+                and d.get("board", 11) == board and "hbm_bytes_per_state_layer" in d:
             cands.append((os.path.getmtime(path), path, d))
     if not cands:
         return None, "no profile under profiles/ was measured on this library's csrc/conv_split.hip (snk_source_hash) in this form"
     _, path, d = max(cands)
-    return d["hbm_bytes_per_state_layer"] * flops_per_launch / (2.0 * 441 * 9 * 128 * 128), os.path.relpath(path, REPO)
+    side = 2 * board - 1
+    return d["hbm_bytes_per_state_layer"] * flops_per_launch / (2.0 * side * side * 9 * 128 * 128), os.path.relpath(path, REPO)
 
 
 def workload_label(board, snakes, blocks, games, breadth, world):
@@ -470,8 +471,8 @@ def main():
         # profile is quoted only for the kernel it was measured on: it names the sha-256 of csrc/conv_split.hip + common.h and the
         # form (algorithm, sub-rectangle layers), and the LOADED library reports the hashes of the sources it was built from
         traffic, traffic_src = None, None
-        if tm and judged:
-            traffic, traffic_src = conv_traffic_profile(se.lib(), algo, qn.n_rect, conv_flops / len(tm))
+        if tm:
+            traffic, traffic_src = conv_traffic_profile(se.lib(), algo, qn.n_rect, conv_flops / len(tm), board=B)
         res = {
             "metric": "self-play env-steps/sec (11x11, 4 snakes, 50 MCTS sims)",
             "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -35,10 +35,16 @@ def sums(d, counter):
 def main():
     fetch_dir, write_dir, log, out_path = sys.argv[1:5]
     note = sys.argv[5] if len(sys.argv) > 5 else ""
-    m = re.search(r"observations (\d+) forwards (\d+) n_rect (\d+) layers (\d+)(?: algo (\w+))?", open(log).read())
+    m = re.search(r"observations (\d+) forwards (\d+) n_rect (\d+) layers (\d+)(?: algo (\w+))?(?: board (\d+))?", open(log).read())
     assert m, "tower_only.py line not found in " + log
     n_obs, fwd, n_rect, layers = (int(m.group(i)) for i in range(1, 5))
     algo = m.group(5) or "f16s"
+    board = int(m.group(6) or 11)
+    side = 2 * board - 1
+    elem = 2 if algo in ("bf16", "f16a") else 4           # bytes of an activation element in HBM
+    # the FULL convolution's algorithmic bytes per state and layer: read x + write the output + the shortcut on every second layer
+    # - the last layer's output, which never goes to HBM (its epilogue feeds the head)
+    algorithmic = side * side * 128 * elem * (2.5 - 1.0 / layers)
     from snake_engine._lib import lib
     L = lib()
     fe, wr = sums(fetch_dir, "FETCH_SIZE"), sums(write_dir, "WRITE_SIZE")
@@ -50,19 +56,18 @@ def main():
     wb = 1024.0 * sum(t for _, t in wr.values())
     per = (rd + wb) / (fwd * n_obs * layers)
     d = {
-        "conv_algo": algo, "rect_layers": n_rect, "tower_layers": layers,
+        "conv_algo": algo, "rect_layers": n_rect, "tower_layers": layers, "board": board,
         "source_sha256": {f: (L.snk_source_hash(f.encode()) or b"").decode() for f in ("conv_split.hip", "common.h")},
         "kernel_symbols": sorted(fe),
-        "workload": f"tools/tower_only.py: {fwd} whole forwards of {n_obs} mid-game 11x11 / 4-snake observations (one chunk)",
+        "workload": f"tools/tower_only.py: {fwd} whole forwards of {n_obs} mid-game {board}x{board} observations (one chunk), {layers} tower layers",
         "states_per_forward": n_obs, "forwards": fwd, "conv_launches_counted": launches,
         "FETCH_SIZE_KB_total": {k: t for k, (_, t) in sorted(fe.items())},
         "WRITE_SIZE_KB_total": {k: t for k, (_, t) in sorted(wr.items())},
         "hbm_read_bytes_per_forward_corrected": rd / fwd, "hbm_write_bytes_per_forward": wb / fwd,
         "hbm_bytes_per_state_layer": per,
-        # the FULL convolution's algorithmic bytes per state and layer: read x (225 792 B) + write the output (225 792 B) + the
-        # shortcut on every second layer (112 896 B on average) - the last layer's output, which never goes to HBM (28 224 B)
-        "algorithmic_bytes_per_state_layer_full_form": 536256.0,
-        "vs_full_form_algorithmic": per / 536256.0,
+        # (11x11 float32 tower: 225 792 + 225 792 + 112 896 - 28 224 = 536 256 B)
+        "algorithmic_bytes_per_state_layer_full_form": algorithmic,
+        "vs_full_form_algorithmic": per / algorithmic,
         "note": ("separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes; FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM' "
                  "(gfx950 reports half the bytes of 16-B-per-lane streaming reads); WRITE_SIZE exact.  " + note).strip(),
     }

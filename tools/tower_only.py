@@ -32,4 +32,4 @@ torch.cuda.synchronize()
 for _ in range(reps):
     q = qn.forward(planes, mask)
 torch.cuda.synchronize()
-print(f"observations {planes.shape[0]} forwards {reps} n_rect {qn.n_rect} layers {2 * qn.blocks} algo {qn.conv_algo}")
+print(f"observations {planes.shape[0]} forwards {reps} n_rect {qn.n_rect} layers {2 * qn.blocks} algo {qn.conv_algo} board {board}")
