@@ -1,5 +1,5 @@
 """k_observe on mid-game boards (32 warm-up ticks of uniform legal moves): planes form and mask + key form, time and HBM
-fraction.  Development tool: observe_time.py [games [planes|mask+key|planes+mask+key]]"""
+fraction.  Development tool: observe_time.py [games [planes|mask+key|planes+mask+key]]      (OBS_BOARD=19: 19x19 / 8 snakes)"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [REPO, os.path.join(REPO, "alphasnake-zero_amd")]
@@ -9,20 +9,23 @@ import snake_engine._lib as _l
 _l.LIB_PATH = os.environ.get("OBS_LIB", _l.LIB_PATH)      # a development build of the library
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 only = sys.argv[2] if len(sys.argv) > 2 else None      # time one form only (for counter passes)
-eng = se.Engine(n, 11, 11, 4, 1, 0.15, seed=1234)
+B = int(os.environ.get("OBS_BOARD", "11"))
+S = 8 if B == 19 else 4
+OBS = 2 * B - 1
+eng = se.Engine(n, B, B, S, 1, 0.15, seed=1234)
 eng.reset()
 g = torch.Generator(device="cuda").manual_seed(1234)
-sub = torch.arange(n, dtype=torch.int32, device="cuda").repeat_interleave(4)
-allp = torch.stack([sub, torch.arange(4, dtype=torch.int32, device="cuda").repeat(n)], dim=1).contiguous()
-blocked = torch.empty((4 * n, 3), dtype=torch.uint8, device="cuda")
+sub = torch.arange(n, dtype=torch.int32, device="cuda").repeat_interleave(S)
+allp = torch.stack([sub, torch.arange(S, dtype=torch.int32, device="cuda").repeat(n)], dim=1).contiguous()
+blocked = torch.empty((S * n, 3), dtype=torch.uint8, device="cuda")
 for _ in range(32):
-    eng.observe(allp, 4 * n, None, blocked, None)
-    r = torch.rand((4 * n, 3), device="cuda", generator=g) - 2.0 * blocked.float()
+    eng.observe(allp, S * n, None, blocked, None)
+    r = torch.rand((S * n, 3), device="cuda", generator=g) - 2.0 * blocked.float()
     mv = torch.where(blocked.bool().all(dim=1), torch.ones((), dtype=torch.int64, device="cuda"), r.argmax(dim=1))
-    eng.step(mv.to(torch.uint8).reshape(n, 4).contiguous())
+    eng.step(mv.to(torch.uint8).reshape(n, S).contiguous())
 pairs = torch.nonzero(eng.alive()).to(torch.int32).contiguous()
 m = pairs.shape[0]
-planes = torch.empty((m, 21, 21, 3), device="cuda")
+planes = torch.empty((m, OBS, OBS, 3), device="cuda")
 mask = torch.empty((m, 3), dtype=torch.uint8, device="cuda")
 key = torch.empty((m, 2), dtype=torch.int64, device="cuda")
 G = eng.slot_bytes
@@ -34,9 +37,9 @@ def timed(fn, iters=10):
         a.record(); fn(); b.record(); torch.cuda.synchronize()
         ts.append(a.elapsed_time(b) * 1e-3)
     return float(np.median(ts))
-for name, fn, byts in (("planes", lambda: eng.observe(pairs, m, planes, None, None), m * (G + 5292)),
+for name, fn, byts in (("planes", lambda: eng.observe(pairs, m, planes, None, None), m * (G + OBS * OBS * 12)),
                        ("mask+key", lambda: eng.observe(pairs, m, None, mask, key), m * (G + 19)),
-                       ("planes+mask+key", lambda: eng.observe(pairs, m, planes, mask, key), m * (G + 5292 + 19))):
+                       ("planes+mask+key", lambda: eng.observe(pairs, m, planes, mask, key), m * (G + OBS * OBS * 12 + 19))):
     if only and name != only:
         continue
     t = timed(fn)
