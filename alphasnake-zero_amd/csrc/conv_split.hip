@@ -131,6 +131,14 @@ __device__ unsigned long long hs_stamp_buf[16384 * 8];
 // where the block runs: HW_ID (hwreg 4: wave slot, SIMD, CU, SH, SE, workgroup slot) | XCC_ID (hwreg 20) << 32
 #define HS_STAMP_HWID(k) if (tid == 0 && blockIdx.x < 16384) hs_stamp_buf[blockIdx.x * 8 + (k)] = \
         (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32;
+// per-tap stamps of wave 0 of the first 2 048 blocks: [block][chunk 0..7][tap 0..8 + chunk end]
+__device__ unsigned long long hs_tap_buf[2048 * 8 * 10];
+#define HS_TSTAMP(c_, s_) if (tid == 0 && blockIdx.x < 2048 && (c_) < 8) hs_tap_buf[(blockIdx.x * 8 + (c_)) * 10 + (s_)] = __builtin_amdgcn_s_memtime();
+extern "C" int snk_dbg_conv_tap_stamps(unsigned long long *h_out)
+{
+    SNK_CHECK_HIP(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(hs_tap_buf), sizeof(unsigned long long) * 2048 * 8 * 10));
+    return 0;
+}
 extern "C" int snk_dbg_conv_stamps(unsigned long long *h_out, int n_blocks)
 {
     SNK_CHECK_HIP(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(hs_stamp_buf), (size_t)n_blocks * 8 * sizeof(unsigned long long)));
@@ -140,6 +148,7 @@ extern "C" int snk_dbg_conv_stamps(unsigned long long *h_out, int n_blocks)
 #define HS_STAMP(k)
 #define HS_STAMP_REAL(k)
 #define HS_STAMP_HWID(k)
+#define HS_TSTAMP(c_, s_)
 #endif
 
 // NI: M tiles (of 32 GEMM rows) per block, <= 8.  MODE fixes the epilogue's options at compile time (no branches per row):
@@ -331,6 +340,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
                 if (t2_ < 9 * NI) { nh = HS_LDS(HS_AOFF(t2_)); if (TWO) nl = HS_LDS(HS_AOFF(t2_) + 32); } \
                 __builtin_amdgcn_sched_barrier(0);                                              \
                 if (i == 0) {                                                                   \
+                    HS_TSTAMP(c, (s))                                                           \
                     if (MORE || (s) + AHEAD < 9) { HS_LOADB(((s) + AHEAD) % RING, gnext + (s)); } \
                     if ((s) == HS_XLOAD_TAP && MORE) { HS_LOAD(c + 1) }                         \
                 }                                                                               \

@@ -72,3 +72,15 @@ if hw.any():
     if len(offs):
         hist = np.histogram(offs, bins=10, range=(0, 1))[0]
         print(f"  start of a block relative to the life of the block it joined on its CU (0 = together, 0.5 = half a life later): deciles {hist.tolist()}")
+if hasattr(L, "snk_dbg_conv_tap_stamps") and os.environ.get("A16_TAPS", "1") != "0":
+    # wave 0's clock at the start of every tap of every chunk (and at the chunk's end, before its barrier): where a chunk's time goes
+    L.snk_dbg_conv_tap_stamps.argtypes = [C.c_void_p]
+    tb = np.zeros((2048, 8, 10), np.uint64)
+    assert L.snk_dbg_conv_tap_stamps(tb.ctypes.data) == 0
+    tb = tb.astype(np.int64)
+    nchunk = int((tb[0, :, 0] > 0).sum())
+    ok = tb[:, 0, 0] > 0
+    d = np.diff(tb[ok][:, :nchunk, :], axis=2)                      # [block][chunk][tap 0..8 duration]
+    print(f"  per tap of wave 0 (mean cycles over {int(ok.sum())} blocks; a tap = NI tiles x {2 if nchunk == 4 else 3} MFMAs x 32 cycles of matrix pipe when alone):")
+    for c_ in range(nchunk):
+        print(f"    chunk {c_}: " + " ".join(f"{v:6.0f}" for v in d[:, c_, :].mean(axis=0)) + f"   sum {d[:, c_, :].sum(axis=1).mean():7.0f}")
