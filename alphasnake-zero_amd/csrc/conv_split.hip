@@ -122,6 +122,11 @@ struct ConvHsArgs {
     const float *g_y;          // that layer's pre-batch-norm output [n][Hd][Wd][128]
     const unsigned char *g_mask;   // its ReLU bits, one byte per quad of channels (csrc/train.hip)
     const float *g_inv;        // its 1 / sigma per channel (center = its batch mean)
+    // MODE 6 / 7 (training step, a block's first layer whose batch norm + ReLU is never written out, see MODE 6 below): the
+    // producer's batch-norm scale and shift per channel -- MODE 6 applies relu(x * aff_scale + aff_shift) to every staged input,
+    // MODE 7 takes the ReLU decision of g_y from the same expression instead of from mask bytes
+    const float *aff_scale, *aff_shift;
+    float *amax_part;          // MODE 4 (optional): [gridDim.x][128] largest |out - center| per channel over the block's pixels
 };
 
 #ifdef HS_STAMPS       // development build only (tools/conv_stamps.py): s_memtime at the phase boundaries of every block
@@ -158,6 +163,12 @@ extern "C" int snk_dbg_conv_stamps(unsigned long long *h_out, int n_blocks)
 //   5 the training step's input gradient: the bare convolution (+ the shortcut's gradient as residual) = the gradient at the previous
 //     layer's output, plus the two per-channel sums that layer's batch-norm backward needs -- sum(g), sum(g xhat), g = the gradient
 //     where the layer's ReLU let the value through -- taken from the values on their way out (snk_bn_train_grad_sums_f64's pass saved)
+//   6 MODE 4 whose INPUT is the previous layer's pre-batch-norm output: relu(x * aff_scale + aff_shift) -- that layer's batch norm
+//     and ReLU, the very expression of k_bn_apply (csrc/train.hip) -- is applied to every value on its way into LDS, so the
+//     activation between the two convolutions of a residual block is never written to HBM nor read back (a pass over two
+//     462 MB tensors less per block and step); the zero border stays zero (it is the padding of the ACTIVATION)
+//   7 MODE 5 for such a layer below: its ReLU decision is y * aff_scale + aff_shift > 0, recomputed from the g_y values the sums
+//     read anyway (no mask bytes exist for it)
 #define hs_dpp(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
 // SPLIT = false: the reduced-precision form for BASELINE configs[4] ("bf16 MFMA conv"): the same kernel with the hi parts
 //   only, one MFMA per product instead of three (f16 operands: 11 significand bits against bf16's 8, float32 accumulate).
@@ -179,7 +190,9 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     static_assert(IO16 == 0 || !SPLIT, "f16 activations only exist in the reduced-precision form");
     static_assert(!BF || (IO16 & 1), "the bf16 form reads bf16 activations");
     constexpr bool IN16 = (IO16 & 1) != 0, OUT16 = (IO16 & 2) != 0;
-    constexpr bool STATS = MODE == 4, GSTATS = MODE == 5, BARE = STATS || GSTATS;
+    constexpr bool STATS = MODE == 4 || MODE == 6, GSTATS = MODE == 5 || MODE == 7, BARE = STATS || GSTATS;
+    constexpr bool AFF = MODE == 6, GAFF = MODE == 7;
+    static_assert(!(AFF || GAFF) || (SPLIT && IO16 == 0 && !RECT), "the deferred batch norm exists in the training step's float32 form only");
     constexpr bool K32 = IN16;
     constexpr int RING = K32 ? HS_RING16 : HS_RING, AHEAD = K32 ? HS_AHEAD16 : HS_AHEAD;      // B-fragment register ring: slots (a divisor of 9), taps ahead
     constexpr bool TWO = SPLIT || K32;                     // two A fragments / two B fragments per (tap, M tile)
@@ -242,6 +255,10 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     f16x8 st8[K32 ? NST : 1];                              // the 16-bit frame's items: eight channels, staged as they are
     f16x4 hi_t;
     float4 d_t;
+    float4 asc = make_float4(1.f, 1.f, 1.f, 1.f), ash = make_float4(0.f, 0.f, 0.f, 0.f);    // MODE 6: the producer's scale / shift of the
+    //   four channels this thread stages in the chunk being split; all 128 of each sit in LDS behind the two staging buffers
+#define HS_AFF_READ(c) { asc = *(const float4 *)(smem + 2 * BUFB + (16 * (c) + 4 * (tid & 3)) * 4);      \
+                         ash = *(const float4 *)(smem + 2 * BUFB + 512 + (16 * (c) + 4 * (tid & 3)) * 4); }
     float amax = 0.f;                                      // largest |scaled input| this thread staged: 65504 = something was clamped
 #define HS_LOAD(c) _Pragma("unroll") for (int k_ = 0; k_ < NST; ++k_) {                         \
         if (K32) st8[k_] = *(const f16x8 *)((RECT ? gp16[k_] : xrow16 + gof[k_]) + KC * (c));   \
@@ -253,6 +270,10 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     if (K32) { } else if (IN16) { hi_t = st16[kk]; } else                                       \
     {                                                                                           \
         float4 v_ = st[kk];                                                                     \
+        if (AFF) {          /* the producer's batch norm + ReLU, as k_bn_apply computes it (multiply, then add: no fma) */ \
+            v_.x = fmaxf(v_.x * asc.x + ash.x, 0.f); v_.y = fmaxf(v_.y * asc.y + ash.y, 0.f);   \
+            v_.z = fmaxf(v_.z * asc.z + ash.z, 0.f); v_.w = fmaxf(v_.w * asc.w + ash.w, 0.f);   \
+        }                                                                                       \
         v_.x *= xs; v_.y *= xs; v_.z *= xs; v_.w *= xs;                                         \
         v_.x = __builtin_amdgcn_fmed3f(v_.x, -65504.f, 65504.f); v_.y = __builtin_amdgcn_fmed3f(v_.y, -65504.f, 65504.f); \
         v_.z = __builtin_amdgcn_fmed3f(v_.z, -65504.f, 65504.f); v_.w = __builtin_amdgcn_fmed3f(v_.w, -65504.f, 65504.f); \
@@ -306,12 +327,14 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
             }
     } else
     for (int o = tid * 16; o < 2 * BUFB; o += 256 * 16) *(uint4 *)(smem + o) = make_uint4(0u, 0u, 0u, 0u);   // borders stay zero
+    if (AFF && tid < 64) *(float4 *)(smem + 2 * BUFB + 16 * tid) = *(const float4 *)((tid < 32 ? p.aff_scale : p.aff_shift - HS_C) + 4 * tid);
     f32x16 acc[NI];
 #pragma unroll
     for (int a = 0; a < NI; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
     __syncthreads();
+    if (AFF) HS_AFF_READ(0)
 #pragma unroll
     for (int k = 0; k < NST; ++k) { HS_SPLIT_A(k) HS_SPLIT_B(k, 0) }
     __syncthreads();
@@ -346,6 +369,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
                 }                                                                               \
                 {                                                                               \
                     const int tl_ = (s) * NI + i - (9 * NI - 2 * NST);                          \
+                    if (AFF && MORE && 9 * NI >= 2 * NST && tl_ == -1) HS_AFF_READ(c + 1)       \
                     if (MORE && 9 * NI >= 2 * NST && tl_ >= 0) {                                \
                         if ((tl_ & 1) == 0) { HS_SPLIT_A((tl_ < 0 ? 0 : tl_ >> 1)) }            \
                         else { HS_SPLIT_B((tl_ < 0 ? 0 : tl_ >> 1), wb) }                       \
@@ -372,6 +396,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
         HS_TAP(0, MORE) HS_TAP(1, MORE) HS_TAP(2, MORE) HS_TAP(3, MORE) HS_TAP(4, MORE)         \
         HS_TAP(5, MORE) HS_TAP(6, MORE) HS_TAP(7, MORE) HS_TAP(8, MORE)                         \
         if (MORE && 9 * NI < 2 * NST) {                 /* too few regions to spread the split over: do it here */ \
+            if (AFF) HS_AFF_READ(c + 1)                                                         \
             _Pragma("unroll") for (int k = 0; k < NST; ++k) { HS_SPLIT_A(k) HS_SPLIT_B(k, wb) } \
         }                                                                                       \
         __syncthreads();                                                                        \
@@ -408,6 +433,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
 #undef HS_SPLIT_A
 #undef HS_SPLIT_B
 #undef HS_LOADB
+#undef HS_AFF_READ
 #undef HS_LDS
 #undef HS_MFMA
 
@@ -519,6 +545,8 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     if (BARE && p.center) cen4 = *(const float4 *)(p.center + 4 * cq);
     float4 iv4 = make_float4(1.f, 1.f, 1.f, 1.f);
     if (GSTATS) iv4 = *(const float4 *)(p.g_inv + 4 * cq);
+    float4 gsc = cen4, gsh = cen4, st_m = cen4;
+    if (GAFF) { gsc = *(const float4 *)(p.aff_scale + 4 * cq); gsh = *(const float4 *)(p.aff_shift + 4 * cq); }
     float *Ms = (float *)smem;                                      // [2][64 rows][HS_MLD]
     const long obase = (long)img * HWc * HS_C + 4 * cq;
     float4 wh = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -581,9 +609,15 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
             v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
             if (GSTATS && off[pass & 1][j] >= 0) {
                 const long e_ = obase + off[pass & 1][j];
-                const unsigned mb_ = p.g_mask[e_ >> 2];
                 const float4 y_ = *(const float4 *)(p.g_y + e_);
-                const float gx = (mb_ & 1u) ? v.x : 0.f, gy = (mb_ & 2u) ? v.y : 0.f, gz = (mb_ & 4u) ? v.z : 0.f, gw = (mb_ & 8u) ? v.w : 0.f;
+                float gx, gy, gz, gw;
+                if (GAFF) {                  // the layer's output was never written: its sign is that of k_bn_apply's expression
+                    gx = y_.x * gsc.x + gsh.x > 0.f ? v.x : 0.f; gy = y_.y * gsc.y + gsh.y > 0.f ? v.y : 0.f;
+                    gz = y_.z * gsc.z + gsh.z > 0.f ? v.z : 0.f; gw = y_.w * gsc.w + gsh.w > 0.f ? v.w : 0.f;
+                } else {
+                    const unsigned mb_ = p.g_mask[e_ >> 2];
+                    gx = (mb_ & 1u) ? v.x : 0.f; gy = (mb_ & 2u) ? v.y : 0.f; gz = (mb_ & 4u) ? v.z : 0.f; gw = (mb_ & 8u) ? v.w : 0.f;
+                }
                 st_s.x += gx; st_s.y += gy; st_s.z += gz; st_s.w += gw;
                 st_q.x += gx * ((y_.x - cen4.x) * iv4.x); st_q.y += gy * ((y_.y - cen4.y) * iv4.y);
                 st_q.z += gz * ((y_.z - cen4.z) * iv4.z); st_q.w += gw * ((y_.w - cen4.w) * iv4.w);
@@ -592,6 +626,10 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
                 const float ex = v.x - cen4.x, ey = v.y - cen4.y, ez = v.z - cen4.z, ew = v.w - cen4.w;
                 st_s.x += ex; st_s.y += ey; st_s.z += ez; st_s.w += ew;
                 st_q.x += ex * ex; st_q.y += ey * ey; st_q.z += ez * ez; st_q.w += ew * ew;
+                if (MODE == 4) {             // the range of what this layer's batch norm can make of it (snk_bn_train_finalize_range)
+                    st_m.x = fmaxf(st_m.x, fabsf(ex)); st_m.y = fmaxf(st_m.y, fabsf(ey));
+                    st_m.z = fmaxf(st_m.z, fabsf(ez)); st_m.w = fmaxf(st_m.w, fabsf(ew));
+                }
             }
             if (has_out && off[pass & 1][j] >= 0) {
                 if (OUT16) {
@@ -614,10 +652,20 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
 #undef HS_EPI_PREP
     if (BARE) {                            // the eight row lanes' sums of a channel quad are added through LDS, in a fixed order
         __syncthreads();
-        float4 *R = (float4 *)smem;        // [2][8][32]
+        float4 *R = (float4 *)smem;        // [2 (3)][8][32]
         R[rr0 * 32 + cq] = st_s;
         R[(8 + rr0) * 32 + cq] = st_q;
+        if (MODE == 4) R[(16 + rr0) * 32 + cq] = st_m;
         __syncthreads();
+        if (MODE == 4 && rr0 == 2 && p.amax_part) {
+            float4 t = R[16 * 32 + cq];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) {
+                const float4 u = R[(16 + r) * 32 + cq];
+                t.x = fmaxf(t.x, u.x); t.y = fmaxf(t.y, u.y); t.z = fmaxf(t.z, u.z); t.w = fmaxf(t.w, u.w);
+            }
+            *(float4 *)(p.amax_part + (size_t)blockIdx.x * HS_C + 4 * cq) = t;
+        }
         if (rr0 < 2) {
             float4 t = R[(8 * rr0) * 32 + cq];
 #pragma unroll
@@ -840,7 +888,8 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
                             const float *d_residual, float *d_out, const float *d_w1x1, float s1, float b1, float *d_h1,
                             int n_images, int height, int width, int relu, bool split, void *stream, int io16 = 0,
                             const float *d_center = nullptr, float *d_stat_part = nullptr, int *grid_out = nullptr, bool bf = false,
-                            const float *d_gy = nullptr, const unsigned char *d_gmask = nullptr, const float *d_ginv = nullptr)
+                            const float *d_gy = nullptr, const unsigned char *d_gmask = nullptr, const float *d_ginv = nullptr,
+                            const float *d_aff_scale = nullptr, const float *d_aff_shift = nullptr, float *d_amax_part = nullptr)
 {
     SNK_REQUIRE(n_images >= 0 && height >= 1 && width >= 3, "snk_conv3x3_bn_f16s: bad shape %d x %d x %d", n_images, height, width);
     SNK_REQUIRE(d_out != d_x, "snk_conv3x3_bn_f16s: in-place convolution is not possible (blocks read their neighbours' input rows)");
@@ -873,10 +922,27 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
     SNK_REQUIRE((long)n_images * n_blk < (1l << 31) && (long)HW * HS_C < (1l << 31), "snk_conv3x3_bn_f16s: batch too large");
     ConvHsArgs a = {d_x, (const f16x8 *)d_wS, (const float *)((const _Float16 *)d_wS + HS_WS_ELEMS), d_scale, d_shift,
                     d_residual, d_out, d_w1x1, d_h1, s1, b1, height, width, n_blk, tiles_base, tiles_rem, relu, (n_images / 8) * 8,
-                    d_center, d_stat_part, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, d_gy, d_gmask, d_ginv};
+                    d_center, d_stat_part, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, d_gy, d_gmask, d_ginv,
+                    d_aff_scale, d_aff_shift, d_amax_part};
     const int n_mt = tiles_max, grid = n_images * n_blk;
     hipStream_t st = (hipStream_t)stream;
     if (grid_out) *grid_out = grid;
+#define HS_LAUNCH_TRAIN(MODE_)                                                                   \
+        switch (n_mt) {                                                                         \
+        case 1: k_conv3x3_f16s<1, MODE_><<<grid, 256, 0, st>>>(a); break;                       \
+        case 2: k_conv3x3_f16s<2, MODE_><<<grid, 256, 0, st>>>(a); break;                       \
+        case 3: k_conv3x3_f16s<3, MODE_><<<grid, 256, 0, st>>>(a); break;                       \
+        case 4: k_conv3x3_f16s<4, MODE_><<<grid, 256, 0, st>>>(a); break;                       \
+        case 5: k_conv3x3_f16s<5, MODE_><<<grid, 256, 0, st>>>(a); break;                       \
+        case 6: k_conv3x3_f16s<6, MODE_><<<grid, 256, 0, st>>>(a); break;                       \
+        case 7: k_conv3x3_f16s<7, MODE_><<<grid, 256, 0, st>>>(a); break;                       \
+        default: k_conv3x3_f16s<8, MODE_><<<grid, 256, 0, st>>>(a); break;                      \
+        }                                                                                       \
+        SNK_CHECK_HIP(hipGetLastError());                                                       \
+        return 0;
+    if (d_stat_part && a.g_y && d_aff_scale) { HS_LAUNCH_TRAIN(7) }    // ... of a layer whose ReLU decision is recomputed from its scale / shift
+    if (d_stat_part && d_aff_scale) { HS_LAUNCH_TRAIN(6) }             // forward pass, the producer's batch norm + ReLU applied on the way in
+#undef HS_LAUNCH_TRAIN
     if (d_stat_part && a.g_y) {          // the training step's input gradient + the previous layer's batch-norm backward sums
         switch (n_mt) {
         case 1: k_conv3x3_f16s<1, 5><<<grid, 256, 0, st>>>(a); break;
@@ -1244,7 +1310,23 @@ extern "C" long snk_conv3x3_stats_partials(int n_images, int height, int width)
 {
     if (n_images <= 0 || height < 1 || width < 3) return -1;
     const long T = ((long)height * width + 31) / 32;
-    return (long)n_images * T * 256 + TF_SCRATCH_FLOATS(256);              // at most one block per M tile
+    return (long)n_images * T * 384 + TF_SCRATCH_FLOATS(256);              // at most one block per M tile: 2 x 128 sums + 128 maxima each
+}
+
+// per-channel maximum over the blocks' maxima: [n_blocks][128] -> [128]
+__global__ __launch_bounds__(256) void k_amax_fold128(const float *__restrict__ part, int n_blocks, float *__restrict__ amax)
+{
+    __shared__ float sh[32][8];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3, c = 8 * blockIdx.x + cl;
+    float m = 0.f;
+    for (int r = rl; r < n_blocks; r += 32) m = fmaxf(m, part[(size_t)r * HS_C + c]);
+    sh[rl][cl] = m;
+    __syncthreads();
+    if (rl == 0) {
+#pragma unroll
+        for (int r = 1; r < 32; ++r) m = fmaxf(m, sh[r][cl]);
+        amax[c] = m;
+    }
 }
 
 extern "C" int snk_conv3x3_f16s_stats(const float *d_x, const void *d_wS, float *d_out, const float *d_center, float *d_partials,
@@ -1256,6 +1338,34 @@ extern "C" int snk_conv3x3_f16s_stats(const float *d_x, const void *d_wS, float 
                                     true, stream, 0, d_center, d_partials, &grid);
     if (rc) return rc;
     tf_fold<double>(d_partials, grid, 256, 256, 1.0, d_sums, (double *)(d_partials + (long)grid * 256), (hipStream_t)stream);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// The same with the two options of the deferred batch norm (snake_engine/train_step.py: the activation between the two convolutions
+// of a residual block is never written out):
+//   d_in_scale / d_in_shift (both or neither): d_x is the PRE-batch-norm output of the layer below and every value is taken as
+//     relu(x * in_scale[c] + in_shift[c]) on its way into the kernel -- bit for bit what snk_bn_train_apply(relu = 1, no residual)
+//     would have written; the input scale in d_wS's tail must cover that range (snk_bn_train_finalize_range);
+//   d_amax (or NULL): 128 floats, the largest |out - center| per channel -- what snk_bn_train_finalize_range turns into the
+//     range of this layer's own batch norm + ReLU output without a pass over it.
+extern "C" int snk_conv3x3_f16s_stats_deferred(const float *d_x, const void *d_wS, float *d_out, const float *d_center,
+                                               const float *d_in_scale, const float *d_in_shift, float *d_amax, float *d_partials,
+                                               double *d_sums, int n_images, int height, int width, void *stream)
+{
+    SNK_REQUIRE(d_x && d_wS && d_out && d_partials && d_sums && n_images > 0 && !d_in_scale == !d_in_shift,
+                "snk_conv3x3_f16s_stats_deferred: bad argument");
+    SNK_REQUIRE(!d_amax || !d_in_scale, "snk_conv3x3_f16s_stats_deferred: the maxima come with the plain input form only");
+    // the launch's grid is known only inside: the maxima sit behind the largest sums + fold scratch the buffer is sized for
+    const long T = ((long)height * width + 31) / 32;
+    float *amax_part = d_amax ? d_partials + (long)n_images * T * 256 + TF_SCRATCH_FLOATS(256) : nullptr;
+    int grid = 0;
+    const int rc = conv_f16s_launch(d_x, d_wS, nullptr, nullptr, nullptr, d_out, nullptr, 0.f, 0.f, nullptr, n_images, height, width, 0,
+                                    true, stream, 0, d_center, d_partials, &grid, false, nullptr, nullptr, nullptr, d_in_scale, d_in_shift,
+                                    d_in_scale ? nullptr : amax_part);
+    if (rc) return rc;
+    tf_fold<double>(d_partials, grid, 256, 256, 1.0, d_sums, (double *)(d_partials + (long)grid * 256), (hipStream_t)stream);
+    if (d_amax) k_amax_fold128<<<HS_C / 8, 256, 0, (hipStream_t)stream>>>(amax_part, grid, d_amax);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1321,6 +1431,24 @@ extern "C" int snk_conv3x3_f16s_igrad_stats(const float *d_x, const void *d_wS, 
     int grid = 0;
     const int rc = conv_f16s_launch(d_x, d_wS, nullptr, nullptr, d_residual, d_out, nullptr, 0.f, 0.f, nullptr, n_images, height, width, 0,
                                     true, stream, 0, d_mean, d_partials, &grid, false, d_y, d_mask, d_inv);
+    if (rc) return rc;
+    tf_fold<double>(d_partials, grid, 256, 256, 1.0, d_sums, (double *)(d_partials + (long)grid * 256), (hipStream_t)stream);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// The same for a layer below whose batch norm + ReLU output was never written (deferred): its ReLU decision is
+// d_y * d_scale[c] + d_shift[c] > 0 -- the sign of what snk_bn_train_apply would have written -- instead of mask bytes.
+extern "C" int snk_conv3x3_f16s_igrad_stats_deferred(const float *d_x, const void *d_wS, const float *d_residual, float *d_out,
+                                                     const float *d_y, const float *d_scale, const float *d_shift, const float *d_mean,
+                                                     const float *d_inv, float *d_partials, double *d_sums, int n_images, int height,
+                                                     int width, void *stream)
+{
+    SNK_REQUIRE(d_x && d_wS && d_out && d_y && d_scale && d_shift && d_mean && d_inv && d_partials && d_sums && n_images > 0,
+                "snk_conv3x3_f16s_igrad_stats_deferred: bad argument");
+    int grid = 0;
+    const int rc = conv_f16s_launch(d_x, d_wS, nullptr, nullptr, d_residual, d_out, nullptr, 0.f, 0.f, nullptr, n_images, height, width, 0,
+                                    true, stream, 0, d_mean, d_partials, &grid, false, d_y, nullptr, d_inv, d_scale, d_shift);
     if (rc) return rc;
     tf_fold<double>(d_partials, grid, 256, 256, 1.0, d_sums, (double *)(d_partials + (long)grid * 256), (hipStream_t)stream);
     SNK_CHECK_HIP(hipGetLastError());

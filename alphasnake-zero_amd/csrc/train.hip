@@ -121,12 +121,17 @@ __global__ __launch_bounds__(TR_THREADS) void k_bn_apply(const float *__restrict
 
 // g = dout where the layer's output is positive (ReLU) or everywhere (no ReLU); xhat = (y - mean) * inv
 #define TR_G(dv, ov) (relu ? make_float4(ov.x > 0.f ? dv.x : 0.f, ov.y > 0.f ? dv.y : 0.f, ov.z > 0.f ? dv.z : 0.f, ov.w > 0.f ? dv.w : 0.f) : dv)
-// the ReLU decision of a quad of channels: from the mask byte k_bn_apply wrote, or from the sign of a tensor
-#define TR_MASKED(dv, o)                                                                        \
+// the ReLU decision of a quad of channels: from the mask byte k_bn_apply wrote, from the sign of a tensor, or (msc: the layer's
+// output was never written, its batch norm + ReLU being deferred into the next convolution's staging) recomputed from the
+// pre-batch-norm value yv with k_bn_apply's own expression
+#define TR_MASKED(dv, o, yv)                                                                    \
     ({                                                                                          \
         float4 g_ = dv;                                                                         \
         if (relu) {                                                                             \
-            if (mask) {                                                                         \
+            if (msc) {                                                                          \
+                g_ = make_float4(yv.x * ms4.x + mh4.x > 0.f ? dv.x : 0.f, yv.y * ms4.y + mh4.y > 0.f ? dv.y : 0.f, \
+                                 yv.z * ms4.z + mh4.z > 0.f ? dv.z : 0.f, yv.w * ms4.w + mh4.w > 0.f ? dv.w : 0.f); \
+            } else if (mask) {                                                                         \
                 const unsigned m_ = mask[(o) >> 2];                                             \
                 g_ = make_float4((m_ & 1u) ? dv.x : 0.f, (m_ & 2u) ? dv.y : 0.f, (m_ & 4u) ? dv.z : 0.f, (m_ & 8u) ? dv.w : 0.f); \
             } else {                                                                            \
@@ -141,16 +146,19 @@ __global__ __launch_bounds__(TR_THREADS) void k_bn_grad_sums(const float *__rest
                                                             const uint8_t *__restrict__ mask,
                                                             const float *__restrict__ y, const float *__restrict__ mean,
                                                             const float *__restrict__ inv, long rows, int relu,
-                                                            float *__restrict__ part)
+                                                            float *__restrict__ part, const float *__restrict__ msc = nullptr,
+                                                            const float *__restrict__ msh = nullptr)
 {
     const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const float4 mu = *(const float4 *)(mean + 4 * cq), iv = *(const float4 *)(inv + 4 * cq);
+    float4 ms4 = mu, mh4 = mu;
+    if (msc) { ms4 = *(const float4 *)(msc + 4 * cq); mh4 = *(const float4 *)(msh + 4 * cq); }
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
     for (long r = (long)blockIdx.x * TR_ROWLANES + rl; r < rows; r += (long)gridDim.x * TR_ROWLANES) {
         const long o = r * TR_C + 4 * cq;
         const float4 dv = *(const float4 *)(dout + o);
-        const float4 g = TR_MASKED(dv, o);
         const float4 v = *(const float4 *)(y + o);
+        const float4 g = TR_MASKED(dv, o, v);
         s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
         q.x += g.x * ((v.x - mu.x) * iv.x); q.y += g.y * ((v.y - mu.y) * iv.y);
         q.z += g.z * ((v.z - mu.z) * iv.z); q.w += g.w * ((v.w - mu.w) * iv.w);
@@ -165,17 +173,20 @@ __global__ __launch_bounds__(TR_THREADS) void k_bn_grad_apply(const float *__res
                                                              const float *__restrict__ inv, const float *__restrict__ a,
                                                              const float *__restrict__ b, const float *__restrict__ c,
                                                              float *__restrict__ dx, float *__restrict__ g_out, long rows,
-                                                             int relu, float *__restrict__ amax_part)
+                                                             int relu, float *__restrict__ amax_part,
+                                                             const float *__restrict__ msc = nullptr, const float *__restrict__ msh = nullptr)
 {
     const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
     float am = 0.f;
     const float4 mu = *(const float4 *)(mean + 4 * cq), iv = *(const float4 *)(inv + 4 * cq);
+    float4 ms4 = mu, mh4 = mu;
+    if (msc) { ms4 = *(const float4 *)(msc + 4 * cq); mh4 = *(const float4 *)(msh + 4 * cq); }
     const float4 a4 = *(const float4 *)(a + 4 * cq), b4 = *(const float4 *)(b + 4 * cq), c4 = *(const float4 *)(c + 4 * cq);
     for (long r = (long)blockIdx.x * TR_ROWLANES + rl; r < rows; r += (long)gridDim.x * TR_ROWLANES) {
         const long o = r * TR_C + 4 * cq;
         const float4 dv = *(const float4 *)(dout + o);
-        const float4 g = TR_MASKED(dv, o);
         const float4 v = *(const float4 *)(y + o);
+        const float4 g = TR_MASKED(dv, o, v);
         float4 d;
         d.x = a4.x * (g.x - b4.x - ((v.x - mu.x) * iv.x) * c4.x);
         d.y = a4.y * (g.y - b4.y - ((v.y - mu.y) * iv.y) * c4.y);
@@ -231,6 +242,36 @@ extern "C" int snk_bn_train_grad_apply(const float *d_dout, const float *d_out, 
     const int grid = tr_grid(rows);
     k_bn_grad_apply<<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_dout, d_out, d_relu_mask, d_y, d_mean, d_inv, d_a, d_b, d_c, d_dx, d_g, rows,
                                                                    relu, d_dx_scale_tail ? d_partials : nullptr);
+    if (d_dx_scale_tail) k_amax_scale<<<1, 1024, 0, (hipStream_t)stream>>>(d_partials, grid, d_dx_scale_tail);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// the two backward kernels for a layer whose batch norm + ReLU output was never written (deferred): the ReLU decision is
+// d_y * d_scale[c] + d_shift[c] > 0, the sign of what snk_bn_train_apply(relu = 1, no residual) would have written
+extern "C" int snk_bn_train_grad_sums_f64_deferred(const float *d_dout, const float *d_y, const float *d_scale, const float *d_shift,
+                                                   const float *d_mean, const float *d_inv, long rows, float *d_partials, double *d_sums,
+                                                   void *stream)
+{
+    SNK_REQUIRE(d_dout && d_y && d_scale && d_shift && d_mean && d_inv && d_partials && d_sums && rows > 0,
+                "snk_bn_train_grad_sums_f64_deferred: bad argument");
+    const int grid = tr_grid(rows);
+    k_bn_grad_sums<<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_dout, nullptr, nullptr, d_y, d_mean, d_inv, rows, 1, d_partials, d_scale, d_shift);
+    tf_fold<double>(d_partials, grid, 2 * TR_C, 2 * TR_C, 1.0, d_sums, (double *)(d_partials + 2048 * 2 * TR_C), (hipStream_t)stream);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int snk_bn_train_grad_apply_deferred(const float *d_dout, const float *d_y, const float *d_scale, const float *d_shift,
+                                                const float *d_mean, const float *d_inv, const float *d_a, const float *d_b,
+                                                const float *d_c, float *d_dx, float *d_g, long rows, float *d_partials,
+                                                float *d_dx_scale_tail, void *stream)
+{
+    SNK_REQUIRE(d_dout && d_y && d_scale && d_shift && d_mean && d_inv && d_a && d_b && d_c && d_dx && rows > 0 &&
+                (!d_dx_scale_tail || d_partials), "snk_bn_train_grad_apply_deferred: bad argument");
+    const int grid = tr_grid(rows);
+    k_bn_grad_apply<<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_dout, nullptr, nullptr, d_y, d_mean, d_inv, d_a, d_b, d_c, d_dx, d_g, rows, 1,
+                                                                   d_dx_scale_tail ? d_partials : nullptr, d_scale, d_shift);
     if (d_dx_scale_tail) k_amax_scale<<<1, 1024, 0, (hipStream_t)stream>>>(d_partials, grid, d_dx_scale_tail);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;

@@ -65,9 +65,39 @@ __global__ __launch_bounds__(TN_THREADS) void k_bn_sums_c(const float *__restric
 __global__ void k_bn_finalize(const double *__restrict__ sums, double count, const float *center,
                               const float *__restrict__ gamma, const float *__restrict__ beta, float *mov_mean,
                               float *mov_var, double momentum, double eps, float *__restrict__ mean_out,
-                              float *__restrict__ inv_out, float *__restrict__ scale_out, float *__restrict__ shift_out, int C)
+                              float *__restrict__ inv_out, float *__restrict__ scale_out, float *__restrict__ shift_out, int C,
+                              const float *__restrict__ amax = nullptr, float *__restrict__ range_tail = nullptr)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float bound[128];
+    if (range_tail) {                                                    // (one block of 128 threads: the launcher checks C <= 128)
+        bound[threadIdx.x] = 0.f;
+        __syncthreads();
+    }
+    if (c < C && range_tail) {
+        // what relu(y * scale + shift) can reach when |y - center| <= amax: the larger end of the interval's image, a hair above
+        // it for the float32 roundings of k_bn_apply's expression (the bound only has to hold; it picks a power of two)
+        const double cen = center ? (double)center[c] : 0.0;
+        const double m0 = sums[c] / count;
+        double var = sums[C + c] / count - m0 * m0;
+        if (var < 0.0) var = 0.0;
+        const double mean = cen + m0, inv = 1.0 / sqrt(var + eps);
+        const double sc = (double)(float)((double)gamma[c] * inv), sh = (double)(float)((double)beta[c] - mean * ((double)gamma[c] * inv));
+        const double hi = sc * (cen + (double)amax[c]) + sh, lo = sc * (cen - (double)amax[c]) + sh;
+        bound[threadIdx.x] = (float)(fmax(fmax(hi, lo), 0.0) * (1.0 + 1e-5));
+    }
+    if (range_tail) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float mx = 0.f;
+            for (int i = 0; i < 128; ++i) mx = fmaxf(mx, bound[i]);
+            int k = 0;
+            if (mx > 0.f && mx < 3.0e38f) k = 11 - ilogbf(mx);           // 2^11 <= mx * 2^k < 2^12 (k_amax_scale, csrc/train.hip)
+            k = max(-100, min(100, k));
+            range_tail[2] = ldexpf(1.0f, k);
+            range_tail[3] = ldexpf(1.0f, -k);
+        }
+    }
     if (c >= C) return;
     const double cen = center ? (double)center[c] : 0.0;
     const double m0 = sums[c] / count;                                   // mean of (y - center)
@@ -129,6 +159,23 @@ extern "C" int snk_bn_train_finalize(const double *d_sums, double count, const f
     k_bn_finalize<<<(channels + 127) / 128, 128, 0, (hipStream_t)stream>>>(d_sums, count, d_center, d_gamma, d_beta, d_moving_mean,
                                                                           d_moving_var, momentum, eps, d_mean, d_inv, d_scale,
                                                                           d_shift, channels);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// snk_bn_train_finalize for a layer whose batch norm + ReLU output is never written (deferred into the next convolution's staging):
+// d_amax = the largest |y - center| per channel (snk_conv3x3_f16s_stats_deferred), d_out_scale_tail = { ., ., scale, 1 / scale } as
+// snk_bn_train_apply writes it for the output it measured -- here from the bound max_c relu(scale_c (center_c +- amax_c) + shift_c),
+// which the output cannot exceed (a looser bound than the measured maximum costs nothing but exponent headroom of the lo parts)
+extern "C" int snk_bn_train_finalize_range(const double *d_sums, double count, const float *d_center, const float *d_gamma,
+                                           const float *d_beta, float *d_moving_mean, float *d_moving_var, double momentum, double eps,
+                                           float *d_mean, float *d_inv, float *d_scale, float *d_shift, const float *d_amax,
+                                           float *d_out_scale_tail, int channels, void *stream)
+{
+    SNK_REQUIRE(d_sums && d_gamma && d_beta && d_mean && d_inv && d_scale && d_shift && d_amax && d_out_scale_tail && channels > 0 &&
+                channels <= 128 && count > 0 && (!d_moving_mean == !d_moving_var), "snk_bn_train_finalize_range: bad argument");
+    k_bn_finalize<<<1, 128, 0, (hipStream_t)stream>>>(d_sums, count, d_center, d_gamma, d_beta, d_moving_mean, d_moving_var, momentum, eps,
+                                                      d_mean, d_inv, d_scale, d_shift, channels, d_amax, d_out_scale_tail);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }

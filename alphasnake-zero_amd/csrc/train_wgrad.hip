@@ -294,10 +294,14 @@ struct Wg2Args {
     float *part;
     const float *x_tail, *dy_tail;
     int n_images, H, W, per_group, rows_x, nxs;      // nxs: X slots a window stages = 16 NK + 2 P + 2
+    const float *x_scale, *x_shift;                  // AFF: x is a PRE-batch-norm tensor, every value is taken as relu(x * scale[c] + shift[c])
 };
 
 // WT: the image width as a compile-time constant (0: read from the arguments): with it every tap's LDS offset is an immediate
-template <int NK, int MAXX, int WT>
+// AFF: the deferred batch norm (snake_engine/train_step.py): X is the pre-batch-norm output of the layer below, its batch norm + ReLU
+//   -- k_bn_apply's expression, csrc/train.hip -- is applied when an item is laid into LDS; the stream's padding slots, which the
+//   buffer descriptor answers with zeros, must stay zeros (they are the padding of the ACTIVATION): one bit per item remembers it
+template <int NK, int MAXX, int WT, bool AFF = false>
 __global__ __launch_bounds__(512) void k_wgrad2_f16s(Wg2Args p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -335,8 +339,15 @@ __global__ __launch_bounds__(512) void k_wgrad2_f16s(Wg2Args p)
         return ((unsigned)(__mul24(__mul24(i, H) + y, W) + x) << 9) | (ok ? 0u : 0x80000000u);      // (no branch: a select of two constants)
     };
     float4 xv[MAXX], yv[NK];
+    // AFF: scale and shift of the block's 64 input channels sit in LDS behind the two buffers (512 bytes; the kernel has no eight
+    // registers to keep a thread's own for its life: they were spilled into the window loop)
+    const unsigned char *aff_tab = smem + 2 * buf_bytes + 16 * xc4;
+    if (AFF && tid < 32) *(float4 *)(smem + 2 * buf_bytes + 16 * tid) = *(const float4 *)((tid < 16 ? p.x_scale : p.x_shift - 64) + 64 * half + 4 * tid);
+    unsigned okbits = 0u;                                                 // AFF: bit j = item j in the registers is a pixel (not padding)
     auto fetch_x = [&](int j, int t) {                                    // item j of window t -> registers
-        xv[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, slot_off(t * 16 * NK - (P + 1) + min(xr0 + 32 * j, nxs - 1)) + xcb, 0, 0));
+        const unsigned o = slot_off(t * 16 * NK - (P + 1) + min(xr0 + 32 * j, nxs - 1));
+        if (AFF) okbits = (okbits & ~(1u << j)) | ((~o >> 31) << j);
+        xv[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, o + xcb, 0, 0));
     };
     auto fetch_y = [&](int j, int t) {
         yv[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ry, slot_off(t * 16 * NK + yr0 + 16 * j) + ycb, 0, 0));
@@ -355,6 +366,14 @@ __global__ __launch_bounds__(512) void k_wgrad2_f16s(Wg2Args p)
     };
     auto store_x = [&](int j, unsigned char *B) {
         uint2 hi, lo;
+        if (AFF) {
+            const bool ok = (okbits >> j) & 1u;
+            const float4 xsc = *(const float4 *)aff_tab, xsh = *(const float4 *)(aff_tab + 256);
+            float4 v = xv[j];
+            v.x = fmaxf(v.x * xsc.x + xsh.x, 0.f); v.y = fmaxf(v.y * xsc.y + xsh.y, 0.f);
+            v.z = fmaxf(v.z * xsc.z + xsh.z, 0.f); v.w = fmaxf(v.w * xsc.w + xsh.w, 0.f);
+            xv[j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        }
         wg_split4(xv[j], sx, hi, lo);
         unsigned char *d = B + xl0 + min(xr0 + 32 * j, nxs - 1) * 64;
         *(uint2 *)d = hi; *(uint2 *)(d + 2 * plane_x) = lo;
@@ -473,7 +492,7 @@ static bool wg2_shape(int h, int w, Wg2Shape &s)
         s.rows_x = 16 * s.nk + WG_GX + 2 * P + 8;
         s.lds = 2 * (4 * s.rows_x * 64 + 8 * 16 * s.nk * 64);
         s.maxx = (s.nxs * 16 + 511) / 512;
-        if (s.maxx <= 5 && s.lds <= 158 * 1024) return true;
+        if (s.maxx <= 5 && s.lds <= 158 * 1024) return true;       // (+ 512 bytes in the deferred form: 160 KB per block is the limit)
     }
     return false;
 }
@@ -516,10 +535,10 @@ extern "C" long snk_conv3x3_wgrad_partials(int height, int width)
     return (long)(b ? WG2_GROUPS : WG_GROUPS) * 9 * 128 * 128;             // the larger of the two forms' needs
 }
 
-extern "C" int snk_conv3x3_wgrad_f16s(const float *d_x, const float *d_dy, const float *d_x_tail, const float *d_dy_tail,
-                                      float *d_partials, float *d_dw, int n_images, int height, int width, void *stream)
+static int wgrad_launch(const float *d_x, const float *d_dy, const float *d_x_tail, const float *d_dy_tail, float *d_partials,
+                        float *d_dw, int n_images, int height, int width, void *stream, const float *d_x_scale,
+                        const float *d_x_shift)
 {
-    SNK_REQUIRE(d_x && d_dy && d_x_tail && d_dy_tail && d_partials && d_dw && n_images > 0, "snk_conv3x3_wgrad_f16s: bad argument");
     SNK_REQUIRE((long)n_images * height * width * 128 < (1l << 40), "snk_conv3x3_wgrad_f16s: batch too large");
     if (wg_use_windows(height, width)) {
         Wg2Shape s2;
@@ -527,17 +546,19 @@ extern "C" int snk_conv3x3_wgrad_f16s(const float *d_x, const float *d_dy, const
         const int per_group = (n_images + WG2_GROUPS - 1) / WG2_GROUPS;
         SNK_REQUIRE((long)per_group * height * width * 512 < (1l << 31) && (long)per_group * (height + 1) * (width + 1) < (1l << 22),
                     "snk_conv3x3_wgrad_f16s: %d images per group do not fit a buffer descriptor", per_group);
-        Wg2Args a2 = {d_x, d_dy, d_partials, d_x_tail, d_dy_tail, n_images, height, width, per_group, s2.rows_x, s2.nxs};
+        Wg2Args a2 = {d_x, d_dy, d_partials, d_x_tail, d_dy_tail, n_images, height, width, per_group, s2.rows_x, s2.nxs, d_x_scale, d_x_shift};
         const dim3 g2(2 * WG2_GROUPS);
         const int wt = height == width && (width == 21 || width == 37) ? width : 0;      // the two canvases of the BASELINE configs
 #define WG2_LAUNCH(NK_, MX_, WT_)                                                               \
         {                                                                                       \
             static bool attr_ = false;       /* more than 64 KB of dynamic LDS needs the attribute */ \
             if (!attr_) {                                                                       \
-                SNK_CHECK_HIP(hipFuncSetAttribute((const void *)k_wgrad2_f16s<NK_, MX_, WT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                SNK_CHECK_HIP(hipFuncSetAttribute((const void *)k_wgrad2_f16s<NK_, MX_, WT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                SNK_CHECK_HIP(hipFuncSetAttribute((const void *)k_wgrad2_f16s<NK_, MX_, WT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
                 attr_ = true;                                                                   \
             }                                                                                   \
-            k_wgrad2_f16s<NK_, MX_, WT_><<<g2, 512, s2.lds, (hipStream_t)stream>>>(a2);         \
+            if (d_x_scale) k_wgrad2_f16s<NK_, MX_, WT_, true><<<g2, 512, s2.lds + 512, (hipStream_t)stream>>>(a2); \
+            else k_wgrad2_f16s<NK_, MX_, WT_, false><<<g2, 512, s2.lds, (hipStream_t)stream>>>(a2); \
         }
         if (wt == 21 && s2.nk == 5 && s2.maxx <= 4) WG2_LAUNCH(5, 4, 21)
         else if (wt == 21 && s2.nk == 4 && s2.maxx <= 4) WG2_LAUNCH(4, 4, 21)
@@ -552,6 +573,7 @@ extern "C" int snk_conv3x3_wgrad_f16s(const float *d_x, const float *d_dy, const
         return 0;
     }
     WgShape s;
+    SNK_REQUIRE(!d_x_scale, "snk_conv3x3_wgrad_f16s_deferred: %d x %d images run the slab form, which has no deferred input", height, width);
     SNK_REQUIRE(wg_shape(height, width, s), "snk_conv3x3_wgrad_f16s: %d x %d images are not supported (width 3 .. 96)", height, width);
     WgArgs a = {d_x, d_dy, d_partials, d_x_tail, d_dy_tail, n_images, height, width, s.P, s.RB, s.n_slabs, s.nk, s.rows_x,
                 (n_images + WG_GROUPS - 1) / WG_GROUPS, s.nx_items, s.ny_items};
@@ -560,3 +582,28 @@ extern "C" int snk_conv3x3_wgrad_f16s(const float *d_x, const float *d_dy, const
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
+
+extern "C" int snk_conv3x3_wgrad_f16s(const float *d_x, const float *d_dy, const float *d_x_tail, const float *d_dy_tail,
+                                      float *d_partials, float *d_dw, int n_images, int height, int width, void *stream)
+{
+    SNK_REQUIRE(d_x && d_dy && d_x_tail && d_dy_tail && d_partials && d_dw && n_images > 0, "snk_conv3x3_wgrad_f16s: bad argument");
+    return wgrad_launch(d_x, d_dy, d_x_tail, d_dy_tail, d_partials, d_dw, n_images, height, width, stream, nullptr, nullptr);
+}
+
+// The weight gradient of a residual block's second layer when the activation between the block's two convolutions was never
+// written (deferred batch norm, snake_engine/train_step.py): d_y_below is the PRE-batch-norm output of the layer below and every
+// value is taken as relu(y * scale[c] + shift[c]) -- bit for bit what snk_bn_train_apply would have written -- when it is laid
+// into LDS.  d_x_tail: the range of that activation (snk_bn_train_finalize_range).  Window form only
+// (snk_train_deferred_bn_supported).
+extern "C" int snk_conv3x3_wgrad_f16s_deferred(const float *d_y_below, const float *d_scale, const float *d_shift, const float *d_dy,
+                                               const float *d_x_tail, const float *d_dy_tail, float *d_partials, float *d_dw,
+                                               int n_images, int height, int width, void *stream)
+{
+    SNK_REQUIRE(d_y_below && d_scale && d_shift && d_dy && d_x_tail && d_dy_tail && d_partials && d_dw && n_images > 0,
+                "snk_conv3x3_wgrad_f16s_deferred: bad argument");
+    return wgrad_launch(d_y_below, d_dy, d_x_tail, d_dy_tail, d_partials, d_dw, n_images, height, width, stream, d_scale, d_shift);
+}
+
+// 1 when the training step may defer the batch norm + ReLU of a residual block's first layer into the kernels that read it
+// (the weight gradient's window form carries the input transform; the slab form does not)
+extern "C" int snk_train_deferred_bn_supported(int height, int width) { return wg_use_windows(height, width) ? 1 : 0; }

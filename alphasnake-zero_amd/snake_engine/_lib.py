@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SNK_LIB_PATH") or os.path.join(_HERE, "libsnake_engine.so")      # SNK_LIB_PATH: a variant build (A/B runs)
 
 MAX_SNAKES, MAX_CELLS, MAX_NODES = 8, 361, 384
-ABI_VERSION = 110        # SNK_ABI_VERSION of include/snake_engine.h these prototypes were written against
+ABI_VERSION = 111        # SNK_ABI_VERSION of include/snake_engine.h these prototypes were written against
 
 
 class EngineError(RuntimeError):
@@ -112,6 +112,13 @@ PROTOTYPES = {
     "snk_conv3x3_stats_partials": (C.c_long, [i32, i32, i32]),
     "snk_conv3x3_f16s_stats": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "snk_conv3x3_f16s_igrad_stats": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "snk_train_deferred_bn_supported": (i32, [i32, i32]),
+    "snk_conv3x3_f16s_stats_deferred": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "snk_bn_train_finalize_range": (i32, [vp, f64, vp, vp, vp, vp, vp, f64, f64, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "snk_conv3x3_wgrad_f16s_deferred": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "snk_conv3x3_f16s_igrad_stats_deferred": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "snk_bn_train_grad_sums_f64_deferred": (i32, [vp, vp, vp, vp, vp, vp, C.c_long, vp, vp, vp]),
+    "snk_bn_train_grad_apply_deferred": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_long, vp, vp, vp]),
     "snk_stem_wgrad_partials": (C.c_long, [i32, i32, i32]),
     "snk_stem_wgrad_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "snk_bn_train_sums_f64": (i32, [vp, C.c_long, vp, vp, vp, vp]),

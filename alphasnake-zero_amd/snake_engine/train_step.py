@@ -22,6 +22,15 @@ Parameters, gradients and Adam moments are single flat buffers; every tensor of 
 ``torch.distributed`` initialised the batch-norm sums (float64) and the gradient buffer are all-reduced: the result equals
 the one-rank full-batch step up to float32 rounding.  A step whose learning rate is 0 (alpha_nnet.py:79-84: every step
 after the 100th) can only move the batch-norm moving averages: ``forward_only`` runs just the forward half.
+
+The deferred batch norm (round 5; ``SNK_TRAIN_DEFER_BN=0`` turns it off): the activation between the two convolutions of a
+residual block -- out_l of an odd layer l, relu(bn(y_l)), no shortcut -- is read by the block's second convolution, by that
+layer's weight gradient and, as a sign, by the batch-norm backward of layer l.  All three take it from y_l instead, as
+relu(y_l * scale_l + shift_l) evaluated the way snk_bn_train_apply evaluates it (bit for bit the same values), while they stage
+or read y_l: out_l and its mask bytes are never written nor read -- one element-wise pass over two 462 MB tensors less per
+block in EVERY step, the forward-only ones included.  The range the second convolution scales its input by, which
+snk_bn_train_apply measures while it writes, comes from the per-channel maxima the first convolution's epilogue takes next
+to its sums (snk_conv3x3_f16s_stats_deferred -> snk_bn_train_finalize_range).
 """
 import os
 
@@ -33,6 +42,7 @@ from .net import F16S_WEIGHT_BYTES
 
 _CONV_STATS = os.environ.get("SNK_TRAIN_CONV_STATS", "1") != "0"      # 0: batch-norm sums in a pass of their own (A/B runs)
 _IGRAD_STATS = os.environ.get("SNK_TRAIN_IGRAD_STATS", "1") != "0"    # 0: the batch-norm BACKWARD sums in a pass of their own
+_DEFER_BN = os.environ.get("SNK_TRAIN_DEFER_BN", "1") != "0"          # 0: every layer's batch norm + ReLU output is written (A/B runs)
 BN_EPS, BN_MOMENTUM, L2_C = 1e-3, 0.99, 1e-5
 ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-7
 C = 128
@@ -85,19 +95,23 @@ class TrainStep:
             if j in self.kernel_idx:
                 self.decay[o:o + sz] = 1
             o += sz
+        # a block's first layers (odd l) whose batch norm + ReLU is applied by the kernels that read its output (see the module text)
+        self.defer = bool(_DEFER_BN and _CONV_STATS and self.L.snk_train_deferred_bn_supported(self.h, self.w) == 1)
         self.moving = {j: torch.as_tensor(ws[j].reshape(-1).copy(), device=self.dev) for j in range(len(ws)) if j not in self.view}
         self.adam_t = 0
         # ---- activations kept for the backward pass, gradients in flight
         act = self.max_rows * self.hw * C
         self.y = [f(act) for _ in range(self.n_layers)]
-        self.out = [f(act) for _ in range(self.n_layers)]
+        self.out = [None if self._deferred(l) else f(act) for l in range(self.n_layers)]
         self.dA, self.dY, self.gres = f(act), f(act), f(act)
         self.mean = [f(C) for _ in range(self.n_layers)]
         self.inv = [f(C) for _ in range(self.n_layers)]
         self.scale = [f(C) for _ in range(self.n_layers)]
         self.shift = [f(C) for _ in range(self.n_layers)]
         self.tail_out = [f(4) for _ in range(self.n_layers)]
-        self.relu_mask = [f(self.max_rows * self.hw * 32, torch.uint8) for _ in range(self.n_layers)]     # 4 bits per byte: out > 0
+        self.relu_mask = [None if self._deferred(l) else f(self.max_rows * self.hw * 32, torch.uint8)
+                          for l in range(self.n_layers)]                                                   # 4 bits per byte: out > 0
+        self.amax = f(C)
         self.tail_dy = f(4)
         self.abc = f(3 * C)
         self.img_f = [torch.empty(F16S_WEIGHT_BYTES, dtype=torch.uint8, device=self.dev) for _ in range(self.n_layers)]
@@ -125,6 +139,9 @@ class TrainStep:
     def _st(self):
         return torch.cuda.current_stream(self.dev).cuda_stream
 
+    def _deferred(self, l):
+        return self.defer and l % 2 == 1
+
     def _k(self, l):                     # Keras list index of conv layer l's kernel (gamma, beta, moving mean / variance follow)
         return 5 * l
 
@@ -143,6 +160,11 @@ class TrainStep:
         if not have_sums:                                        # the tower's convolutions take the sums on their way out
             check(L.snk_bn_train_sums_f64(_p(self.y[l]), rows, _p(mm), _p(self.partials), _p(self.sums), st))
         self._all_reduce(self.sums)
+        if self._deferred(l):                                    # nobody writes out_l: its range comes from the convolution's maxima
+            check(L.snk_bn_train_finalize_range(_p(self.sums), float(count), _p(mm), _p(self.view[k + 1]), _p(self.view[k + 2]), _p(mm),
+                                                _p(mv), BN_MOMENTUM, BN_EPS, _p(self.mean[l]), _p(self.inv[l]), _p(self.scale[l]),
+                                                _p(self.shift[l]), _p(self.amax), _p(tail), C, st))
+            return
         check(L.snk_bn_train_finalize(_p(self.sums), float(count), _p(mm), _p(self.view[k + 1]), _p(self.view[k + 2]), _p(mm), _p(mv),
                                       BN_MOMENTUM, BN_EPS, _p(self.mean[l]), _p(self.inv[l]), _p(self.scale[l]), _p(self.shift[l]), C, st))
         check(L.snk_bn_train_apply(_p(self.y[l]), _p(self.scale[l]), _p(self.shift[l]), _p(res), _p(relu_out), rows, 1,
@@ -165,7 +187,15 @@ class TrainStep:
         for l in range(1, self.n_layers):
             k = self._k(l)
             check(L.snk_conv3x3_prepare_weights_f16s_train(_p(self.view[k]), _p(self.img_f[l]), _p(self.tail_out[l - 1]), 0, None, st))
-            if _CONV_STATS:
+            if self._deferred(l - 1):                             # reads y_{l-1} through layer l - 1's batch norm + ReLU
+                check(L.snk_conv3x3_f16s_stats_deferred(_p(self.y[l - 1]), _p(self.img_f[l]), _p(self.y[l]), _p(self.moving[k + 3]),
+                                                        _p(self.scale[l - 1]), _p(self.shift[l - 1]), None, _p(self.cv_partials),
+                                                        _p(self.sums), n, self.h, self.w, st))
+            elif self._deferred(l):                               # also takes the maxima its own deferred batch norm is ranged by
+                check(L.snk_conv3x3_f16s_stats_deferred(_p(self.out[l - 1]), _p(self.img_f[l]), _p(self.y[l]), _p(self.moving[k + 3]),
+                                                        None, None, _p(self.amax), _p(self.cv_partials), _p(self.sums), n, self.h,
+                                                        self.w, st))
+            elif _CONV_STATS:
                 check(L.snk_conv3x3_f16s_stats(_p(self.out[l - 1]), _p(self.img_f[l]), _p(self.y[l]), _p(self.moving[k + 3]),
                                                _p(self.cv_partials), _p(self.sums), n, self.h, self.w, st))
             else:
@@ -191,7 +221,11 @@ class TrainStep:
         L, st, rows, k = self.L, self._st(), n * self.hw, self._k(l)
         sign = self.mask_override.get(l)                          # tests: a tensor whose sign replaces the recorded ReLU mask
         bits = None if sign is not None else self.relu_mask[l]
-        if not have_sums:                                         # the input-gradient convolution above took them on its way out
+        deferred = sign is None and self._deferred(l)             # no mask bytes: the decision is recomputed from y_l, scale_l, shift_l
+        if not have_sums and deferred:
+            check(L.snk_bn_train_grad_sums_f64_deferred(_p(self.dA), _p(self.y[l]), _p(self.scale[l]), _p(self.shift[l]), _p(self.mean[l]),
+                                                        _p(self.inv[l]), rows, _p(self.partials), _p(self.sums), st))
+        elif not have_sums:                                       # the input-gradient convolution above took them on its way out
             check(L.snk_bn_train_grad_sums_f64(_p(self.dA), _p(sign), _p(bits), _p(self.y[l]), _p(self.mean[l]), _p(self.inv[l]), rows, 1,
                                                _p(self.partials), _p(self.sums), st))
         local = self.sums
@@ -202,6 +236,11 @@ class TrainStep:
         a, b, c = self.abc[:C], self.abc[C:2 * C], self.abc[2 * C:]
         check(L.snk_bn_train_grad_finalize(_p(self.sums), _p(local), float(count), _p(self.view[k + 1]), _p(self.inv[l]), _p(a), _p(b), _p(c),
                                            _p(self.gview[k + 1]), _p(self.gview[k + 2]), C, st))
+        if deferred:
+            check(L.snk_bn_train_grad_apply_deferred(_p(self.dA), _p(self.y[l]), _p(self.scale[l]), _p(self.shift[l]), _p(self.mean[l]),
+                                                     _p(self.inv[l]), _p(a), _p(b), _p(c), _p(self.dY),
+                                                     _p(self.gres) if want_res else None, rows, _p(self.partials), _p(tail), st))
+            return
         check(L.snk_bn_train_grad_apply(_p(self.dA), _p(sign), _p(bits), _p(self.y[l]), _p(self.mean[l]), _p(self.inv[l]), _p(a), _p(b), _p(c),
                                         _p(self.dY), _p(self.gres) if want_res else None, rows, 1, _p(self.partials), _p(tail), st))
 
@@ -231,12 +270,22 @@ class TrainStep:
         for l in range(self.n_layers - 1, 0, -1):
             k, second = self._k(l), l % 2 == 0
             self._bn_backward(l, n, count, want_res=second, tail=self.tail_dy, have_sums=have_sums)   # dA -> dY (+ gres: the shortcut's gradient)
-            check(L.snk_conv3x3_wgrad_f16s(_p(self.out[l - 1]), _p(self.dY), _p(self.tail_out[l - 1]), _p(self.tail_dy),
-                                           _p(self.wg_partials), _p(self.gview[k]), n, self.h, self.w, st))
+            if self._deferred(l - 1):
+                check(L.snk_conv3x3_wgrad_f16s_deferred(_p(self.y[l - 1]), _p(self.scale[l - 1]), _p(self.shift[l - 1]), _p(self.dY),
+                                                        _p(self.tail_out[l - 1]), _p(self.tail_dy), _p(self.wg_partials),
+                                                        _p(self.gview[k]), n, self.h, self.w, st))
+            else:
+                check(L.snk_conv3x3_wgrad_f16s(_p(self.out[l - 1]), _p(self.dY), _p(self.tail_out[l - 1]), _p(self.tail_dy),
+                                               _p(self.wg_partials), _p(self.gview[k]), n, self.h, self.w, st))
             check(L.snk_conv3x3_prepare_weights_f16s_train(_p(self.view[k]), _p(self.img_b), _p(self.tail_dy), 1, _p(self.img_f[l]), st))
             # gradient at out[l - 1]; its epilogue also takes the two sums the batch-norm backward of layer l - 1 starts with
             have_sums = _IGRAD_STATS and (l - 1) not in self.mask_override
-            if have_sums:
+            if have_sums and self._deferred(l - 1):
+                check(L.snk_conv3x3_f16s_igrad_stats_deferred(_p(self.dY), _p(self.img_b), _p(None if second else self.gres), _p(self.dA),
+                                                              _p(self.y[l - 1]), _p(self.scale[l - 1]), _p(self.shift[l - 1]),
+                                                              _p(self.mean[l - 1]), _p(self.inv[l - 1]), _p(self.cv_partials),
+                                                              _p(self.sums), n, self.h, self.w, st))
+            elif have_sums:
                 check(L.snk_conv3x3_f16s_igrad_stats(_p(self.dY), _p(self.img_b), _p(None if second else self.gres), _p(self.dA),
                                                      _p(self.y[l - 1]), _p(self.relu_mask[l - 1]), _p(self.mean[l - 1]), _p(self.inv[l - 1]),
                                                      _p(self.cv_partials), _p(self.sums), n, self.h, self.w, st))

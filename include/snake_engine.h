@@ -50,8 +50,10 @@ typedef struct {
 } snk_game_state;
 
 const char *snk_last_error(void);
-#define SNK_ABI_VERSION 110 /* 100: rounds 1-3; 110: round 5 (the gate argument d_skip of the tick kernels, round 4; the 16-bit
-                             * towers' own weight image and rectangle plan, round 5): a caller compares it with snk_version() */
+#define SNK_ABI_VERSION 111 /* 100: rounds 1-3; 110: round 5 (the gate argument d_skip of the tick kernels, round 4; the 16-bit
+                             * towers' own weight image and rectangle plan, round 5); 111: the training step's deferred batch
+                             * norm (seven entry points added, snk_conv3x3_stats_partials returns more): a caller compares it
+                             * with snk_version() */
 int snk_version(void);
 
 /* ---- engine lifetime -------------------------------------------------------------------
@@ -480,6 +482,41 @@ int snk_conv3x3_f16s_stats(const float *d_x, const void *d_wS, float *d_out, con
 int snk_conv3x3_f16s_igrad_stats(const float *d_x, const void *d_wS, const float *d_residual, float *d_out, const float *d_y,
                                  const uint8_t *d_mask, const float *d_mean, const float *d_inv, float *d_partials,
                                  double *d_sums, int n_images, int height, int width, void *stream);
+/* ---- the deferred batch norm of the training step (alpha_nnet.py:25-47 under Keras fit, alpha_nnet.py:58-59) ----------------
+ * The activation BETWEEN the two convolutions of a residual block, relu(bn(conv1(x))), has exactly three readers: the block's
+ * second convolution, that layer's weight gradient, and (as a sign) the batch-norm backward of the first.  These entry points let
+ * all three take it from the first convolution's PRE-batch-norm output y as relu(y * scale[c] + shift[c]) -- the expression
+ * snk_bn_train_apply(relu = 1, no residual) evaluates, bit for bit -- so that the activation and its mask bytes are never written
+ * nor read: one element-wise pass over two 462 MB tensors less per block, in every step (also the forward-only steps at rate 0).
+ *   snk_train_deferred_bn_supported(h, w)   1 when every kernel involved exists for the shape (the weight gradient's window form)
+ *   snk_conv3x3_f16s_stats_deferred         snk_conv3x3_f16s_stats with d_in_scale / d_in_shift (both or neither: d_x is such a y)
+ *                                           and d_amax (or NULL; plain input only): 128 floats, largest |out - center| per channel
+ *   snk_bn_train_finalize_range             snk_bn_train_finalize + d_out_scale_tail = { ., ., 2^k, 2^-k } with 2^11 <= bound 2^k <
+ *                                           2^12, bound = max_c relu(scale_c (center_c +- amax_c) + shift_c) >= every value the
+ *                                           deferred activation takes (what snk_bn_train_apply measures while it writes)
+ *   snk_conv3x3_wgrad_f16s_deferred         snk_conv3x3_wgrad_f16s whose X operand is such a y (d_x_tail from finalize_range)
+ *   snk_conv3x3_f16s_igrad_stats_deferred   snk_conv3x3_f16s_igrad_stats whose ReLU decision is d_y * d_scale + d_shift > 0
+ *   snk_bn_train_grad_sums_f64_deferred / snk_bn_train_grad_apply_deferred   the same decision in the two element-wise kernels */
+int snk_train_deferred_bn_supported(int height, int width);
+int snk_conv3x3_f16s_stats_deferred(const float *d_x, const void *d_wS, float *d_out, const float *d_center, const float *d_in_scale,
+                                    const float *d_in_shift, float *d_amax, float *d_partials, double *d_sums, int n_images,
+                                    int height, int width, void *stream);
+int snk_bn_train_finalize_range(const double *d_sums, double count, const float *d_center, const float *d_gamma, const float *d_beta,
+                                float *d_moving_mean, float *d_moving_var, double momentum, double eps, float *d_mean, float *d_inv,
+                                float *d_scale, float *d_shift, const float *d_amax, float *d_out_scale_tail, int channels,
+                                void *stream);
+int snk_conv3x3_wgrad_f16s_deferred(const float *d_y_below, const float *d_scale, const float *d_shift, const float *d_dy,
+                                    const float *d_x_tail, const float *d_dy_tail, float *d_partials, float *d_dw, int n_images,
+                                    int height, int width, void *stream);
+int snk_conv3x3_f16s_igrad_stats_deferred(const float *d_x, const void *d_wS, const float *d_residual, float *d_out, const float *d_y,
+                                          const float *d_scale, const float *d_shift, const float *d_mean, const float *d_inv,
+                                          float *d_partials, double *d_sums, int n_images, int height, int width, void *stream);
+int snk_bn_train_grad_sums_f64_deferred(const float *d_dout, const float *d_y, const float *d_scale, const float *d_shift,
+                                        const float *d_mean, const float *d_inv, long rows, float *d_partials, double *d_sums,
+                                        void *stream);
+int snk_bn_train_grad_apply_deferred(const float *d_dout, const float *d_y, const float *d_scale, const float *d_shift,
+                                     const float *d_mean, const float *d_inv, const float *d_a, const float *d_b, const float *d_c,
+                                     float *d_dx, float *d_g, long rows, float *d_partials, float *d_dx_scale_tail, void *stream);
 long snk_stem_wgrad_partials(int n_images, int height, int width);
 int snk_stem_wgrad_f32(const float *d_x, const float *d_dy, float *d_partials, float *d_dw, int n_images, int height, int width,
                        void *stream);

@@ -332,6 +332,7 @@ def test_batch_norm_backward_sums_in_the_input_gradient_epilogue_change_nothing_
     Y = torch.as_tensor(np.tanh(rs.randn(n, 3)).astype(np.float32), device="cuda")
     ws = net.glorot_uniform_weights((hw, hw, 3), blocks=blocks, seed=4)
     grads = {}
+    monkeypatch.setattr(train_step, "_DEFER_BN", False)     # the mask bytes of layer 1 are read below (deferred: tests further down)
     for fused in (True, False):
         monkeypatch.setattr(train_step, "_IGRAD_STATS", fused)
         ts = train_step.TrainStep(ws, (hw, hw, 3), n, "cuda")
@@ -357,6 +358,95 @@ def test_batch_norm_backward_sums_in_the_input_gradient_epilogue_change_nothing_
         assert torch.equal(dA1[:n * hw * hw * 128], dA2[:n * hw * hw * 128])
         err = (sums - ref).abs().max().item()
         assert err <= 1e-5 * max(ref.abs().max().item(), 1e-12), (err, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("n,blocks,hw", [(24, 2, 21), (6, 1, 37), (10, 2, 13)])
+def test_deferred_batch_norm_reads_the_same_values_as_the_written_activation(torch_gpu, monkeypatch, n, blocks, hw):
+    """round 5: the activation between the two convolutions of a residual block is never written -- its three readers (the
+    block's second convolution, that layer's weight gradient, the first layer's batch-norm backward) evaluate relu(y * scale +
+    shift) themselves (snake_engine/train_step.py; alpha_nnet.py:25-47 under Keras fit).  Entry point by entry point against the
+    written activation with the SAME input scales: bit-identical outputs; then two whole steps, one with and one without the
+    deferral (only the power-of-two input range differs: a bound instead of the measured maximum)"""
+    torch = torch_gpu
+    from snake_engine import net, train_step
+    from snake_engine._lib import lib, check
+    from snake_engine.train_step import _p
+    rs = np.random.RandomState(100 + n)
+    X = torch.as_tensor(rs.rand(n, hw, hw, 3).astype(np.float32), device="cuda")
+    Y = torch.as_tensor(np.tanh(rs.randn(n, 3)).astype(np.float32), device="cuda")
+    ws = net.glorot_uniform_weights((hw, hw, 3), blocks=blocks, seed=6)
+    for l in range(2 + 2 * blocks):                         # batch-norm parameters away from 1 / 0, some scales NEGATIVE
+        g = ws[5 * l + 1] * (0.6 + 0.8 * rs.rand(*ws[5 * l + 1].shape))
+        g[::7] *= -1.0
+        ws[5 * l + 1] = g.astype(np.float32)
+        ws[5 * l + 2] = (0.3 * rs.randn(*ws[5 * l + 2].shape)).astype(np.float32)
+    L, st = lib(), torch.cuda.current_stream().cuda_stream
+    assert L.snk_train_deferred_bn_supported(hw, hw) == 1
+    runs = {}
+    for defer in (False, True):
+        monkeypatch.setattr(train_step, "_DEFER_BN", defer)
+        ts = train_step.TrainStep(ws, (hw, hw, 3), n, "cuda")
+        assert ts.defer == defer and (ts.out[1] is None) == defer and (ts.relu_mask[1] is None) == defer and ts.out[2] is not None
+        q = ts.forward(X, Y, n).clone()
+        ts.backward(Y, n)
+        runs[defer] = (ts, q, ts.gradients(), ts.weights())
+    ts, q0, g0, w0 = runs[False]
+    td, q1, g1, w1 = runs[True]
+    rows, act = n * hw * hw, n * hw * hw * 128
+    # ---- the range: a bound of the written activation's maximum, at most a few binary orders above it
+    true_max = float(ts.out[1][:act].max())
+    k_meas, k_bound = float(ts.tail_out[1][2]), float(td.tail_out[1][2])
+    assert 2.0 ** 11 <= true_max * k_meas < 2.0 ** 12
+    assert true_max * k_bound < 2.0 ** 12 and k_bound >= k_meas / 64.0, (true_max, k_meas, k_bound)
+    # ---- forward convolution of layer 2 reading y_1 through layer 1's scale / shift == reading the written out_1 (same image, same scale)
+    y2 = torch.empty_like(ts.y[2])
+    sums, ref = torch.zeros(256, dtype=torch.float64, device="cuda"), torch.zeros(256, dtype=torch.float64, device="cuda")
+    y2_ref = torch.empty_like(ts.y[2])
+    check(L.snk_conv3x3_f16s_stats(_p(ts.out[1]), _p(ts.img_f[2]), _p(y2_ref), None, _p(ts.cv_partials), _p(ref), n, hw, hw, st))
+    check(L.snk_conv3x3_f16s_stats_deferred(_p(ts.y[1]), _p(ts.img_f[2]), _p(y2), None, _p(ts.scale[1]), _p(ts.shift[1]), None,
+                                            _p(ts.cv_partials), _p(sums), n, hw, hw, st))
+    assert torch.equal(y2[:act], y2_ref[:act]) and torch.equal(sums, ref)
+    # ---- the maxima next to the sums: exact
+    amax = torch.zeros(128, device="cuda")
+    check(L.snk_conv3x3_f16s_stats_deferred(_p(ts.out[1]), _p(ts.img_f[2]), _p(y2), None, None, None, _p(amax), _p(ts.cv_partials),
+                                            _p(sums), n, hw, hw, st))
+    assert torch.equal(y2[:act], y2_ref[:act]) and torch.equal(sums, ref)
+    assert torch.equal(amax, y2_ref[:act].view(rows, 128).abs().max(dim=0).values)
+    # ---- backward: the state of the written run after its backward pass holds dY of layer 1 last; rebuild layer 2's pieces
+    dy = torch.randn(act, device="cuda") * 1e-3
+    tail_dy = _tail_of(torch, L, dy)
+    dw_a, dw_b = torch.zeros(9 * 128 * 128, device="cuda"), torch.zeros(9 * 128 * 128, device="cuda")
+    check(L.snk_conv3x3_wgrad_f16s(_p(ts.out[1]), _p(dy), _p(ts.tail_out[1]), _p(tail_dy), _p(ts.wg_partials), _p(dw_a), n, hw, hw, st))
+    check(L.snk_conv3x3_wgrad_f16s_deferred(_p(ts.y[1]), _p(ts.scale[1]), _p(ts.shift[1]), _p(dy), _p(ts.tail_out[1]), _p(tail_dy),
+                                            _p(ts.wg_partials), _p(dw_b), n, hw, hw, st))
+    assert torch.equal(dw_a, dw_b) and float(dw_a.abs().max()) > 0
+    k = ts._k(2)
+    check(L.snk_conv3x3_prepare_weights_f16s_train(_p(ts.view[k]), _p(ts.img_b), _p(tail_dy), 1, _p(ts.img_f[2]), st))
+    dA_a, dA_b = torch.empty(act, device="cuda"), torch.empty(act, device="cuda")
+    check(L.snk_conv3x3_f16s_igrad_stats(_p(dy), _p(ts.img_b), None, _p(dA_a), _p(ts.y[1]), _p(ts.relu_mask[1]), _p(ts.mean[1]),
+                                         _p(ts.inv[1]), _p(ts.cv_partials), _p(ref), n, hw, hw, st))
+    check(L.snk_conv3x3_f16s_igrad_stats_deferred(_p(dy), _p(ts.img_b), None, _p(dA_b), _p(ts.y[1]), _p(ts.scale[1]), _p(ts.shift[1]),
+                                                  _p(ts.mean[1]), _p(ts.inv[1]), _p(ts.cv_partials), _p(sums), n, hw, hw, st))
+    assert torch.equal(dA_a, dA_b) and torch.equal(sums, ref)
+    check(L.snk_bn_train_grad_sums_f64(_p(dA_a), None, _p(ts.relu_mask[1]), _p(ts.y[1]), _p(ts.mean[1]), _p(ts.inv[1]), rows, 1,
+                                       _p(ts.partials), _p(ref), st))
+    check(L.snk_bn_train_grad_sums_f64_deferred(_p(dA_a), _p(ts.y[1]), _p(ts.scale[1]), _p(ts.shift[1]), _p(ts.mean[1]), _p(ts.inv[1]), rows,
+                                                _p(ts.partials), _p(sums), st))
+    assert torch.equal(sums, ref)
+    a, b, c = ts.abc[:128], ts.abc[128:256], ts.abc[256:]
+    dx_a, dx_b, g_a, g_b = (torch.empty(act, device="cuda") for _ in range(4))
+    t_a, t_b = torch.zeros(4, device="cuda"), torch.zeros(4, device="cuda")
+    check(L.snk_bn_train_grad_apply(_p(dA_a), None, _p(ts.relu_mask[1]), _p(ts.y[1]), _p(ts.mean[1]), _p(ts.inv[1]), _p(a), _p(b), _p(c),
+                                    _p(dx_a), _p(g_a), rows, 1, _p(ts.partials), _p(t_a), st))
+    check(L.snk_bn_train_grad_apply_deferred(_p(dA_a), _p(ts.y[1]), _p(ts.scale[1]), _p(ts.shift[1]), _p(ts.mean[1]), _p(ts.inv[1]), _p(a),
+                                             _p(b), _p(c), _p(dx_b), _p(g_b), rows, _p(ts.partials), _p(t_b), st))
+    assert torch.equal(dx_a, dx_b) and torch.equal(g_a, g_b) and torch.equal(t_a, t_b)
+    # ---- whole steps: Q, every gradient, the moving statistics
+    assert float((q0 - q1).abs().max()) <= 2e-6
+    for j in g0:
+        assert np.abs(g0[j] - g1[j]).max() <= 2e-5 * max(np.abs(g0[j]).max(), 1e-12), (j, np.abs(g0[j] - g1[j]).max(), np.abs(g0[j]).max())
+    for j, (u, v) in enumerate(zip(w0, w1)):
+        assert np.abs(u - v).max() <= 1e-6 * max(np.abs(u).max(), 1e-12), j
 
 
 def test_fit_on_the_kernels_tracks_fit_with_library_operators(torch_gpu):

@@ -38,7 +38,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     nn = x.shape[0] * 441 * 128
     for l in (0, 1, 2):
         ts.log[f"y{l}"] = ts.y[l][:nn].cpu().numpy().reshape(x.shape[0], -1)
-        ts.log[f"out{l}"] = ts.out[l][:nn].cpu().numpy().reshape(x.shape[0], -1)
+        if ts.out[l] is not None:
+            ts.log[f"out{l}"] = ts.out[l][:nn].cpu().numpy().reshape(x.shape[0], -1)
         ts.log[f"tail{l}"] = ts.tail_out[l].cpu().numpy()
     np.savez(sys.argv[2] + f"/log_w{world}_r{rank}.npz", **ts.log)
     np.savez(sys.argv[2] + f"/g_w{world}_r{rank}.npz", **{str(k): v for k, v in g.items()}, mse=ts.G[ts.n_params].cpu().numpy(),
