@@ -200,7 +200,9 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     constexpr int NST = K32 ? HS_NST16 : HS_NST, BUFB = K32 ? HS_BUF16 : HS_NPB * HS_LDP;
     constexpr int PIECE = K32 ? 8 : 4;                     // channels of a staging item
     constexpr bool P8 = IN16 && OUT16;                     // the epilogue handles 8 channels (16 bytes in and out) per thread and row
-    const bool has_res = (MODE == 0 || GSTATS) ? p.res != nullptr : (MODE == 2 || MODE == 3);
+    // (MODE 7 never takes a shortcut's gradient: it produces the gradient at a block's FIRST layer's output -- its epilogue has the
+    // registers the shortcut rows would take for the g_y rows instead, requested a pass ahead)
+    const bool has_res = GAFF ? false : (MODE == 0 || GSTATS) ? p.res != nullptr : (MODE == 2 || MODE == 3);
     const bool has_head = MODE == 0 ? p.w1x1 != nullptr : MODE == 3;
     const bool has_out = MODE == 0 ? p.out != nullptr : MODE != 3;
     const float relu_floor = ((MODE != 0 && !BARE) || (MODE == 0 && p.relu)) ? 0.f : -__builtin_inff();
@@ -411,6 +413,16 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
 #pragma unroll 1
     for (; c < NCHUNK - 1; ++c) HS_CHUNK(true)
     HS_STAMP(2)
+    // MODE 7: the g_y rows of the epilogue's first pass are requested here, into the registers the staging items no longer need: their
+    // HBM latency passes under the last chunk's MFMAs (the epilogue below requests every later pass's rows one pass ahead)
+    float4 gyv[GAFF ? 2 : 1][GAFF ? 8 : 1];
+    if (GAFF) {
+#pragma unroll
+        for (int j = 0; j < (NI >= 2 ? 8 : 4); ++j) {
+            const int m_ = min(m0 + (tid >> 5) + 8 * j, m1 - 1);
+            gyv[0][j] = *(const float4 *)(p.g_y + (long)img * HWc * HS_C + 4 * (tid & 31) + (long)m_ * HS_C);
+        }
+    }
     HS_CHUNK(false)                    // the last chunk stages nothing
     HS_STAMP(3)
     if (K32) __builtin_amdgcn_s_setprio(0);
@@ -597,6 +609,11 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
         float4 m[8];
 #pragma unroll
         for (int j = 0; j < HS_ROWS(pass) / 8; ++j) m[j] = *(const float4 *)&Mb[(rr0 + 8 * j) * HS_MLD + 4 * cq];
+        if (GAFF && pass + 1 < NPASS) {
+#pragma unroll
+            for (int j = 0; j < HS_ROWS(pass + 1) / 8; ++j)
+                gyv[(pass + 1) & 1][j] = *(const float4 *)(p.g_y + obase + max(off[(pass + 1) & 1][j], 0));
+        }
 #pragma unroll
         for (int j = 0; j < HS_ROWS(pass) / 8; ++j) {
             float4 v = m[j];
@@ -609,7 +626,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
             v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
             if (GSTATS && off[pass & 1][j] >= 0) {
                 const long e_ = obase + off[pass & 1][j];
-                const float4 y_ = *(const float4 *)(p.g_y + e_);
+                const float4 y_ = GAFF ? gyv[pass & 1][j] : *(const float4 *)(p.g_y + e_);
                 float gx, gy, gz, gw;
                 if (GAFF) {                  // the layer's output was never written: its sign is that of k_bn_apply's expression
                     gx = y_.x * gsc.x + gsh.x > 0.f ? v.x : 0.f; gy = y_.y * gsc.y + gsh.y > 0.f ? v.y : 0.f;
@@ -940,6 +957,8 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
         }                                                                                       \
         SNK_CHECK_HIP(hipGetLastError());                                                       \
         return 0;
+    SNK_REQUIRE(!(d_stat_part && a.g_y && d_aff_scale && d_residual),
+                "snk_conv3x3_f16s_igrad_stats_deferred: the layer below a block's second convolution has no shortcut gradient to add");
     if (d_stat_part && a.g_y && d_aff_scale) { HS_LAUNCH_TRAIN(7) }    // ... of a layer whose ReLU decision is recomputed from its scale / shift
     if (d_stat_part && d_aff_scale) { HS_LAUNCH_TRAIN(6) }             // forward pass, the producer's batch norm + ReLU applied on the way in
 #undef HS_LAUNCH_TRAIN
@@ -1306,26 +1325,32 @@ extern "C" int snk_conv3x3_bn_f16s_head(const float *d_x, const void *d_wS, cons
 // their way out, d_sums[0..127] = sum over all pixels of (out - center), d_sums[128..255] = sum of (out - center)^2 (float64;
 // d_center: 128 floats or NULL) -- what snk_bn_train_sums_f64 would compute from d_out in a pass of its own.
 // d_partials: snk_conv3x3_stats_partials(n_images, height, width) floats.
+#define HS_AMAX_STAGE 64                                 // rows the first of the two maximum folds leaves
 extern "C" long snk_conv3x3_stats_partials(int n_images, int height, int width)
 {
     if (n_images <= 0 || height < 1 || width < 3) return -1;
     const long T = ((long)height * width + 31) / 32;
-    return (long)n_images * T * 384 + TF_SCRATCH_FLOATS(256);              // at most one block per M tile: 2 x 128 sums + 128 maxima each
+    // at most one block per M tile: 2 x 128 sums + 128 maxima each; the two folds' scratch
+    return (long)n_images * T * 384 + TF_SCRATCH_FLOATS(256) + HS_AMAX_STAGE * HS_C;
 }
 
-// per-channel maximum over the blocks' maxima: [n_blocks][128] -> [128]
-__global__ __launch_bounds__(256) void k_amax_fold128(const float *__restrict__ part, int n_blocks, float *__restrict__ amax)
+// per-channel maximum over the blocks' maxima: [n_rows][128] -> [gridDim.x][128] (whole 512-byte rows per eight-lane group, block b
+// takes rows b, b + gridDim.x, ..); run twice: the blocks' maxima -> 64 rows -> 1
+__global__ __launch_bounds__(256) void k_amax_fold128(const float *__restrict__ part, int n_rows, float *__restrict__ out)
 {
-    __shared__ float sh[32][8];
-    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3, c = 8 * blockIdx.x + cl;
-    float m = 0.f;
-    for (int r = rl; r < n_blocks; r += 32) m = fmaxf(m, part[(size_t)r * HS_C + c]);
-    sh[rl][cl] = m;
+    __shared__ float4 sh[8][32];
+    const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = blockIdx.x * 8 + rl; r < n_rows; r += gridDim.x * 8) {
+        const float4 v = *(const float4 *)(part + (size_t)r * HS_C + 4 * cq);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+    }
+    sh[rl][cq] = m;
     __syncthreads();
     if (rl == 0) {
 #pragma unroll
-        for (int r = 1; r < 32; ++r) m = fmaxf(m, sh[r][cl]);
-        amax[c] = m;
+        for (int r = 1; r < 8; ++r) { const float4 v = sh[r][cq]; m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w); }
+        *(float4 *)(out + (size_t)blockIdx.x * HS_C + 4 * cq) = m;
     }
 }
 
@@ -1365,7 +1390,11 @@ extern "C" int snk_conv3x3_f16s_stats_deferred(const float *d_x, const void *d_w
                                     d_in_scale ? nullptr : amax_part);
     if (rc) return rc;
     tf_fold<double>(d_partials, grid, 256, 256, 1.0, d_sums, (double *)(d_partials + (long)grid * 256), (hipStream_t)stream);
-    if (d_amax) k_amax_fold128<<<HS_C / 8, 256, 0, (hipStream_t)stream>>>(amax_part, grid, d_amax);
+    if (d_amax) {
+        float *stage = d_partials + (long)n_images * T * 384 + TF_SCRATCH_FLOATS(256);
+        k_amax_fold128<<<HS_AMAX_STAGE, 256, 0, (hipStream_t)stream>>>(amax_part, grid, stage);
+        k_amax_fold128<<<1, 256, 0, (hipStream_t)stream>>>(stage, HS_AMAX_STAGE, d_amax);
+    }
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
