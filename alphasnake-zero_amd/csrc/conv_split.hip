@@ -901,6 +901,87 @@ extern "C" int snk_conv3x3_prepare_weights_f16s_train(const float *d_w_hwio, voi
     return 0;
 }
 
+// All tower layers of a training step at once (snake_engine/train_step.py): for every layer i the power-of-two weight scale (once
+// per kernel, shared by its two images), the forward image and -- where h_wS_bwd[i] is given -- the input gradient's image, in TWO
+// launches instead of four per layer and direction.  The images' input scales (tail[2..3]) are NOT set here: the training step has
+// the element-wise kernel that writes a convolution's input leave them there directly (d_out_scale_tail / d_dx_scale_tail =
+// the image's tail), so a weight image is made once per optimizer step and stays valid for as long as the weights do (every
+// forward-only step at learning rate 0 reuses it).
+#define HS_BATCH_MAX 40
+struct F16sBatch { const float *w[HS_BATCH_MAX]; _Float16 *fwd[HS_BATCH_MAX]; _Float16 *bwd[HS_BATCH_MAX]; };
+
+__global__ __launch_bounds__(1024) void k_f16s_wscale_batch(F16sBatch b)
+{
+    __shared__ float red[1024];
+    const float4 *w4 = (const float4 *)b.w[blockIdx.x];
+    float m = 0.f;
+#pragma unroll 12
+    for (int i = threadIdx.x; i < 9 * HS_C * HS_C / 4; i += 1024) {
+        const float4 v = w4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x < 2) {
+        _Float16 *img = threadIdx.x == 0 ? b.fwd[blockIdx.x] : b.bwd[blockIdx.x];
+        if (!img) return;
+        float *tail = (float *)(img + HS_WS_ELEMS);
+        const float mx = red[0];
+        int k = 0;
+        if (mx > 0.f && mx < 3.0e38f) k = 8 - ilogbf(mx);          // as k_f16s_wscale
+        k = max(-100, min(100, k));
+        tail[0] = ldexpf(1.0f, -k);
+        tail[1] = ldexpf(1.0f, k);
+        tail[4] = tail[5] = tail[6] = tail[7] = 0.f;              // range flag, no guard word; tail[2..3] belong to the input's producer
+    }
+}
+
+// grid (pieces / 256, layers, 2 directions); the tails' weight scales were written by k_f16s_wscale_batch (the launch before)
+__global__ __launch_bounds__(256) void k_f16s_weights_batch(F16sBatch b)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;          // one f16x8 fragment piece
+    const bool flip = blockIdx.z != 0;
+    _Float16 *wS = flip ? b.bwd[blockIdx.y] : b.fwd[blockIdx.y];
+    if (v >= HS_WS_ELEMS / 8 || !wS) return;
+    const float *w = b.w[blockIdx.y];
+    const float mul = ((const float *)(wS + HS_WS_ELEMS))[1];
+    const int g = v / 512, rem = v - g * 512;
+    const int c = g / 9, tap = g - 9 * c;                       // (the fragment order of k_f16s_weights)
+    const int wn = rem >> 7, hl = (rem >> 6) & 1, lane = rem & 63;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int cout = 32 * wn + l31;
+    for (int j = 0; j < 8; ++j) {
+        const int cin = HS_KC * c + 8 * h + j;
+        const float val = (flip ? w[(long)((8 - tap) * HS_C + cout) * HS_C + cin] : w[(long)(tap * HS_C + cin) * HS_C + cout]) * mul;
+        const _Float16 hi = (_Float16)val;
+        wS[(long)v * 8 + j] = hl ? (_Float16)(val - (float)hi) : hi;
+    }
+}
+
+extern "C" int snk_conv3x3_prepare_weights_f16s_train_batch(const float *const *h_w_hwio, void *const *h_wS_fwd, void *const *h_wS_bwd,
+                                                            int n_layers, void *stream)
+{
+    SNK_REQUIRE(h_w_hwio && h_wS_fwd && n_layers > 0 && n_layers <= HS_BATCH_MAX,
+                "snk_conv3x3_prepare_weights_f16s_train_batch: 1 .. %d layers per call", HS_BATCH_MAX);
+    F16sBatch b = {};
+    bool any_bwd = false;
+    for (int i = 0; i < n_layers; ++i) {
+        SNK_REQUIRE(h_w_hwio[i] && h_wS_fwd[i], "snk_conv3x3_prepare_weights_f16s_train_batch: NULL kernel or image (layer %d)", i);
+        b.w[i] = h_w_hwio[i];
+        b.fwd[i] = (_Float16 *)h_wS_fwd[i];
+        b.bwd[i] = h_wS_bwd ? (_Float16 *)h_wS_bwd[i] : nullptr;
+        any_bwd = any_bwd || b.bwd[i];
+    }
+    k_f16s_wscale_batch<<<n_layers, 1024, 0, (hipStream_t)stream>>>(b);
+    k_f16s_weights_batch<<<dim3((HS_WS_ELEMS / 8 + 255) / 256, n_layers, any_bwd ? 2 : 1), 256, 0, (hipStream_t)stream>>>(b);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_scale, const float *d_shift,
                             const float *d_residual, float *d_out, const float *d_w1x1, float s1, float b1, float *d_h1,
                             int n_images, int height, int width, int relu, bool split, void *stream, int io16 = 0,

@@ -31,17 +31,24 @@ or read y_l: out_l and its mask bytes are never written nor read -- one element-
 block in EVERY step, the forward-only ones included.  The range the second convolution scales its input by, which
 snk_bn_train_apply measures while it writes, comes from the per-channel maxima the first convolution's epilogue takes next
 to its sums (snk_conv3x3_f16s_stats_deferred -> snk_bn_train_finalize_range).
+
+Weight images (round 5; ``SNK_TRAIN_BATCH_PREP=0`` turns it off): all tower layers' forward and input-gradient images are made in
+two launches per optimizer step (snk_conv3x3_prepare_weights_f16s_train_batch) and kept while the weights stay -- the
+forward-only steps make none.  An image's input scale is written straight into its tail by the kernel that writes the
+convolution's input (``tail_out[l]`` is a view of layer l + 1's forward image, ``tail_dy[l]`` of layer l's input-gradient image).
 """
+import ctypes
 import os
 
 import numpy as np
 import torch
 
 from ._lib import check, lib
-from .net import F16S_WEIGHT_BYTES
+from .net import F16S_TAIL_OFFSET, F16S_WEIGHT_BYTES
 
 _CONV_STATS = os.environ.get("SNK_TRAIN_CONV_STATS", "1") != "0"      # 0: batch-norm sums in a pass of their own (A/B runs)
 _IGRAD_STATS = os.environ.get("SNK_TRAIN_IGRAD_STATS", "1") != "0"    # 0: the batch-norm BACKWARD sums in a pass of their own
+_BATCH_PREP = os.environ.get("SNK_TRAIN_BATCH_PREP", "1") != "0"      # 0: every layer's weight images made one by one, each step (A/B runs)
 _DEFER_BN = os.environ.get("SNK_TRAIN_DEFER_BN", "1") != "0"          # 0: every layer's batch norm + ReLU output is written (A/B runs)
 BN_EPS, BN_MOMENTUM, L2_C = 1e-3, 0.99, 1e-5
 ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-7
@@ -108,14 +115,28 @@ class TrainStep:
         self.inv = [f(C) for _ in range(self.n_layers)]
         self.scale = [f(C) for _ in range(self.n_layers)]
         self.shift = [f(C) for _ in range(self.n_layers)]
+        self.batch_prep = _BATCH_PREP
         self.tail_out = [f(4) for _ in range(self.n_layers)]
         self.relu_mask = [None if self._deferred(l) else f(self.max_rows * self.hw * 32, torch.uint8)
                           for l in range(self.n_layers)]                                                   # 4 bits per byte: out > 0
         self.amax = f(C)
-        self.tail_dy = f(4)
         self.abc = f(3 * C)
-        self.img_f = [torch.empty(F16S_WEIGHT_BYTES, dtype=torch.uint8, device=self.dev) for _ in range(self.n_layers)]
-        self.img_b = torch.empty(F16S_WEIGHT_BYTES, dtype=torch.uint8, device=self.dev)
+        self.img_f = [torch.zeros(F16S_WEIGHT_BYTES, dtype=torch.uint8, device=self.dev) for _ in range(self.n_layers)]
+        tail = lambda img: img[F16S_TAIL_OFFSET:F16S_TAIL_OFFSET + 16].view(torch.float32)
+        if self.batch_prep:
+            # one input-gradient image per layer; the scale tails the element-wise kernels write ARE the images' tails
+            self.img_b_all = [None] + [torch.zeros(F16S_WEIGHT_BYTES, dtype=torch.uint8, device=self.dev) for _ in range(1, self.n_layers)]
+            for l in range(self.n_layers - 1):
+                self.tail_out[l] = tail(self.img_f[l + 1])
+            self.tail_dy_all = [None] + [tail(self.img_b_all[l]) for l in range(1, self.n_layers)]
+            arr = lambda ptrs: (ctypes.c_void_p * len(ptrs))(*ptrs)
+            self._h_w = arr([self.view[self._k(l)].data_ptr() for l in range(1, self.n_layers)])
+            self._h_f = arr([self.img_f[l].data_ptr() for l in range(1, self.n_layers)])
+            self._h_b = arr([self.img_b_all[l].data_ptr() for l in range(1, self.n_layers)])
+        else:
+            self.img_b_all = [None] + [torch.empty(F16S_WEIGHT_BYTES, dtype=torch.uint8, device=self.dev)] * (self.n_layers - 1)
+            self.tail_dy_all = [None] + [f(4)] * (self.n_layers - 1)       # (one buffer: the layers take turns)
+        self.w_version, self.img_version, self.img_has_bwd = 0, -1, False  # weight images are current when img_version == w_version
         self.ones, self.zeros = torch.ones(C, device=self.dev), f(C)
         self.sums, self.sums_local = f(2 * C, torch.float64), f(2 * C, torch.float64)
         self.partials = f(self.L.snk_bn_train_partials())
@@ -136,6 +157,14 @@ class TrainStep:
         self.saved_rows = 0
 
     # ---- small helpers ---------------------------------------------------------------------------------------------
+    def _prepare_images(self, want_bwd):
+        """the tower's weight images, once per set of weights (the batch form; the other form makes them layer by layer in place)"""
+        if not self.batch_prep or (self.img_version == self.w_version and (self.img_has_bwd or not want_bwd)):
+            return
+        check(self.L.snk_conv3x3_prepare_weights_f16s_train_batch(self._h_w, self._h_f, self._h_b if want_bwd else None,
+                                                                  self.n_layers - 1, self._st()))
+        self.img_version, self.img_has_bwd = self.w_version, bool(want_bwd)
+
     def _st(self):
         return torch.cuda.current_stream(self.dev).cuda_stream
 
@@ -174,10 +203,11 @@ class TrainStep:
         check(self.L.snk_conv3x3_bn_f16s(_p(x), _p(image), _p(self.ones), _p(self.zeros), _p(res), _p(out), n, self.h, self.w, 0, self._st()))
 
     # ---- forward ---------------------------------------------------------------------------------------------------
-    def forward(self, x, target, n_global):
+    def forward(self, x, target, n_global, want_bwd=False):
         """x: cuda float32 [n, h, w, 3] contiguous, target: [n, 3] or None; n_global: rows of the batch over all ranks.
         Leaves q in self.q[:n * 3]; the squared-error term of the loss (divided by 3 n_global) goes to G[-1]."""
         L, st = self.L, self._st()
+        self._prepare_images(want_bwd)
         n = int(x.shape[0])
         assert 0 < n <= self.max_rows and x.is_contiguous() and x.dtype == torch.float32 and tuple(x.shape[1:]) == (self.h, self.w, 3)
         count = n_global * self.hw
@@ -186,7 +216,8 @@ class TrainStep:
         self._bn_forward(0, n, count, None, self.out[0], self.tail_out[0])
         for l in range(1, self.n_layers):
             k = self._k(l)
-            check(L.snk_conv3x3_prepare_weights_f16s_train(_p(self.view[k]), _p(self.img_f[l]), _p(self.tail_out[l - 1]), 0, None, st))
+            if not self.batch_prep:
+                check(L.snk_conv3x3_prepare_weights_f16s_train(_p(self.view[k]), _p(self.img_f[l]), _p(self.tail_out[l - 1]), 0, None, st))
             if self._deferred(l - 1):                             # reads y_{l-1} through layer l - 1's batch norm + ReLU
                 check(L.snk_conv3x3_f16s_stats_deferred(_p(self.y[l - 1]), _p(self.img_f[l]), _p(self.y[l]), _p(self.moving[k + 3]),
                                                         _p(self.scale[l - 1]), _p(self.shift[l - 1]), None, _p(self.cv_partials),
@@ -246,6 +277,7 @@ class TrainStep:
 
     def backward(self, target, n_global):
         L, st = self.L, self._st()
+        self._prepare_images(True)
         n = self.saved_rows
         rows, count = n * self.hw, n_global * self.hw
         i, kh = self.fc_idx, self._k(self.n_layers)
@@ -269,6 +301,7 @@ class TrainStep:
         have_sums = False
         for l in range(self.n_layers - 1, 0, -1):
             k, second = self._k(l), l % 2 == 0
+            self.img_b, self.tail_dy = self.img_b_all[l], self.tail_dy_all[l]
             self._bn_backward(l, n, count, want_res=second, tail=self.tail_dy, have_sums=have_sums)   # dA -> dY (+ gres: the shortcut's gradient)
             if self._deferred(l - 1):
                 check(L.snk_conv3x3_wgrad_f16s_deferred(_p(self.y[l - 1]), _p(self.scale[l - 1]), _p(self.shift[l - 1]), _p(self.dY),
@@ -277,7 +310,8 @@ class TrainStep:
             else:
                 check(L.snk_conv3x3_wgrad_f16s(_p(self.out[l - 1]), _p(self.dY), _p(self.tail_out[l - 1]), _p(self.tail_dy),
                                                _p(self.wg_partials), _p(self.gview[k]), n, self.h, self.w, st))
-            check(L.snk_conv3x3_prepare_weights_f16s_train(_p(self.view[k]), _p(self.img_b), _p(self.tail_dy), 1, _p(self.img_f[l]), st))
+            if not self.batch_prep:
+                check(L.snk_conv3x3_prepare_weights_f16s_train(_p(self.view[k]), _p(self.img_b), _p(self.tail_dy), 1, _p(self.img_f[l]), st))
             # gradient at out[l - 1]; its epilogue also takes the two sums the batch-norm backward of layer l - 1 starts with
             have_sums = _IGRAD_STATS and (l - 1) not in self.mask_override
             if have_sums and self._deferred(l - 1):
@@ -298,7 +332,7 @@ class TrainStep:
     def step(self, x, target, n_global, lr):
         """forward, backward, gradient all-reduce, Adam.  Returns a 2-element device tensor {mse, l2 loss} of this step."""
         L, st = self.L, self._st()
-        self.forward(x, target, n_global)
+        self.forward(x, target, n_global, want_bwd=True)
         self.backward(target, n_global)
         self._all_reduce(self.G)                                       # every gradient + the squared-error term, one bucket
         check(L.snk_l2_sum(_p(self.W), _p(self.decay), self.n_params, L2_C, _p(self.l2_partials), _p(self.l2_value), st))
@@ -307,6 +341,7 @@ class TrainStep:
         lr_t = lr * np.sqrt(1.0 - ADAM_B2 ** self.adam_t) / (1.0 - ADAM_B1 ** self.adam_t)
         check(L.snk_adam_l2_step(_p(self.W), _p(self.G), _p(self.M), _p(self.V), _p(self.decay), self.n_params, float(lr_t),
                                  ADAM_B1, ADAM_B2, ADAM_EPS, L2_C, st))
+        self.w_version += 1                                            # the weight images are stale
         return loss
 
     def forward_only(self, x, target, n_global):

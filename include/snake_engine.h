@@ -52,7 +52,7 @@ typedef struct {
 const char *snk_last_error(void);
 #define SNK_ABI_VERSION 111 /* 100: rounds 1-3; 110: round 5 (the gate argument d_skip of the tick kernels, round 4; the 16-bit
                              * towers' own weight image and rectangle plan, round 5); 111: the training step's deferred batch
-                             * norm (seven entry points added, snk_conv3x3_stats_partials returns more): a caller compares it
+                             * norm (eight entry points added, snk_conv3x3_stats_partials returns more): a caller compares it
                              * with snk_version() */
 int snk_version(void);
 
@@ -466,6 +466,14 @@ int snk_bn_train_grad_apply(const float *d_dout, const float *d_out, const uint8
  *   snk_l2_sum               d_out[0] = scale * sum of w[i]^2 over d_decay[i] != 0; d_partials: 1 024 floats                      */
 int snk_conv3x3_prepare_weights_f16s_train(const float *d_w_hwio, void *d_wS, const float *d_in_tail, int input_gradient,
                                            const void *d_wS_same_kernel, void *stream);
+/* The weight images of ALL tower layers of a training step in two launches: h_w_hwio / h_wS_fwd / h_wS_bwd are HOST arrays of
+ * n_layers (<= 40) device pointers -- the Keras kernels, their forward images and (array or entries may be NULL) their
+ * input-gradient images.  Writes every image's fragments, weight scale and a cleared range flag, NOT its input scale: floats 2 and
+ * 3 of the tail at SNK_CONV_F16S_TAIL_OFFSET are left to the kernel that writes the convolution's input (hand that address to
+ * snk_bn_train_apply / snk_bn_train_grad_apply / snk_bn_train_finalize_range as their scale tail).  Images made this way stay
+ * valid while the weights do: the forward-only steps at learning rate 0 (alpha_nnet.py:79-84) reuse them. */
+int snk_conv3x3_prepare_weights_f16s_train_batch(const float *const *h_w_hwio, void *const *h_wS_fwd, void *const *h_wS_bwd,
+                                                 int n_layers, void *stream);
 int snk_stem_conv_f32(const float *d_x, const float *d_w, float *d_out, int n_images, int height, int width, void *stream);
 /* The forward convolution of a tower layer under training: d_out = conv3x3_same(d_x, w), bare (the batch norm comes after), and
  * from the same values on their way out of the kernel d_sums[0..127] = sum (out - center), [128..255] = sum (out - center)^2
