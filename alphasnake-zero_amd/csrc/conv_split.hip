@@ -127,6 +127,7 @@ struct ConvHsArgs {
     // MODE 7 takes the ReLU decision of g_y from the same expression instead of from mask bytes
     const float *aff_scale, *aff_shift;
     float *amax_part;          // MODE 4 (optional): [gridDim.x][128] largest |out - center| per channel over the block's pixels
+    const unsigned char *res_mask;     // MODE 8: ReLU bits (one byte per quad of channels) the shortcut rows are taken through
 };
 
 #ifdef HS_STAMPS       // development build only (tools/conv_stamps.py): s_memtime at the phase boundaries of every block
@@ -169,6 +170,10 @@ extern "C" int snk_dbg_conv_stamps(unsigned long long *h_out, int n_blocks)
 //     462 MB tensors less per block and step); the zero border stays zero (it is the padding of the ACTIVATION)
 //   7 MODE 5 for such a layer below: its ReLU decision is y * aff_scale + aff_shift > 0, recomputed from the g_y values the sums
 //     read anyway (no mask bytes exist for it)
+//   8 MODE 5 whose shortcut gradient is res WHERE res_mask's bit is set: res is then the gradient at the block's OUTPUT as the layer
+//     above received it, res_mask that output's ReLU bits -- the batch-norm backward of the block's second layer no longer writes
+//     the masked copy (462 MB per block) just for this epilogue to read it back.  out may be res itself (a thread reads the rows
+//     it writes, and reads them first)
 #define hs_dpp(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
 // SPLIT = false: the reduced-precision form for BASELINE configs[4] ("bf16 MFMA conv"): the same kernel with the hi parts
 //   only, one MFMA per product instead of three (f16 operands: 11 significand bits against bf16's 8, float32 accumulate).
@@ -190,9 +195,10 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     static_assert(IO16 == 0 || !SPLIT, "f16 activations only exist in the reduced-precision form");
     static_assert(!BF || (IO16 & 1), "the bf16 form reads bf16 activations");
     constexpr bool IN16 = (IO16 & 1) != 0, OUT16 = (IO16 & 2) != 0;
-    constexpr bool STATS = MODE == 4 || MODE == 6, GSTATS = MODE == 5 || MODE == 7, BARE = STATS || GSTATS;
+    constexpr bool STATS = MODE == 4 || MODE == 6, GSTATS = MODE == 5 || MODE == 7 || MODE == 8, BARE = STATS || GSTATS;
+    constexpr bool RESMASK = MODE == 8;
     constexpr bool AFF = MODE == 6, GAFF = MODE == 7;
-    static_assert(!(AFF || GAFF) || (SPLIT && IO16 == 0 && !RECT), "the deferred batch norm exists in the training step's float32 form only");
+    static_assert(!(AFF || GAFF || RESMASK) || (SPLIT && IO16 == 0 && !RECT), "the deferred batch norm exists in the training step's float32 form only");
     constexpr bool K32 = IN16;
     constexpr int RING = K32 ? HS_RING16 : HS_RING, AHEAD = K32 ? HS_AHEAD16 : HS_AHEAD;      // B-fragment register ring: slots (a divisor of 9), taps ahead
     constexpr bool TWO = SPLIT || K32;                     // two A fragments / two B fragments per (tap, M tile)
@@ -202,10 +208,11 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     constexpr bool P8 = IN16 && OUT16;                     // the epilogue handles 8 channels (16 bytes in and out) per thread and row
     // (MODE 7 never takes a shortcut's gradient: it produces the gradient at a block's FIRST layer's output -- its epilogue has the
     // registers the shortcut rows would take for the g_y rows instead, requested a pass ahead)
-    const bool has_res = GAFF ? false : (MODE == 0 || GSTATS) ? p.res != nullptr : (MODE == 2 || MODE == 3);
+    const bool has_res = GAFF ? false : RESMASK ? true : (MODE == 0 || GSTATS) ? p.res != nullptr : (MODE == 2 || MODE == 3);
     const bool has_head = MODE == 0 ? p.w1x1 != nullptr : MODE == 3;
     const bool has_out = MODE == 0 ? p.out != nullptr : MODE != 3;
     const float relu_floor = ((MODE != 0 && !BARE) || (MODE == 0 && p.relu)) ? 0.f : -__builtin_inff();
+    (void)has_head; (void)has_out; (void)relu_floor;       // (the input-gradient epilogue uses none of them)
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;        // wave wn owns outputs 32 wn .. 32 wn + 31
     const int h = lane >> 5, l31 = lane & 31;
     const int Wr = RECT ? rw : p.Wd;                       // width of the GEMM's image
@@ -547,6 +554,108 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
                 *(f16x8 *)((_Float16 *)p.out + (long)img * HWc * HS_C + o_) = *(const f16x8 *)((const _Float16 *)p.bg_out + o_);
             }
         }
+    } else if constexpr (GSTATS) {
+    // ---- the training step's input-gradient epilogue (MODE 5 / 7 / 8): the same 64-row exchange; everything a pass needs from HBM --
+    //      the shortcut rows, the g_y rows, the mask bytes -- is requested in ONE batch before the pass is exchanged, at clamped
+    //      addresses, and NO branch surrounds a load or a store: rows past the block's pixels are computed, kept out of the sums by
+    //      their mask, and stored to an offset the image's buffer descriptor drops.  (Round 5's first form kept the g_y row and
+    //      the mask byte inside `if (row is the block's)`: the compiler then waited vmcnt(0) in every row -- for the row's own two
+    //      loads AND for the previous row's store -- 28 HBM round trips one after the other per thread and block, which is what
+    //      made this launch 0.11 ms slower than the bare convolution.)  MODE 7 has no shortcut rows and holds the g_y rows of TWO
+    //      passes instead: requested a pass ahead, the first pass's under the last chunk above.
+    const int cq = tid & 31, rr0 = tid >> 5;
+    const float winv = p.wscale_inv[0] * p.wscale_inv[3];
+    const float4 cen4 = *(const float4 *)(p.center + 4 * cq), iv4 = *(const float4 *)(p.g_inv + 4 * cq);
+    float4 gsc = cen4, gsh = cen4;
+    if (GAFF) { gsc = *(const float4 *)(p.aff_scale + 4 * cq); gsh = *(const float4 *)(p.aff_shift + 4 * cq); }
+    float4 st_s = make_float4(0.f, 0.f, 0.f, 0.f), st_q = st_s;
+    float *Ms = (float *)smem;                                      // [2][64 rows][HS_MLD]
+    // every tensor through a buffer descriptor of the IMAGE: one offset register serves all rows of all passes (a row is a constant
+    // further on), and what lies past the image reads as zero (mask byte 0: out of the sums)
+    const long ielem = (long)img * HWc * HS_C;
+    const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(p.out + ielem), 0, HWc * HS_C * 4, 0x00020000);
+    const auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(p.g_y + ielem), 0, HWc * HS_C * 4, 0x00020000);
+    const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((has_res ? p.res : p.g_y) + ielem), 0, HWc * HS_C * 4, 0x00020000);
+    const auto m_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((GAFF ? (const unsigned char *)p.g_y : p.g_mask) + (ielem >> 2)), 0, HWc * (HS_C / 4), 0x00020000);
+    const auto q_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((RESMASK ? p.res_mask : (const unsigned char *)p.g_y) + (ielem >> 2)), 0, HWc * (HS_C / 4), 0x00020000);
+    const unsigned vo4 = (unsigned)((m0 + rr0) * HS_C + 4 * cq) * 4u, vo1 = (unsigned)((m0 + rr0) * (HS_C / 4) + cq);
+    constexpr int NPASS = (NI + 1) / 2;
+    float4 rv[8], yv[GAFF ? 1 : 8];
+    unsigned mbv[GAFF ? 1 : 8], rmv[RESMASK ? 8 : 1];
+#define HS_ROWS(pass) (((pass) + 1 < NPASS ? 2 : NI - 2 * (NPASS - 1)) * 32)
+#define HS_LD4(rsrc, pass, j) __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo4, (64 * (pass) + 8 * (j)) * HS_C * 4, 0))
+#define HS_LD1(rsrc, pass, j) (unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(rsrc, vo1, (64 * (pass) + 8 * (j)) * (HS_C / 4), 0)
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < HS_ROWS(pass) / 8; ++j) {
+            if (!GAFF) rv[j] = HS_LD4(r_rsrc, pass, j);      // (MODE 5 without a shortcut: the row is read -- through g_y's descriptor -- and not used)
+            if (RESMASK) rmv[j] = HS_LD1(q_rsrc, pass, j);
+            if (!GAFF) { yv[j] = HS_LD4(y_rsrc, pass, j); mbv[j] = HS_LD1(m_rsrc, pass, j); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float *Mb = Ms + (pass & 1) * (64 * HS_MLD);
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+            if (2 * pass + ii < NI) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Mb[(32 * ii + (r & 3) + 8 * (r >> 2) + 4 * h) * HS_MLD + 32 * wn + l31] = acc[2 * pass + ii][r];
+            }
+        __syncthreads();
+        float4 m[8];
+#pragma unroll
+        for (int j = 0; j < HS_ROWS(pass) / 8; ++j) m[j] = *(const float4 *)&Mb[(rr0 + 8 * j) * HS_MLD + 4 * cq];
+        if (GAFF && pass + 1 < NPASS) {
+#pragma unroll
+            for (int j = 0; j < HS_ROWS(pass + 1) / 8; ++j) gyv[(pass + 1) & 1][j] = HS_LD4(y_rsrc, pass + 1, j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < HS_ROWS(pass) / 8; ++j) {
+            const bool mine = m0 + 64 * pass + rr0 + 8 * j < m1;
+            float4 v = m[j];
+            v.x = __builtin_fmaf(v.x, winv, 0.f); v.y = __builtin_fmaf(v.y, winv, 0.f);
+            v.z = __builtin_fmaf(v.z, winv, 0.f); v.w = __builtin_fmaf(v.w, winv, 0.f);
+            if (has_res) {
+                float4 r_ = rv[j];
+                if (RESMASK) r_ = make_float4((rmv[j] & 1u) ? r_.x : 0.f, (rmv[j] & 2u) ? r_.y : 0.f, (rmv[j] & 4u) ? r_.z : 0.f, (rmv[j] & 8u) ? r_.w : 0.f);
+                v.x += r_.x; v.y += r_.y; v.z += r_.z; v.w += r_.w;
+            }
+            const float4 y_ = GAFF ? gyv[pass & 1][j] : yv[j];
+            bool bx, by, bz, bw;
+            if (GAFF) {                      // the layer's output was never written: its sign is that of k_bn_apply's expression
+                bx = y_.x * gsc.x + gsh.x > 0.f; by = y_.y * gsc.y + gsh.y > 0.f; bz = y_.z * gsc.z + gsh.z > 0.f; bw = y_.w * gsc.w + gsh.w > 0.f;
+            } else { bx = mbv[j] & 1u; by = mbv[j] & 2u; bz = mbv[j] & 4u; bw = mbv[j] & 8u; }
+            const float gx = (mine && bx) ? v.x : 0.f, gy = (mine && by) ? v.y : 0.f, gz = (mine && bz) ? v.z : 0.f, gw = (mine && bw) ? v.w : 0.f;
+            st_s.x += gx; st_s.y += gy; st_s.z += gz; st_s.w += gw;
+            st_q.x += gx * ((y_.x - cen4.x) * iv4.x); st_q.y += gy * ((y_.y - cen4.y) * iv4.y);
+            st_q.z += gz * ((y_.z - cen4.z) * iv4.z); st_q.w += gw * ((y_.w - cen4.w) * iv4.w);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, v), o_rsrc, mine ? vo4 : 0x80000000u,
+                                                   (64 * pass + 8 * j) * HS_C * 4, 0);
+            // gfx950 reads a 16-byte store's data registers over several cycles; the compiler guards a VALU write to them that follows at
+            // once only when the store has NO scalar offset (measured here: rows whose data register pair was rewritten by the
+            // next row's v_pk_fma_f32 in the cycle after the store reached HBM with the NEXT row's values in the last four lanes of
+            // every sixteen, tools/dbg/igrad_dbg.py) -- so: wait states by hand, and nothing scheduled across them
+            asm volatile("s_nop 2");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef HS_ROWS
+#undef HS_LD4
+#undef HS_LD1
+    __syncthreads();                       // the eight row lanes' sums of a channel quad are added through LDS, in a fixed order
+    float4 *R = (float4 *)smem;            // [2][8][32]
+    R[rr0 * 32 + cq] = st_s;
+    R[(8 + rr0) * 32 + cq] = st_q;
+    __syncthreads();
+    if (rr0 < 2) {
+        float4 t = R[(8 * rr0) * 32 + cq];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) { const float4 u = R[(8 * rr0 + r) * 32 + cq]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        *(float4 *)(p.stat_part + (size_t)blockIdx.x * 256 + rr0 * 128 + 4 * cq) = t;
+    }
     } else {
     const int cq = tid & 31, rr0 = tid >> 5;
     const float winv = p.wscale_inv[0] * p.wscale_inv[3];
@@ -555,10 +664,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     sc4.x *= winv; sc4.y *= winv; sc4.z *= winv; sc4.w *= winv;
     float4 cen4 = make_float4(0.f, 0.f, 0.f, 0.f), st_s = cen4, st_q = cen4;
     if (BARE && p.center) cen4 = *(const float4 *)(p.center + 4 * cq);
-    float4 iv4 = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (GSTATS) iv4 = *(const float4 *)(p.g_inv + 4 * cq);
-    float4 gsc = cen4, gsh = cen4, st_m = cen4;
-    if (GAFF) { gsc = *(const float4 *)(p.aff_scale + 4 * cq); gsh = *(const float4 *)(p.aff_shift + 4 * cq); }
+    float4 st_m = cen4;
     float *Ms = (float *)smem;                                      // [2][64 rows][HS_MLD]
     const long obase = (long)img * HWc * HS_C + 4 * cq;
     float4 wh = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -609,11 +715,6 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
         float4 m[8];
 #pragma unroll
         for (int j = 0; j < HS_ROWS(pass) / 8; ++j) m[j] = *(const float4 *)&Mb[(rr0 + 8 * j) * HS_MLD + 4 * cq];
-        if (GAFF && pass + 1 < NPASS) {
-#pragma unroll
-            for (int j = 0; j < HS_ROWS(pass + 1) / 8; ++j)
-                gyv[(pass + 1) & 1][j] = *(const float4 *)(p.g_y + obase + max(off[(pass + 1) & 1][j], 0));
-        }
 #pragma unroll
         for (int j = 0; j < HS_ROWS(pass) / 8; ++j) {
             float4 v = m[j];
@@ -624,21 +725,6 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
                 v.x += r_.x; v.y += r_.y; v.z += r_.z; v.w += r_.w;
             }
             v.x = fmaxf(v.x, relu_floor); v.y = fmaxf(v.y, relu_floor); v.z = fmaxf(v.z, relu_floor); v.w = fmaxf(v.w, relu_floor);
-            if (GSTATS && off[pass & 1][j] >= 0) {
-                const long e_ = obase + off[pass & 1][j];
-                const float4 y_ = GAFF ? gyv[pass & 1][j] : *(const float4 *)(p.g_y + e_);
-                float gx, gy, gz, gw;
-                if (GAFF) {                  // the layer's output was never written: its sign is that of k_bn_apply's expression
-                    gx = y_.x * gsc.x + gsh.x > 0.f ? v.x : 0.f; gy = y_.y * gsc.y + gsh.y > 0.f ? v.y : 0.f;
-                    gz = y_.z * gsc.z + gsh.z > 0.f ? v.z : 0.f; gw = y_.w * gsc.w + gsh.w > 0.f ? v.w : 0.f;
-                } else {
-                    const unsigned mb_ = p.g_mask[e_ >> 2];
-                    gx = (mb_ & 1u) ? v.x : 0.f; gy = (mb_ & 2u) ? v.y : 0.f; gz = (mb_ & 4u) ? v.z : 0.f; gw = (mb_ & 8u) ? v.w : 0.f;
-                }
-                st_s.x += gx; st_s.y += gy; st_s.z += gz; st_s.w += gw;
-                st_q.x += gx * ((y_.x - cen4.x) * iv4.x); st_q.y += gy * ((y_.y - cen4.y) * iv4.y);
-                st_q.z += gz * ((y_.z - cen4.z) * iv4.z); st_q.w += gw * ((y_.w - cen4.w) * iv4.w);
-            }
             if (STATS && off[pass & 1][j] >= 0) {
                 const float ex = v.x - cen4.x, ey = v.y - cen4.y, ez = v.z - cen4.z, ew = v.w - cen4.w;
                 st_s.x += ex; st_s.y += ey; st_s.z += ez; st_s.w += ew;
@@ -987,10 +1073,12 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
                             int n_images, int height, int width, int relu, bool split, void *stream, int io16 = 0,
                             const float *d_center = nullptr, float *d_stat_part = nullptr, int *grid_out = nullptr, bool bf = false,
                             const float *d_gy = nullptr, const unsigned char *d_gmask = nullptr, const float *d_ginv = nullptr,
-                            const float *d_aff_scale = nullptr, const float *d_aff_shift = nullptr, float *d_amax_part = nullptr)
+                            const float *d_aff_scale = nullptr, const float *d_aff_shift = nullptr, float *d_amax_part = nullptr,
+                            const unsigned char *d_res_mask = nullptr)
 {
     SNK_REQUIRE(n_images >= 0 && height >= 1 && width >= 3, "snk_conv3x3_bn_f16s: bad shape %d x %d x %d", n_images, height, width);
     SNK_REQUIRE(d_out != d_x, "snk_conv3x3_bn_f16s: in-place convolution is not possible (blocks read their neighbours' input rows)");
+    SNK_REQUIRE(d_out != d_residual || d_res_mask, "snk_conv3x3_bn_f16s: the output may overwrite the shortcut in the masked-shortcut form only");
     if (n_images == 0) return 0;
     const int P = width + 1, HW = height * width;
     const bool a16 = (io16 & 1) != 0;                      // the 16-bit frame: LDS rows pitched in bytes, six staging items
@@ -1021,7 +1109,7 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
     ConvHsArgs a = {d_x, (const f16x8 *)d_wS, (const float *)((const _Float16 *)d_wS + HS_WS_ELEMS), d_scale, d_shift,
                     d_residual, d_out, d_w1x1, d_h1, s1, b1, height, width, n_blk, tiles_base, tiles_rem, relu, (n_images / 8) * 8,
                     d_center, d_stat_part, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, d_gy, d_gmask, d_ginv,
-                    d_aff_scale, d_aff_shift, d_amax_part};
+                    d_aff_scale, d_aff_shift, d_amax_part, d_res_mask};
     const int n_mt = tiles_max, grid = n_images * n_blk;
     hipStream_t st = (hipStream_t)stream;
     if (grid_out) *grid_out = grid;
@@ -1040,6 +1128,7 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
         return 0;
     SNK_REQUIRE(!(d_stat_part && a.g_y && d_aff_scale && d_residual),
                 "snk_conv3x3_f16s_igrad_stats_deferred: the layer below a block's second convolution has no shortcut gradient to add");
+    if (d_stat_part && a.g_y && d_res_mask) { HS_LAUNCH_TRAIN(8) }     // input gradient + sums, the shortcut's gradient taken through ReLU bits
     if (d_stat_part && a.g_y && d_aff_scale) { HS_LAUNCH_TRAIN(7) }    // ... of a layer whose ReLU decision is recomputed from its scale / shift
     if (d_stat_part && d_aff_scale) { HS_LAUNCH_TRAIN(6) }             // forward pass, the producer's batch norm + ReLU applied on the way in
 #undef HS_LAUNCH_TRAIN
@@ -1559,6 +1648,26 @@ extern "C" int snk_conv3x3_f16s_igrad_stats_deferred(const float *d_x, const voi
     int grid = 0;
     const int rc = conv_f16s_launch(d_x, d_wS, nullptr, nullptr, d_residual, d_out, nullptr, 0.f, 0.f, nullptr, n_images, height, width, 0,
                                     true, stream, 0, d_mean, d_partials, &grid, false, d_y, nullptr, d_inv, d_scale, d_shift);
+    if (rc) return rc;
+    tf_fold<double>(d_partials, grid, 256, 256, 1.0, d_sums, (double *)(d_partials + (long)grid * 256), (hipStream_t)stream);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// snk_conv3x3_f16s_igrad_stats whose shortcut gradient is d_residual WHERE d_residual_mask's bit is set: d_residual = the gradient
+// at the residual block's output (before that output's ReLU), d_residual_mask = that output's ReLU bits (snk_bn_train_apply's
+// bytes) -- the masked copy snk_bn_train_grad_apply(d_g) writes is not needed.  d_out may be d_residual (in place).
+extern "C" int snk_conv3x3_f16s_igrad_stats_masked_res(const float *d_x, const void *d_wS, const float *d_residual,
+                                                       const uint8_t *d_residual_mask, float *d_out, const float *d_y,
+                                                       const uint8_t *d_mask, const float *d_mean, const float *d_inv, float *d_partials,
+                                                       double *d_sums, int n_images, int height, int width, void *stream)
+{
+    SNK_REQUIRE(d_x && d_wS && d_residual && d_residual_mask && d_out && d_y && d_mask && d_mean && d_inv && d_partials && d_sums &&
+                n_images > 0, "snk_conv3x3_f16s_igrad_stats_masked_res: bad argument");
+    int grid = 0;
+    const int rc = conv_f16s_launch(d_x, d_wS, nullptr, nullptr, d_residual, d_out, nullptr, 0.f, 0.f, nullptr, n_images, height, width, 0,
+                                    true, stream, 0, d_mean, d_partials, &grid, false, d_y, d_mask, d_inv, nullptr, nullptr, nullptr,
+                                    d_residual_mask);
     if (rc) return rc;
     tf_fold<double>(d_partials, grid, 256, 256, 1.0, d_sums, (double *)(d_partials + (long)grid * 256), (hipStream_t)stream);
     SNK_CHECK_HIP(hipGetLastError());

@@ -120,6 +120,7 @@ PROTOTYPES = {
     "snk_conv3x3_f16s_igrad_stats_deferred": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "snk_bn_train_grad_sums_f64_deferred": (i32, [vp, vp, vp, vp, vp, vp, C.c_long, vp, vp, vp]),
     "snk_bn_train_grad_apply_deferred": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_long, vp, vp, vp]),
+    "snk_conv3x3_f16s_igrad_stats_masked_res": (i32, [vp] * 11 + [i32, i32, i32, vp]),
     "snk_stem_wgrad_partials": (C.c_long, [i32, i32, i32]),
     "snk_stem_wgrad_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "snk_bn_train_sums_f64": (i32, [vp, C.c_long, vp, vp, vp, vp]),

@@ -32,6 +32,13 @@ block in EVERY step, the forward-only ones included.  The range the second convo
 snk_bn_train_apply measures while it writes, comes from the per-channel maxima the first convolution's epilogue takes next
 to its sums (snk_conv3x3_f16s_stats_deferred -> snk_bn_train_finalize_range).
 
+The shortcut's gradient (round 5; ``SNK_TRAIN_RES_MASK=0`` turns it off): the gradient a residual block hands to its shortcut is
+the gradient at the block's output where that output's ReLU let the value through.  The batch-norm backward of the block's second
+layer no longer writes that masked copy (462 MB per block): the gradient it READ stays where it is (the block's two
+input-gradient launches alternate between two buffers), and the input-gradient launch of the block's first layer, which adds
+the shortcut's gradient in its epilogue, takes it from there through the output's mask bytes
+(snk_conv3x3_f16s_igrad_stats_masked_res), in place.
+
 Weight images (round 5; ``SNK_TRAIN_BATCH_PREP=0`` turns it off): all tower layers' forward and input-gradient images are made in
 two launches per optimizer step (snk_conv3x3_prepare_weights_f16s_train_batch) and kept while the weights stay -- the
 forward-only steps make none.  An image's input scale is written straight into its tail by the kernel that writes the
@@ -49,6 +56,7 @@ from .net import F16S_TAIL_OFFSET, F16S_WEIGHT_BYTES
 _CONV_STATS = os.environ.get("SNK_TRAIN_CONV_STATS", "1") != "0"      # 0: batch-norm sums in a pass of their own (A/B runs)
 _IGRAD_STATS = os.environ.get("SNK_TRAIN_IGRAD_STATS", "1") != "0"    # 0: the batch-norm BACKWARD sums in a pass of their own
 _BATCH_PREP = os.environ.get("SNK_TRAIN_BATCH_PREP", "1") != "0"      # 0: every layer's weight images made one by one, each step (A/B runs)
+_RES_MASK = os.environ.get("SNK_TRAIN_RES_MASK", "1") != "0"          # 0: the shortcut's gradient is written as a masked copy (A/B runs)
 _DEFER_BN = os.environ.get("SNK_TRAIN_DEFER_BN", "1") != "0"          # 0: every layer's batch norm + ReLU output is written (A/B runs)
 BN_EPS, BN_MOMENTUM, L2_C = 1e-3, 0.99, 1e-5
 ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-7
@@ -110,7 +118,9 @@ class TrainStep:
         act = self.max_rows * self.hw * C
         self.y = [f(act) for _ in range(self.n_layers)]
         self.out = [None if self._deferred(l) else f(act) for l in range(self.n_layers)]
+        self.res_mask = bool(_RES_MASK and _IGRAD_STATS)
         self.dA, self.dY, self.gres = f(act), f(act), f(act)
+        self.dA2 = f(act) if self.res_mask else None
         self.mean = [f(C) for _ in range(self.n_layers)]
         self.inv = [f(C) for _ in range(self.n_layers)]
         self.scale = [f(C) for _ in range(self.n_layers)]
@@ -248,16 +258,17 @@ class TrainStep:
         return self.q[:3 * n].view(n, 3)
 
     # ---- backward --------------------------------------------------------------------------------------------------
-    def _bn_backward(self, l, n, count, want_res, tail, have_sums=False):
+    def _bn_backward(self, l, n, count, want_res, tail, have_sums=False, src=None):
         L, st, rows, k = self.L, self._st(), n * self.hw, self._k(l)
+        src = self.dA if src is None else src                     # the gradient at out_l
         sign = self.mask_override.get(l)                          # tests: a tensor whose sign replaces the recorded ReLU mask
         bits = None if sign is not None else self.relu_mask[l]
         deferred = sign is None and self._deferred(l)             # no mask bytes: the decision is recomputed from y_l, scale_l, shift_l
         if not have_sums and deferred:
-            check(L.snk_bn_train_grad_sums_f64_deferred(_p(self.dA), _p(self.y[l]), _p(self.scale[l]), _p(self.shift[l]), _p(self.mean[l]),
+            check(L.snk_bn_train_grad_sums_f64_deferred(_p(src), _p(self.y[l]), _p(self.scale[l]), _p(self.shift[l]), _p(self.mean[l]),
                                                         _p(self.inv[l]), rows, _p(self.partials), _p(self.sums), st))
         elif not have_sums:                                       # the input-gradient convolution above took them on its way out
-            check(L.snk_bn_train_grad_sums_f64(_p(self.dA), _p(sign), _p(bits), _p(self.y[l]), _p(self.mean[l]), _p(self.inv[l]), rows, 1,
+            check(L.snk_bn_train_grad_sums_f64(_p(src), _p(sign), _p(bits), _p(self.y[l]), _p(self.mean[l]), _p(self.inv[l]), rows, 1,
                                                _p(self.partials), _p(self.sums), st))
         local = self.sums
         if self.dist is not None:
@@ -268,11 +279,11 @@ class TrainStep:
         check(L.snk_bn_train_grad_finalize(_p(self.sums), _p(local), float(count), _p(self.view[k + 1]), _p(self.inv[l]), _p(a), _p(b), _p(c),
                                            _p(self.gview[k + 1]), _p(self.gview[k + 2]), C, st))
         if deferred:
-            check(L.snk_bn_train_grad_apply_deferred(_p(self.dA), _p(self.y[l]), _p(self.scale[l]), _p(self.shift[l]), _p(self.mean[l]),
+            check(L.snk_bn_train_grad_apply_deferred(_p(src), _p(self.y[l]), _p(self.scale[l]), _p(self.shift[l]), _p(self.mean[l]),
                                                      _p(self.inv[l]), _p(a), _p(b), _p(c), _p(self.dY),
                                                      _p(self.gres) if want_res else None, rows, _p(self.partials), _p(tail), st))
             return
-        check(L.snk_bn_train_grad_apply(_p(self.dA), _p(sign), _p(bits), _p(self.y[l]), _p(self.mean[l]), _p(self.inv[l]), _p(a), _p(b), _p(c),
+        check(L.snk_bn_train_grad_apply(_p(src), _p(sign), _p(bits), _p(self.y[l]), _p(self.mean[l]), _p(self.inv[l]), _p(a), _p(b), _p(c),
                                         _p(self.dY), _p(self.gres) if want_res else None, rows, 1, _p(self.partials), _p(tail), st))
 
     def backward(self, target, n_global):
@@ -299,10 +310,14 @@ class TrainStep:
         check(L.snk_head_conv1x1_bwd(_p(self.g1), _p(self.z), _p(self.h_mean_inv), _p(self.h_abc), _p(self.out[-1]), _p(self.view[kh]),
                                      _p(self.dA), _p(self.gview[kh]), _p(self.partials), rows, st))
         have_sums = False
+        A, B, masked = self.dA, self.dA2, False                   # A holds the gradient a block receives at its output
         for l in range(self.n_layers - 1, 0, -1):
             k, second = self._k(l), l % 2 == 0
             self.img_b, self.tail_dy = self.img_b_all[l], self.tail_dy_all[l]
-            self._bn_backward(l, n, count, want_res=second, tail=self.tail_dy, have_sums=have_sums)   # dA -> dY (+ gres: the shortcut's gradient)
+            if second:                                            # this block leaves its shortcut's gradient in A, unmasked and unwritten?
+                masked = self.res_mask and not {l, l - 2} & set(self.mask_override)
+            src = B if (masked and not second) else A
+            self._bn_backward(l, n, count, want_res=second and not masked, tail=self.tail_dy, have_sums=have_sums, src=src)   # -> dY (+ gres)
             if self._deferred(l - 1):
                 check(L.snk_conv3x3_wgrad_f16s_deferred(_p(self.y[l - 1]), _p(self.scale[l - 1]), _p(self.shift[l - 1]), _p(self.dY),
                                                         _p(self.tail_out[l - 1]), _p(self.tail_dy), _p(self.wg_partials),
@@ -314,17 +329,24 @@ class TrainStep:
                 check(L.snk_conv3x3_prepare_weights_f16s_train(_p(self.view[k]), _p(self.img_b), _p(self.tail_dy), 1, _p(self.img_f[l]), st))
             # gradient at out[l - 1]; its epilogue also takes the two sums the batch-norm backward of layer l - 1 starts with
             have_sums = _IGRAD_STATS and (l - 1) not in self.mask_override
-            if have_sums and self._deferred(l - 1):
-                check(L.snk_conv3x3_f16s_igrad_stats_deferred(_p(self.dY), _p(self.img_b), _p(None if second else self.gres), _p(self.dA),
+            dst = B if (masked and second) else A                 # (a block's second layer must not overwrite what its shortcut still needs)
+            res = None if second else (A if masked else self.gres)
+            if masked and not second:
+                check(L.snk_conv3x3_f16s_igrad_stats_masked_res(_p(self.dY), _p(self.img_b), _p(A), _p(self.relu_mask[l + 1]), _p(A),
+                                                                _p(self.y[l - 1]), _p(self.relu_mask[l - 1]), _p(self.mean[l - 1]),
+                                                                _p(self.inv[l - 1]), _p(self.cv_partials), _p(self.sums), n, self.h,
+                                                                self.w, st))
+            elif have_sums and self._deferred(l - 1):
+                check(L.snk_conv3x3_f16s_igrad_stats_deferred(_p(self.dY), _p(self.img_b), _p(res), _p(dst),
                                                               _p(self.y[l - 1]), _p(self.scale[l - 1]), _p(self.shift[l - 1]),
                                                               _p(self.mean[l - 1]), _p(self.inv[l - 1]), _p(self.cv_partials),
                                                               _p(self.sums), n, self.h, self.w, st))
             elif have_sums:
-                check(L.snk_conv3x3_f16s_igrad_stats(_p(self.dY), _p(self.img_b), _p(None if second else self.gres), _p(self.dA),
+                check(L.snk_conv3x3_f16s_igrad_stats(_p(self.dY), _p(self.img_b), _p(res), _p(dst),
                                                      _p(self.y[l - 1]), _p(self.relu_mask[l - 1]), _p(self.mean[l - 1]), _p(self.inv[l - 1]),
                                                      _p(self.cv_partials), _p(self.sums), n, self.h, self.w, st))
             else:
-                self._conv(self.dY, self.img_b, None if second else self.gres, self.dA, n)
+                self._conv(self.dY, self.img_b, res, dst, n)
         self._bn_backward(0, n, count, want_res=False, tail=None, have_sums=have_sums)
         check(L.snk_stem_wgrad_f32(_p(self.x0), _p(self.dY), _p(self.sw_partials), _p(self.gview[0]), n, self.h, self.w, st))
 

@@ -52,7 +52,7 @@ typedef struct {
 const char *snk_last_error(void);
 #define SNK_ABI_VERSION 111 /* 100: rounds 1-3; 110: round 5 (the gate argument d_skip of the tick kernels, round 4; the 16-bit
                              * towers' own weight image and rectangle plan, round 5); 111: the training step's deferred batch
-                             * norm (eight entry points added, snk_conv3x3_stats_partials returns more): a caller compares it
+                             * norm (nine entry points added, snk_conv3x3_stats_partials returns more): a caller compares it
                              * with snk_version() */
 int snk_version(void);
 
@@ -525,6 +525,14 @@ int snk_bn_train_grad_sums_f64_deferred(const float *d_dout, const float *d_y, c
 int snk_bn_train_grad_apply_deferred(const float *d_dout, const float *d_y, const float *d_scale, const float *d_shift,
                                      const float *d_mean, const float *d_inv, const float *d_a, const float *d_b, const float *d_c,
                                      float *d_dx, float *d_g, long rows, float *d_partials, float *d_dx_scale_tail, void *stream);
+/* snk_conv3x3_f16s_igrad_stats whose shortcut gradient is d_residual WHERE d_residual_mask's bit is set: d_residual = the
+ * gradient at the residual block's output as the layer above delivered it (before that output's ReLU), d_residual_mask = that
+ * output's ReLU bits (snk_bn_train_apply's bytes).  The masked copy snk_bn_train_grad_apply(d_g) would write for this epilogue
+ * (462 MB per block at 2 048 x 21 x 21) is then not needed.  d_out may be d_residual (in place). */
+int snk_conv3x3_f16s_igrad_stats_masked_res(const float *d_x, const void *d_wS, const float *d_residual,
+                                            const uint8_t *d_residual_mask, float *d_out, const float *d_y, const uint8_t *d_mask,
+                                            const float *d_mean, const float *d_inv, float *d_partials, double *d_sums,
+                                            int n_images, int height, int width, void *stream);
 long snk_stem_wgrad_partials(int n_images, int height, int width);
 int snk_stem_wgrad_f32(const float *d_x, const float *d_dy, float *d_partials, float *d_dw, int n_images, int height, int width,
                        void *stream);

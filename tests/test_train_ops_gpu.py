@@ -449,6 +449,49 @@ def test_deferred_batch_norm_reads_the_same_values_as_the_written_activation(tor
         assert np.abs(u - v).max() <= 1e-6 * max(np.abs(u).max(), 1e-12), j
 
 
+@pytest.mark.parametrize("n,blocks,hw", [(24, 2, 21), (6, 1, 37), (10, 3, 13)])
+def test_shortcut_gradient_through_the_mask_bytes_equals_the_masked_copy(torch_gpu, monkeypatch, n, blocks, hw):
+    """round 5: the batch-norm backward of a block's second layer no longer writes dout * mask for the shortcut; the
+    input-gradient launch of the block's first layer reads the gradient the block RECEIVED through the output's mask bytes
+    (snk_conv3x3_f16s_igrad_stats_masked_res), in place.  Same values added in the same order: every gradient of a whole
+    step is bit-identical, and so are the entry point's tensor and sums (alpha_nnet.py:25-47 under Keras fit)"""
+    torch = torch_gpu
+    from snake_engine import net, train_step
+    from snake_engine._lib import lib, check
+    from snake_engine.train_step import _p
+    rs = np.random.RandomState(200 + n)
+    X = torch.as_tensor(rs.rand(n, hw, hw, 3).astype(np.float32), device="cuda")
+    Y = torch.as_tensor(np.tanh(rs.randn(n, 3)).astype(np.float32), device="cuda")
+    ws = net.glorot_uniform_weights((hw, hw, 3), blocks=blocks, seed=8)
+    grads = {}
+    for masked in (True, False):
+        monkeypatch.setattr(train_step, "_RES_MASK", masked)
+        ts = train_step.TrainStep(ws, (hw, hw, 3), n, "cuda")
+        assert ts.res_mask == masked
+        ts.forward(X, Y, n)
+        ts.backward(Y, n)
+        grads[masked] = ts.gradients()
+    for j in grads[True]:
+        assert np.array_equal(grads[True][j], grads[False][j]), j
+    # the entry point: shortcut rows through mask bytes == the masked copy as shortcut, also when the output overwrites the rows
+    L, st = lib(), torch.cuda.current_stream().cuda_stream
+    act = n * hw * hw * 128
+    g = torch.Generator(device="cuda").manual_seed(n)
+    R = torch.randn(act, device="cuda", generator=g) * 1e-3
+    M = ts.relu_mask[2][:act // 4]
+    bits = torch.stack([(M >> b) & 1 for b in range(4)], dim=1).reshape(-1).bool()
+    RM = torch.where(bits, R, torch.zeros_like(R))
+    out_a, out_b = torch.empty(act, device="cuda"), R.clone()
+    sums, ref = torch.zeros(256, dtype=torch.float64, device="cuda"), torch.zeros(256, dtype=torch.float64, device="cuda")
+    l = 1                                                  # the launch below layer 1: sums for layer 0 (the stem's batch norm)
+    check(L.snk_conv3x3_f16s_igrad_stats(_p(ts.dY), _p(ts.img_b), _p(RM), _p(out_a), _p(ts.y[l - 1]), _p(ts.relu_mask[l - 1]),
+                                         _p(ts.mean[l - 1]), _p(ts.inv[l - 1]), _p(ts.cv_partials), _p(ref), n, hw, hw, st))
+    check(L.snk_conv3x3_f16s_igrad_stats_masked_res(_p(ts.dY), _p(ts.img_b), _p(out_b), _p(M), _p(out_b), _p(ts.y[l - 1]),
+                                                    _p(ts.relu_mask[l - 1]), _p(ts.mean[l - 1]), _p(ts.inv[l - 1]), _p(ts.cv_partials),
+                                                    _p(sums), n, hw, hw, st))
+    assert torch.equal(out_a, out_b) and torch.equal(sums, ref) and float(ref.abs().max()) > 0
+
+
 def test_fit_on_the_kernels_tracks_fit_with_library_operators(torch_gpu):
     """utils.trainer_torch.fit on the same rows and shuffle order on this library's kernels and with every operator from
     PyTorch / MIOpen (SNK_TRAIN_CONV=torch).  Adam's first steps move every weight by about lr * sign(gradient), so weights
