@@ -17,6 +17,7 @@
 // the f32 MFMA's two k-slots only have to agree between A and B.  Global -> LDS staging is
 // register double-buffered: the loads of chunk c+1 are issued before the 64 MFMAs of chunk c.
 #include "common.h"
+#include "train_fold.h"
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -428,6 +429,8 @@ struct StemArgs {
     const unsigned *bbox; // k_stem_conv_mfma only, or NULL: per image y0 | x0 << 8 | y1 << 16 | x1 << 24 (k_obs_bbox, conv_split.hip);
     int grow;            //   only the pixels of that box grown by `grow` (cut to the canvas) are computed and written
     int group;           // k_stem_conv_mfma: images per iteration of a block (their padded copies sit side by side in LDS); 0 = 1
+    const float *center; // k_stem_conv_mfma<0, true> (training step): per-channel centre of the batch-norm sums (or NULL = 0)
+    float *stat_part;    //   [gridDim.x][2][128] sums of (out - center) and (out - center)^2 over the block's images
 };
 
 // 256 pixels per block; thread (pg = tid / 32, cq = tid % 32) computes outputs 4 cq .. 4 cq + 3 of pixels pg + 8 k with its
@@ -566,11 +569,16 @@ __global__ __launch_bounds__(256) void k_stem_conv_img(StemArgs p)
 // the accumulators: for each accumulator register the two 32-lane halves write 128 contiguous bytes of two pixel rows.
 typedef _Float16 sm_f16x8 __attribute__((ext_vector_type(8)));
 typedef float sm_f32x16 __attribute__((ext_vector_type(16)));
-template <int OUT16>
+// STATS (training step, with raw): the per-channel sums the stem's batch norm starts from are taken from the values on their way
+//   out -- a lane owns four channels (32 nt + l31) of the rows it stores -- and leave as one partial row per block: the pass
+//   snk_bn_train_sums_f64 makes over the 462 MB output (0.11 ms per step, in every step) is not needed
+template <int OUT16, bool STATS = false>
 __global__ __launch_bounds__(256) void k_stem_conv_mfma(StemArgs p)
 {
     extern __shared__ __align__(16) float st_img[];
     __shared__ float s_wmax[4];
+    __shared__ float s_stat[STATS ? 4 : 1][STATS ? 2 : 1][STATS ? CV_C : 1];
+    float cen[4] = {0.f, 0.f, 0.f, 0.f}, ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
     const int Hd = p.Hd, Wd = p.Wd, HW = Hd * Wd, row3 = Wd * 3, P3 = (Wd + 2) * 3;
     const int n_img = p.M / HW;
@@ -620,6 +628,10 @@ __global__ __launch_bounds__(256) void k_stem_conv_mfma(StemArgs p)
         shf[nt] = p.raw ? 0.f : p.shift[32 * nt + l31];
     }
     const float floor_ = p.raw ? -__builtin_inff() : 0.f;
+    if (STATS && p.center) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) cen[nt] = p.center[32 * nt + l31];
+    }
 
     const int n_lds = (Hd + 2) * P3;
     // A block takes G images per iteration: one load / barrier / compute / store round per image left the wavefronts unevenly
@@ -705,6 +717,7 @@ __global__ __launch_bounds__(256) void k_stem_conv_mfma(StemArgs p)
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
                         const float v = fmaxf(__builtin_fmaf(acc[nt][r], scl[nt], shf[nt]), floor_);
+                        if (STATS) { const float e_ = v - cen[nt]; ssum[nt] += e_; ssq[nt] += e_ * e_; }
                         if (OUT16 == 2) ((__bf16 *)out16)[(long)row * CV_C + 32 * nt + l31] = (__bf16)v;
                         else if (OUT16) out16[(long)row * CV_C + 32 * nt + l31] = (_Float16)fminf(v, 65504.f);
                         else out[(long)row * CV_C + 32 * nt + l31] = v;
@@ -712,6 +725,17 @@ __global__ __launch_bounds__(256) void k_stem_conv_mfma(StemArgs p)
                 }
             }
         }
+    }
+    if (STATS) {                                // the two row halves of a lane pair, then the four wavefronts, in a fixed order
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            ssum[nt] += __shfl_xor(ssum[nt], 32, 64);
+            ssq[nt] += __shfl_xor(ssq[nt], 32, 64);
+            if (h == 0) { s_stat[wv][0][32 * nt + l31] = ssum[nt]; s_stat[wv][1][32 * nt + l31] = ssq[nt]; }
+        }
+        __syncthreads();
+        const int q = tid >> 7, c = tid & 127;
+        p.stat_part[(size_t)blockIdx.x * 256 + tid] = ((s_stat[0][q][c] + s_stat[1][q][c]) + s_stat[2][q][c]) + s_stat[3][q][c];
     }
 }
 
@@ -891,14 +915,16 @@ extern "C" int snk_conv3x3_bn_f32_winograd(const float *d_x, const float *d_U, c
 
 // images a block of k_stem_conv_mfma takes per iteration (their padded float32 copies share the 64 KB of dynamic LDS), and the
 // launch that goes with it; SNK_STEM_GROUP=1 restores one image per iteration (A/B runs)
-template <int OUT16>
-static void stem_mfma_launch(StemArgs a, int n_images, size_t lds_one, int max_grid, hipStream_t st)
+template <int OUT16, bool STATS = false>
+static int stem_mfma_launch(StemArgs a, int n_images, size_t lds_one, int max_grid, hipStream_t st)
 {
     static const int group_max = getenv("SNK_STEM_GROUP") ? max(1, min(4, atoi(getenv("SNK_STEM_GROUP")))) : 4;
-    int g = (int)min((size_t)group_max, (size_t)(64 * 1024) / lds_one);
+    int g = (int)min((size_t)group_max, (size_t)((STATS ? 59 : 64) * 1024) / lds_one);     // (STATS: 4 KB of static LDS for the sums)
     g = max(1, min(g, n_images));
     a.group = g;
-    k_stem_conv_mfma<OUT16><<<min((n_images + g - 1) / g, max_grid), 256, g * lds_one, st>>>(a);
+    const int grid = min((n_images + g - 1) / g, max_grid);
+    k_stem_conv_mfma<OUT16, STATS><<<grid, 256, g * lds_one, st>>>(a);
+    return grid;
 }
 
 extern "C" int snk_stem_conv_bn_relu_f32(const float *d_x, const float *d_w, const float *d_scale, const float *d_shift,
@@ -983,6 +1009,24 @@ extern "C" int snk_stem_conv_f32(const float *d_x, const float *d_w, float *d_ou
     SNK_REQUIRE(lds <= 64 * 1024, "snk_stem_conv_f32: observation %d x %d too large", height, width);
     StemArgs a = {d_x, d_w, nullptr, nullptr, d_out, (int)M, height, width, 1};
     stem_mfma_launch<0>(a, n_images, lds, 512, (hipStream_t)stream);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// the same with the sums its batch norm starts from taken in the kernel's epilogue: d_sums[0..127] = sum over all pixels of (out -
+// center), d_sums[128..255] = sum of (out - center)^2 (float64; d_center: 128 floats or NULL) -- snk_bn_train_sums_f64(d_out) without
+// its pass over the output.  d_partials: snk_bn_train_partials() floats.
+extern "C" int snk_stem_conv_f32_stats(const float *d_x, const float *d_w, float *d_out, const float *d_center, float *d_partials,
+                                       double *d_sums, int n_images, int height, int width, void *stream)
+{
+    SNK_REQUIRE(d_x && d_w && d_out && d_partials && d_sums && n_images > 0, "snk_stem_conv_f32_stats: bad argument");
+    const long M = (long)n_images * height * width;
+    SNK_REQUIRE(M < (1l << 31), "snk_stem_conv_f32_stats: batch too large");
+    const size_t lds = (size_t)(height + 2) * (width + 2) * 3 * sizeof(float);
+    SNK_REQUIRE(lds <= 59 * 1024, "snk_stem_conv_f32_stats: observation %d x %d too large", height, width);
+    StemArgs a = {d_x, d_w, nullptr, nullptr, d_out, (int)M, height, width, 1, nullptr, 0, 0, d_center, d_partials};
+    const int grid = stem_mfma_launch<0, true>(a, n_images, lds, 512, (hipStream_t)stream);
+    tf_fold<double>(d_partials, grid, 256, 256, 1.0, d_sums, (double *)(d_partials + 2048 * 256), (hipStream_t)stream);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -95,13 +95,23 @@ __device__ static inline void tr_block_amax(float m, float *__restrict__ amax_pa
     if (threadIdx.x == 0) amax_part[blockIdx.x] = shm[0];
 }
 
+// HEAD (the tower's last layer, alpha_nnet.py:46-50): the head's 1x1 convolution rides on the values being written -- z[r] = dot(out[r][:],
+// w1x1), summed over the 32 lanes that hold a row, and the block partials of sum (z - center), sum (z - center)^2 (the single
+// channel's batch-norm statistics): snk_head_conv1x1_sums's pass over the 462 MB activation is not needed
+#define tr_dpp(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+template <bool HEAD>
 __global__ __launch_bounds__(TR_THREADS) void k_bn_apply(const float *__restrict__ y, const float *__restrict__ scale,
                                                         const float *__restrict__ shift, const float *__restrict__ res,
                                                         float *__restrict__ out, long rows, int relu,
-                                                        float *__restrict__ amax_part, uint8_t *__restrict__ mask_out)
+                                                        float *__restrict__ amax_part, uint8_t *__restrict__ mask_out,
+                                                        const float *__restrict__ w1x1 = nullptr, const float *__restrict__ center1 = nullptr,
+                                                        float *__restrict__ z = nullptr, float *__restrict__ part1 = nullptr)
 {
     const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const float4 sc = *(const float4 *)(scale + 4 * cq), sh = *(const float4 *)(shift + 4 * cq);
+    float4 w1 = sc;
+    float cen1 = 0.f, hs = 0.f, hq = 0.f;
+    if (HEAD) { w1 = *(const float4 *)(w1x1 + 4 * cq); if (center1) cen1 = center1[0]; }
     float am = 0.f;
     for (long r = (long)blockIdx.x * TR_ROWLANES + rl; r < rows; r += (long)gridDim.x * TR_ROWLANES) {
         const long o = r * TR_C + 4 * cq;
@@ -115,8 +125,29 @@ __global__ __launch_bounds__(TR_THREADS) void k_bn_apply(const float *__restrict
         *(float4 *)(out + o) = t;
         if (mask_out) mask_out[r * 32 + cq] = (uint8_t)((t.x > 0.f ? 1 : 0) | (t.y > 0.f ? 2 : 0) | (t.z > 0.f ? 4 : 0) | (t.w > 0.f ? 8 : 0));
         am = fmaxf(fmaxf(am, fmaxf(fabsf(t.x), fabsf(t.y))), fmaxf(fabsf(t.z), fabsf(t.w)));
+        if (HEAD) {                 // (k_head1x1's arithmetic, csrc/train_net.hip: the same sums in the same order)
+            float d = (t.x * w1.x + t.y * w1.y) + (t.z * w1.z + t.w * w1.w);
+            d += tr_dpp(d, 0xB1); d += tr_dpp(d, 0x4E); d += tr_dpp(d, 0x141); d += tr_dpp(d, 0x140);
+            d += __shfl_xor(d, 16, 64);
+            if (cq == 0) {
+                z[r] = d;
+                const float e = d - cen1;
+                hs += e; hq += e * e;
+            }
+        }
     }
     if (amax_part) tr_block_amax(am, amax_part);
+    if (HEAD) {
+        __shared__ float sh2[2][TR_THREADS];
+        sh2[0][threadIdx.x] = hs;
+        sh2[1][threadIdx.x] = hq;
+        __syncthreads();
+        for (int o = TR_THREADS / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) { sh2[0][threadIdx.x] += sh2[0][threadIdx.x + o]; sh2[1][threadIdx.x] += sh2[1][threadIdx.x + o]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { part1[2 * blockIdx.x] = sh2[0][0]; part1[2 * blockIdx.x + 1] = sh2[1][0]; }
+    }
 }
 
 // g = dout where the layer's output is positive (ReLU) or everywhere (no ReLU); xhat = (y - mean) * inv
@@ -211,9 +242,26 @@ extern "C" int snk_bn_train_apply(const float *d_y, const float *d_scale, const 
 {
     SNK_REQUIRE(d_y && d_scale && d_shift && d_out && rows > 0 && (!d_out_scale_tail || d_partials), "snk_bn_train_apply: bad argument");
     const int grid = tr_grid(rows);
-    k_bn_apply<<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_y, d_scale, d_shift, d_residual, d_out, rows, relu,
-                                                              d_out_scale_tail ? d_partials : nullptr, d_relu_mask);
+    k_bn_apply<false><<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_y, d_scale, d_shift, d_residual, d_out, rows, relu,
+                                                                     d_out_scale_tail ? d_partials : nullptr, d_relu_mask);
     if (d_out_scale_tail) k_amax_scale<<<1, 1024, 0, (hipStream_t)stream>>>(d_partials, grid, d_out_scale_tail);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// snk_bn_train_apply (relu = 1) for the tower's LAST layer, with the head's 1x1 convolution and its batch-norm sums taken from the
+// values on their way out: d_z[rows] = dot(out[row][:], d_w1x1), d_hsums = { sum (z - center1), sum (z - center1)^2 } (float64;
+// d_center1: one float or NULL) -- what snk_head_conv1x1_sums computes from d_out in a pass of its own.
+extern "C" int snk_bn_train_apply_head(const float *d_y, const float *d_scale, const float *d_shift, const float *d_residual,
+                                       float *d_out, long rows, float *d_partials, uint8_t *d_relu_mask, const float *d_w1x1,
+                                       const float *d_center1, float *d_z, double *d_hsums, void *stream)
+{
+    SNK_REQUIRE(d_y && d_scale && d_shift && d_out && rows > 0 && d_partials && d_w1x1 && d_z && d_hsums, "snk_bn_train_apply_head: bad argument");
+    const int grid = tr_grid(rows);
+    float *part1 = d_partials + 2048;          // (behind the 2 048 maxima a plain launch would leave)
+    k_bn_apply<true><<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_y, d_scale, d_shift, d_residual, d_out, rows, 1, nullptr, d_relu_mask,
+                                                                    d_w1x1, d_center1, d_z, part1);
+    tf_fold<double>(part1, grid, 2, 2, 1.0, d_hsums, (double *)(d_partials + 2048 * 2 * TR_C), (hipStream_t)stream);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }

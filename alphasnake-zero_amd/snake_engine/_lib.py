@@ -106,10 +106,12 @@ PROTOTYPES = {
     "snk_conv3x3_wgrad_partials": (C.c_long, [i32, i32]),
     "snk_conv3x3_wgrad_f16s": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "snk_bn_train_apply": (i32, [vp, vp, vp, vp, vp, C.c_long, i32, vp, vp, vp, vp]),
+    "snk_bn_train_apply_head": (i32, [vp, vp, vp, vp, vp, C.c_long, vp, vp, vp, vp, vp, vp, vp]),
     "snk_bn_train_grad_apply": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_long, i32, vp, vp, vp]),
     "snk_conv3x3_prepare_weights_f16s_train": (i32, [vp, vp, vp, i32, vp, vp]),
     "snk_conv3x3_prepare_weights_f16s_train_batch": (i32, [vp, vp, vp, i32, vp]),
     "snk_stem_conv_f32": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "snk_stem_conv_f32_stats": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "snk_conv3x3_stats_partials": (C.c_long, [i32, i32, i32]),
     "snk_conv3x3_f16s_stats": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "snk_conv3x3_f16s_igrad_stats": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),

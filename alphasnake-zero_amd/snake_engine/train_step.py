@@ -57,6 +57,7 @@ _CONV_STATS = os.environ.get("SNK_TRAIN_CONV_STATS", "1") != "0"      # 0: batch
 _IGRAD_STATS = os.environ.get("SNK_TRAIN_IGRAD_STATS", "1") != "0"    # 0: the batch-norm BACKWARD sums in a pass of their own
 _BATCH_PREP = os.environ.get("SNK_TRAIN_BATCH_PREP", "1") != "0"      # 0: every layer's weight images made one by one, each step (A/B runs)
 _RES_MASK = os.environ.get("SNK_TRAIN_RES_MASK", "1") != "0"          # 0: the shortcut's gradient is written as a masked copy (A/B runs)
+_HEAD_FUSED = os.environ.get("SNK_TRAIN_HEAD_FUSED", "1") != "0"      # 0: the head's 1x1 convolution in a pass of its own (A/B runs)
 _DEFER_BN = os.environ.get("SNK_TRAIN_DEFER_BN", "1") != "0"          # 0: every layer's batch norm + ReLU output is written (A/B runs)
 BN_EPS, BN_MOMENTUM, L2_C = 1e-3, 0.99, 1e-5
 ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-7
@@ -193,7 +194,7 @@ class TrainStep:
             else:
                 self.dist.all_reduce(t)
 
-    def _bn_forward(self, l, n, count, res, relu_out, tail, have_sums=False):
+    def _bn_forward(self, l, n, count, res, relu_out, tail, have_sums=False, head=False):
         L, st, rows, k = self.L, self._st(), n * self.hw, self._k(l)
         mm, mv = self.moving[k + 3], self.moving[k + 4]
         if not have_sums:                                        # the tower's convolutions take the sums on their way out
@@ -206,6 +207,11 @@ class TrainStep:
             return
         check(L.snk_bn_train_finalize(_p(self.sums), float(count), _p(mm), _p(self.view[k + 1]), _p(self.view[k + 2]), _p(mm), _p(mv),
                                       BN_MOMENTUM, BN_EPS, _p(self.mean[l]), _p(self.inv[l]), _p(self.scale[l]), _p(self.shift[l]), C, st))
+        if head:                                                 # the last layer: the head's 1x1 convolution and its sums ride along
+            kh = self._k(self.n_layers)
+            check(L.snk_bn_train_apply_head(_p(self.y[l]), _p(self.scale[l]), _p(self.shift[l]), _p(res), _p(relu_out), rows, _p(self.partials),
+                                            _p(self.relu_mask[l]), _p(self.view[kh]), _p(self.moving[kh + 3]), _p(self.z), _p(self.h_sums), st))
+            return
         check(L.snk_bn_train_apply(_p(self.y[l]), _p(self.scale[l]), _p(self.shift[l]), _p(res), _p(relu_out), rows, 1,
                                    _p(self.partials), _p(tail), _p(self.relu_mask[l]), st))
 
@@ -222,8 +228,12 @@ class TrainStep:
         assert 0 < n <= self.max_rows and x.is_contiguous() and x.dtype == torch.float32 and tuple(x.shape[1:]) == (self.h, self.w, 3)
         count = n_global * self.hw
         self.x0, self.saved_rows = x, n
-        check(L.snk_stem_conv_f32(_p(x), _p(self.view[0]), _p(self.y[0]), n, self.h, self.w, st))
-        self._bn_forward(0, n, count, None, self.out[0], self.tail_out[0])
+        if _CONV_STATS:                                           # the stem's batch-norm sums leave its kernel with the output
+            check(L.snk_stem_conv_f32_stats(_p(x), _p(self.view[0]), _p(self.y[0]), _p(self.moving[3]), _p(self.partials), _p(self.sums),
+                                            n, self.h, self.w, st))
+        else:
+            check(L.snk_stem_conv_f32(_p(x), _p(self.view[0]), _p(self.y[0]), n, self.h, self.w, st))
+        self._bn_forward(0, n, count, None, self.out[0], self.tail_out[0], have_sums=_CONV_STATS)
         for l in range(1, self.n_layers):
             k = self._k(l)
             if not self.batch_prep:
@@ -242,11 +252,13 @@ class TrainStep:
             else:
                 self._conv(self.out[l - 1], self.img_f[l], None, self.y[l], n)
             res = self.out[l - 2] if l % 2 == 0 else None                # a block's second layer adds the block's input
-            self._bn_forward(l, n, count, res, self.out[l], self.tail_out[l], have_sums=_CONV_STATS)
+            self._bn_forward(l, n, count, res, self.out[l], self.tail_out[l], have_sums=_CONV_STATS,
+                             head=_HEAD_FUSED and l == self.n_layers - 1)
         kh = self._k(self.n_layers)
         mm, mv = self.moving[kh + 3], self.moving[kh + 4]
         rows = n * self.hw
-        check(L.snk_head_conv1x1_sums(_p(self.out[-1]), _p(self.view[kh]), rows, _p(mm), _p(self.z), _p(self.partials), _p(self.h_sums), st))
+        if not _HEAD_FUSED:
+            check(L.snk_head_conv1x1_sums(_p(self.out[-1]), _p(self.view[kh]), rows, _p(mm), _p(self.z), _p(self.partials), _p(self.h_sums), st))
         self._all_reduce(self.h_sums)
         check(L.snk_bn_train_finalize(_p(self.h_sums), float(count), _p(mm), _p(self.view[kh + 1]), _p(self.view[kh + 2]), _p(mm), _p(mv),
                                       BN_MOMENTUM, BN_EPS, _p(self.h_mean_inv), _p(self.h_mean_inv) + 4, _p(self.h_sb), _p(self.h_sb) + 4, 1, st))

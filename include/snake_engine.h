@@ -52,7 +52,7 @@ typedef struct {
 const char *snk_last_error(void);
 #define SNK_ABI_VERSION 111 /* 100: rounds 1-3; 110: round 5 (the gate argument d_skip of the tick kernels, round 4; the 16-bit
                              * towers' own weight image and rectangle plan, round 5); 111: the training step's deferred batch
-                             * norm (nine entry points added, snk_conv3x3_stats_partials returns more): a caller compares it
+                             * norm (eleven entry points added, snk_conv3x3_stats_partials returns more): a caller compares it
                              * with snk_version() */
 int snk_version(void);
 
@@ -428,6 +428,13 @@ int snk_conv3x3_wgrad_f16s(const float *d_x, const float *d_dy, const float *d_x
 int snk_bn_train_apply(const float *d_y, const float *d_scale, const float *d_shift, const float *d_residual,
                        float *d_out, long rows, int relu, float *d_partials, float *d_out_scale_tail, uint8_t *d_relu_mask,
                        void *stream);
+/* snk_bn_train_apply (relu = 1) for the tower's LAST layer with the head's 1x1 convolution (alpha_nnet.py:49) and its batch-norm
+ * sums taken from the values on their way out: d_z[rows] = dot(out[row][:], d_w1x1), d_hsums = { sum (z - center1), sum (z -
+ * center1)^2 } (float64; d_center1: one float or NULL) -- snk_head_conv1x1_sums without its pass over d_out.  No scale tail: no
+ * convolution reads this output.  d_partials: snk_bn_train_partials() floats. */
+int snk_bn_train_apply_head(const float *d_y, const float *d_scale, const float *d_shift, const float *d_residual, float *d_out,
+                            long rows, float *d_partials, uint8_t *d_relu_mask, const float *d_w1x1, const float *d_center1,
+                            float *d_z, double *d_hsums, void *stream);
 int snk_bn_train_grad_sums_f64(const float *d_dout, const float *d_out, const uint8_t *d_relu_mask, const float *d_y,
                                const float *d_mean, const float *d_inv, long rows, int relu, float *d_partials, double *d_sums,
                                void *stream);
@@ -475,6 +482,10 @@ int snk_conv3x3_prepare_weights_f16s_train(const float *d_w_hwio, void *d_wS, co
 int snk_conv3x3_prepare_weights_f16s_train_batch(const float *const *h_w_hwio, void *const *h_wS_fwd, void *const *h_wS_bwd,
                                                  int n_layers, void *stream);
 int snk_stem_conv_f32(const float *d_x, const float *d_w, float *d_out, int n_images, int height, int width, void *stream);
+/* snk_stem_conv_f32 with the sums its batch norm starts from taken in the kernel's epilogue (d_sums as snk_bn_train_sums_f64(d_out,
+ * d_center) leaves them, without that pass over the output); d_partials: snk_bn_train_partials() floats */
+int snk_stem_conv_f32_stats(const float *d_x, const float *d_w, float *d_out, const float *d_center, float *d_partials,
+                            double *d_sums, int n_images, int height, int width, void *stream);
 /* The forward convolution of a tower layer under training: d_out = conv3x3_same(d_x, w), bare (the batch norm comes after), and
  * from the same values on their way out of the kernel d_sums[0..127] = sum (out - center), [128..255] = sum (out - center)^2
  * over all n * h * w pixels (float64; d_center: 128 floats or NULL): snk_bn_train_sums_f64(d_out) without the extra pass.

@@ -492,6 +492,51 @@ def test_shortcut_gradient_through_the_mask_bytes_equals_the_masked_copy(torch_g
     assert torch.equal(out_a, out_b) and torch.equal(sums, ref) and float(ref.abs().max()) > 0
 
 
+@pytest.mark.parametrize("n,hw", [(70, 21), (9, 13), (5, 37), (1, 21)])
+def test_sums_taken_in_the_stem_and_the_head_on_their_way_out(torch_gpu, n, hw):
+    """round 5: the stem's convolution leaves with the sums its batch norm starts from (snk_stem_conv_f32_stats), and the last
+    tower layer's batch-norm kernel with the head's 1x1 convolution and ITS sums (snk_bn_train_apply_head) -- two passes over a
+    462 MB tensor less in every step.  Outputs bit-identical to the separate kernels', sums equal up to summation order
+    (alpha_nnet.py:21-24, 46-50 under Keras fit)"""
+    torch = torch_gpu
+    from snake_engine._lib import lib, check
+    L, st = lib(), torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(n * hw)
+    rows = n * hw * hw
+    x = torch.rand(n, hw, hw, 3, device="cuda", generator=g)
+    w = torch.randn(3, 3, 3, 128, device="cuda", generator=g) * 0.2
+    cen = torch.randn(128, device="cuda", generator=g) * 0.1
+    part = torch.empty(L.snk_bn_train_partials(), device="cuda")
+    y_a, y_b = torch.empty(rows * 128, device="cuda"), torch.empty(rows * 128, device="cuda")
+    s_a, s_b = torch.zeros(256, dtype=torch.float64, device="cuda"), torch.zeros(256, dtype=torch.float64, device="cuda")
+    check(L.snk_stem_conv_f32(x.data_ptr(), w.data_ptr(), y_a.data_ptr(), n, hw, hw, st))
+    check(L.snk_bn_train_sums_f64(y_a.data_ptr(), rows, cen.data_ptr(), part.data_ptr(), s_a.data_ptr(), st))
+    check(L.snk_stem_conv_f32_stats(x.data_ptr(), w.data_ptr(), y_b.data_ptr(), cen.data_ptr(), part.data_ptr(), s_b.data_ptr(), n, hw, hw, st))
+    assert torch.equal(y_a, y_b)
+    ref = torch.cat([(y_a.view(rows, 128).double() - cen.double()).sum(0), ((y_a.view(rows, 128).double() - cen.double()) ** 2).sum(0)])
+    assert float((s_b - ref).abs().max()) <= 1e-6 * float(ref.abs().max()) and float((s_a - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+    # ---- the last layer's batch norm + shortcut + ReLU with the head's 1x1 stage
+    y = torch.randn(rows * 128, device="cuda", generator=g)
+    res = torch.randn(rows * 128, device="cuda", generator=g)
+    sc, sh = torch.rand(128, device="cuda", generator=g) + 0.5, torch.randn(128, device="cuda", generator=g) * 0.3
+    w1 = torch.randn(128, device="cuda", generator=g) * 0.1
+    c1 = torch.full((1,), 0.37, device="cuda")
+    o_a, o_b = torch.empty(rows * 128, device="cuda"), torch.empty(rows * 128, device="cuda")
+    m_a, m_b = torch.zeros(rows * 32, dtype=torch.uint8, device="cuda"), torch.zeros(rows * 32, dtype=torch.uint8, device="cuda")
+    z_a, z_b = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    h_a, h_b = torch.zeros(2, dtype=torch.float64, device="cuda"), torch.zeros(2, dtype=torch.float64, device="cuda")
+    tail = torch.zeros(4, device="cuda")
+    check(L.snk_bn_train_apply(y.data_ptr(), sc.data_ptr(), sh.data_ptr(), res.data_ptr(), o_a.data_ptr(), rows, 1, part.data_ptr(),
+                               tail.data_ptr(), m_a.data_ptr(), st))
+    check(L.snk_head_conv1x1_sums(o_a.data_ptr(), w1.data_ptr(), rows, c1.data_ptr(), z_a.data_ptr(), part.data_ptr(), h_a.data_ptr(), st))
+    check(L.snk_bn_train_apply_head(y.data_ptr(), sc.data_ptr(), sh.data_ptr(), res.data_ptr(), o_b.data_ptr(), rows, part.data_ptr(),
+                                    m_b.data_ptr(), w1.data_ptr(), c1.data_ptr(), z_b.data_ptr(), h_b.data_ptr(), st))
+    assert torch.equal(o_a, o_b) and torch.equal(m_a, m_b) and torch.equal(z_a, z_b)
+    assert float((h_a - h_b).abs().max()) <= 1e-9 * float(h_a.abs().max())
+    zr = (o_a.view(rows, 128).double() * w1.double()).sum(1)
+    assert float((z_b.double() - zr).abs().max()) <= 1e-5 * float(zr.abs().max())
+
+
 def test_fit_on_the_kernels_tracks_fit_with_library_operators(torch_gpu):
     """utils.trainer_torch.fit on the same rows and shuffle order on this library's kernels and with every operator from
     PyTorch / MIOpen (SNK_TRAIN_CONV=torch).  Adam's first steps move every weight by about lr * sign(gradient), so weights

@@ -20,7 +20,7 @@ def tail_of(x):
     return image[F16S_TAIL_OFFSET:F16S_TAIL_OFFSET + 16].view(torch.float32).clone()
 
 
-worst = 0.0
+worst, n_def = 0.0, 0
 for t in range(trials):
     hw = int(rs.choice([5, 7, 9, 13, 17, 21, 21, 25, 29, 33, 37, 37, 41, 45]))
     if L.snk_conv3x3_wgrad_partials(hw, hw) < 0:
@@ -40,5 +40,17 @@ for t in range(trials):
     err = float((dk.double() - ref).abs().max() / ref.abs().max())
     worst = max(worst, err)
     assert torch.isfinite(dk).all() and err <= 2e-6, (t, n, hw, xm, gm, err)
-print(f"fuzz_wgrad seed {seed}: {trials} shapes (widths 5 .. 45, 1 .. 260 images, |x| 1e-2 .. 1e2, |dy| 1e-5 .. 1) within 2e-6 of float64, worst {worst:.1e}"
+    if L.snk_train_deferred_bn_supported(hw, hw) == 1:      # the deferred form: X = relu(y * scale + shift) applied on the way into LDS, bit for bit
+        ypre = torch.randn(n, hw, hw, 128, device="cuda", generator=g) * xm
+        sc = (torch.rand(128, device="cuda", generator=g) + 0.25) * torch.where(torch.rand(128, device="cuda", generator=g) < 0.2, -1.0, 1.0)
+        sh = torch.randn(128, device="cuda", generator=g) * xm * 0.3
+        xd = torch.relu(ypre * sc + sh).contiguous()
+        txd = tail_of(xd)
+        dk_a, dk_b = torch.full_like(dk, float("nan")), torch.full_like(dk, float("nan"))
+        check(L.snk_conv3x3_wgrad_f16s(xd.data_ptr(), dy.data_ptr(), txd.data_ptr(), tdy.data_ptr(), part.data_ptr(), dk_a.data_ptr(), n, hw, hw, st))
+        check(L.snk_conv3x3_wgrad_f16s_deferred(ypre.data_ptr(), sc.data_ptr(), sh.data_ptr(), dy.data_ptr(), txd.data_ptr(), tdy.data_ptr(),
+                                                part.data_ptr(), dk_b.data_ptr(), n, hw, hw, st))
+        assert torch.equal(dk_a, dk_b), (t, n, hw, "deferred")
+        n_def += 1
+print(f"fuzz_wgrad seed {seed}: {trials} shapes (widths 5 .. 45, 1 .. 260 images, |x| 1e-2 .. 1e2, |dy| 1e-5 .. 1) within 2e-6 of float64, worst {worst:.1e}; {n_def} of them also in the deferred form, bit-identical to the written activation"
       f"{' (slab form)' if os.environ.get('SNK_WGRAD') == 'slabs' else ''}")
