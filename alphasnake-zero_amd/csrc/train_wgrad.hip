@@ -409,6 +409,11 @@ __global__ __launch_bounds__(512) void k_wgrad2_f16s(Wg2Args p)
     __syncthreads();                                                      // window 0 is in buffer 0
     WG_STAMP(1, __builtin_amdgcn_s_memtime())
     for (int t = 0; t < T; ++t) {
+#ifdef WG_SKEW
+        // the two wavefronts of a SIMD (w and w + 4) leave the window's barrier together and run the same code: the second one waits a
+        // little, so that its staging bursts fall into the first one's MFMA runs and the other way round
+        if (wv >> 2) __builtin_amdgcn_s_sleep(WG_SKEW);
+#endif
         unsigned char *B = smem + (t & 1) * buf_bytes, *Bn = smem + ((t + 1) & 1) * buf_bytes;
         const unsigned char *XH = B + wa * plane_x, *XL = XH + 2 * plane_x;
         const unsigned char *YH = B + 4 * plane_x + wb * plane_y, *YL = YH + 4 * plane_y;
