@@ -174,6 +174,8 @@ extern "C" int snk_dbg_conv_stamps(unsigned long long *h_out, int n_blocks)
 //     above received it, res_mask that output's ReLU bits -- the batch-norm backward of the block's second layer no longer writes
 //     the masked copy (462 MB per block) just for this epilogue to read it back.  out may be res itself (a thread reads the rows
 //     it writes, and reads them first)
+//   9 MODE 6 that also takes MODE 4's per-channel maxima (its own batch norm is deferred too: the layer above a deferred stem)
+//  10 MODE 8 whose ReLU decision for the sums is recomputed like MODE 7's (the layer below is the deferred stem: no mask bytes)
 #define hs_dpp(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
 // SPLIT = false: the reduced-precision form for BASELINE configs[4] ("bf16 MFMA conv"): the same kernel with the hi parts
 //   only, one MFMA per product instead of three (f16 operands: 11 significand bits against bf16's 8, float32 accumulate).
@@ -195,9 +197,9 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     static_assert(IO16 == 0 || !SPLIT, "f16 activations only exist in the reduced-precision form");
     static_assert(!BF || (IO16 & 1), "the bf16 form reads bf16 activations");
     constexpr bool IN16 = (IO16 & 1) != 0, OUT16 = (IO16 & 2) != 0;
-    constexpr bool STATS = MODE == 4 || MODE == 6, GSTATS = MODE == 5 || MODE == 7 || MODE == 8, BARE = STATS || GSTATS;
-    constexpr bool RESMASK = MODE == 8;
-    constexpr bool AFF = MODE == 6, GAFF = MODE == 7;
+    constexpr bool STATS = MODE == 4 || MODE == 6 || MODE == 9, GSTATS = MODE == 5 || MODE == 7 || MODE == 8 || MODE == 10, BARE = STATS || GSTATS;
+    constexpr bool RESMASK = MODE == 8 || MODE == 10, AMAX = MODE == 4 || MODE == 9;
+    constexpr bool AFF = MODE == 6 || MODE == 9, GAFF = MODE == 7 || MODE == 10, NORES = MODE == 7;
     static_assert(!(AFF || GAFF || RESMASK) || (SPLIT && IO16 == 0 && !RECT), "the deferred batch norm exists in the training step's float32 form only");
     constexpr bool K32 = IN16;
     constexpr int RING = K32 ? HS_RING16 : HS_RING, AHEAD = K32 ? HS_AHEAD16 : HS_AHEAD;      // B-fragment register ring: slots (a divisor of 9), taps ahead
@@ -208,7 +210,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     constexpr bool P8 = IN16 && OUT16;                     // the epilogue handles 8 channels (16 bytes in and out) per thread and row
     // (MODE 7 never takes a shortcut's gradient: it produces the gradient at a block's FIRST layer's output -- its epilogue has the
     // registers the shortcut rows would take for the g_y rows instead, requested a pass ahead)
-    const bool has_res = GAFF ? false : RESMASK ? true : (MODE == 0 || GSTATS) ? p.res != nullptr : (MODE == 2 || MODE == 3);
+    const bool has_res = NORES ? false : RESMASK ? true : (MODE == 0 || GSTATS) ? p.res != nullptr : (MODE == 2 || MODE == 3);
     const bool has_head = MODE == 0 ? p.w1x1 != nullptr : MODE == 3;
     const bool has_out = MODE == 0 ? p.out != nullptr : MODE != 3;
     const float relu_floor = ((MODE != 0 && !BARE) || (MODE == 0 && p.relu)) ? 0.f : -__builtin_inff();
@@ -422,8 +424,8 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     HS_STAMP(2)
     // MODE 7: the g_y rows of the epilogue's first pass are requested here, into the registers the staging items no longer need: their
     // HBM latency passes under the last chunk's MFMAs (the epilogue below requests every later pass's rows one pass ahead)
-    float4 gyv[GAFF ? 2 : 1][GAFF ? 8 : 1];
-    if (GAFF) {
+    float4 gyv[NORES ? 2 : 1][NORES ? 8 : 1];
+    if (NORES) {
 #pragma unroll
         for (int j = 0; j < (NI >= 2 ? 8 : 4); ++j) {
             const int m_ = min(m0 + (tid >> 5) + 8 * j, m1 - 1);
@@ -580,7 +582,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
     const auto q_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((RESMASK ? p.res_mask : (const unsigned char *)p.g_y) + (ielem >> 2)), 0, HWc * (HS_C / 4), 0x00020000);
     const unsigned vo4 = (unsigned)((m0 + rr0) * HS_C + 4 * cq) * 4u, vo1 = (unsigned)((m0 + rr0) * (HS_C / 4) + cq);
     constexpr int NPASS = (NI + 1) / 2;
-    float4 rv[8], yv[GAFF ? 1 : 8];
+    float4 rv[8], yv[NORES ? 1 : 8];
     unsigned mbv[GAFF ? 1 : 8], rmv[RESMASK ? 8 : 1];
 #define HS_ROWS(pass) (((pass) + 1 < NPASS ? 2 : NI - 2 * (NPASS - 1)) * 32)
 #define HS_LD4(rsrc, pass, j) __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo4, (64 * (pass) + 8 * (j)) * HS_C * 4, 0))
@@ -590,9 +592,10 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < HS_ROWS(pass) / 8; ++j) {
-            if (!GAFF) rv[j] = HS_LD4(r_rsrc, pass, j);      // (MODE 5 without a shortcut: the row is read -- through g_y's descriptor -- and not used)
+            if (!NORES) rv[j] = HS_LD4(r_rsrc, pass, j);     // (MODE 5 without a shortcut: the row is read -- through g_y's descriptor -- and not used)
             if (RESMASK) rmv[j] = HS_LD1(q_rsrc, pass, j);
-            if (!GAFF) { yv[j] = HS_LD4(y_rsrc, pass, j); mbv[j] = HS_LD1(m_rsrc, pass, j); }
+            if (!NORES) yv[j] = HS_LD4(y_rsrc, pass, j);
+            if (!GAFF) mbv[j] = HS_LD1(m_rsrc, pass, j);
         }
         __builtin_amdgcn_sched_barrier(0);
         float *Mb = Ms + (pass & 1) * (64 * HS_MLD);
@@ -607,7 +610,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
         float4 m[8];
 #pragma unroll
         for (int j = 0; j < HS_ROWS(pass) / 8; ++j) m[j] = *(const float4 *)&Mb[(rr0 + 8 * j) * HS_MLD + 4 * cq];
-        if (GAFF && pass + 1 < NPASS) {
+        if (NORES && pass + 1 < NPASS) {
 #pragma unroll
             for (int j = 0; j < HS_ROWS(pass + 1) / 8; ++j) gyv[(pass + 1) & 1][j] = HS_LD4(y_rsrc, pass + 1, j);
         }
@@ -623,7 +626,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
                 if (RESMASK) r_ = make_float4((rmv[j] & 1u) ? r_.x : 0.f, (rmv[j] & 2u) ? r_.y : 0.f, (rmv[j] & 4u) ? r_.z : 0.f, (rmv[j] & 8u) ? r_.w : 0.f);
                 v.x += r_.x; v.y += r_.y; v.z += r_.z; v.w += r_.w;
             }
-            const float4 y_ = GAFF ? gyv[pass & 1][j] : yv[j];
+            const float4 y_ = NORES ? gyv[pass & 1][j] : yv[j];
             bool bx, by, bz, bw;
             if (GAFF) {                      // the layer's output was never written: its sign is that of k_bn_apply's expression
                 bx = y_.x * gsc.x + gsh.x > 0.f; by = y_.y * gsc.y + gsh.y > 0.f; bz = y_.z * gsc.z + gsh.z > 0.f; bw = y_.w * gsc.w + gsh.w > 0.f;
@@ -729,7 +732,7 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
                 const float ex = v.x - cen4.x, ey = v.y - cen4.y, ez = v.z - cen4.z, ew = v.w - cen4.w;
                 st_s.x += ex; st_s.y += ey; st_s.z += ez; st_s.w += ew;
                 st_q.x += ex * ex; st_q.y += ey * ey; st_q.z += ez * ez; st_q.w += ew * ew;
-                if (MODE == 4) {             // the range of what this layer's batch norm can make of it (snk_bn_train_finalize_range)
+                if (AMAX) {                  // the range of what this layer's batch norm can make of it (snk_bn_train_finalize_range)
                     st_m.x = fmaxf(st_m.x, fabsf(ex)); st_m.y = fmaxf(st_m.y, fabsf(ey));
                     st_m.z = fmaxf(st_m.z, fabsf(ez)); st_m.w = fmaxf(st_m.w, fabsf(ew));
                 }
@@ -758,9 +761,9 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
         float4 *R = (float4 *)smem;        // [2 (3)][8][32]
         R[rr0 * 32 + cq] = st_s;
         R[(8 + rr0) * 32 + cq] = st_q;
-        if (MODE == 4) R[(16 + rr0) * 32 + cq] = st_m;
+        if (AMAX) R[(16 + rr0) * 32 + cq] = st_m;
         __syncthreads();
-        if (MODE == 4 && rr0 == 2 && p.amax_part) {
+        if (AMAX && rr0 == 2 && p.amax_part) {
             float4 t = R[16 * 32 + cq];
 #pragma unroll
             for (int r = 1; r < 8; ++r) {
@@ -1126,10 +1129,12 @@ static int conv_f16s_launch(const float *d_x, const void *d_wS, const float *d_s
         }                                                                                       \
         SNK_CHECK_HIP(hipGetLastError());                                                       \
         return 0;
-    SNK_REQUIRE(!(d_stat_part && a.g_y && d_aff_scale && d_residual),
+    SNK_REQUIRE(!(d_stat_part && a.g_y && d_aff_scale && d_residual && !d_res_mask),
                 "snk_conv3x3_f16s_igrad_stats_deferred: the layer below a block's second convolution has no shortcut gradient to add");
+    if (d_stat_part && a.g_y && d_res_mask && d_aff_scale) { HS_LAUNCH_TRAIN(10) }   // ... and the ReLU decision of the sums recomputed (deferred stem below)
     if (d_stat_part && a.g_y && d_res_mask) { HS_LAUNCH_TRAIN(8) }     // input gradient + sums, the shortcut's gradient taken through ReLU bits
     if (d_stat_part && a.g_y && d_aff_scale) { HS_LAUNCH_TRAIN(7) }    // ... of a layer whose ReLU decision is recomputed from its scale / shift
+    if (d_stat_part && d_aff_scale && d_amax_part) { HS_LAUNCH_TRAIN(9) }
     if (d_stat_part && d_aff_scale) { HS_LAUNCH_TRAIN(6) }             // forward pass, the producer's batch norm + ReLU applied on the way in
 #undef HS_LAUNCH_TRAIN
     if (d_stat_part && a.g_y) {          // the training step's input gradient + the previous layer's batch-norm backward sums
@@ -1542,7 +1547,7 @@ extern "C" int snk_conv3x3_f16s_stats(const float *d_x, const void *d_wS, float 
 //   d_in_scale / d_in_shift (both or neither): d_x is the PRE-batch-norm output of the layer below and every value is taken as
 //     relu(x * in_scale[c] + in_shift[c]) on its way into the kernel -- bit for bit what snk_bn_train_apply(relu = 1, no residual)
 //     would have written; the input scale in d_wS's tail must cover that range (snk_bn_train_finalize_range);
-//   d_amax (or NULL): 128 floats, the largest |out - center| per channel -- what snk_bn_train_finalize_range turns into the
+//   d_amax (or NULL; with either input form): 128 floats, the largest |out - center| per channel -- what snk_bn_train_finalize_range turns into the
 //     range of this layer's own batch norm + ReLU output without a pass over it.
 extern "C" int snk_conv3x3_f16s_stats_deferred(const float *d_x, const void *d_wS, float *d_out, const float *d_center,
                                                const float *d_in_scale, const float *d_in_shift, float *d_amax, float *d_partials,
@@ -1550,14 +1555,13 @@ extern "C" int snk_conv3x3_f16s_stats_deferred(const float *d_x, const void *d_w
 {
     SNK_REQUIRE(d_x && d_wS && d_out && d_partials && d_sums && n_images > 0 && !d_in_scale == !d_in_shift,
                 "snk_conv3x3_f16s_stats_deferred: bad argument");
-    SNK_REQUIRE(!d_amax || !d_in_scale, "snk_conv3x3_f16s_stats_deferred: the maxima come with the plain input form only");
     // the launch's grid is known only inside: the maxima sit behind the largest sums + fold scratch the buffer is sized for
     const long T = ((long)height * width + 31) / 32;
     float *amax_part = d_amax ? d_partials + (long)n_images * T * 256 + TF_SCRATCH_FLOATS(256) : nullptr;
     int grid = 0;
     const int rc = conv_f16s_launch(d_x, d_wS, nullptr, nullptr, nullptr, d_out, nullptr, 0.f, 0.f, nullptr, n_images, height, width, 0,
                                     true, stream, 0, d_center, d_partials, &grid, false, nullptr, nullptr, nullptr, d_in_scale, d_in_shift,
-                                    d_in_scale ? nullptr : amax_part);
+                                    amax_part);
     if (rc) return rc;
     tf_fold<double>(d_partials, grid, 256, 256, 1.0, d_sums, (double *)(d_partials + (long)grid * 256), (hipStream_t)stream);
     if (d_amax) {
@@ -1667,6 +1671,26 @@ extern "C" int snk_conv3x3_f16s_igrad_stats_masked_res(const float *d_x, const v
     int grid = 0;
     const int rc = conv_f16s_launch(d_x, d_wS, nullptr, nullptr, d_residual, d_out, nullptr, 0.f, 0.f, nullptr, n_images, height, width, 0,
                                     true, stream, 0, d_mean, d_partials, &grid, false, d_y, d_mask, d_inv, nullptr, nullptr, nullptr,
+                                    d_residual_mask);
+    if (rc) return rc;
+    tf_fold<double>(d_partials, grid, 256, 256, 1.0, d_sums, (double *)(d_partials + (long)grid * 256), (hipStream_t)stream);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// snk_conv3x3_f16s_igrad_stats_masked_res for a layer below whose batch norm + ReLU output was never written (the deferred stem):
+// the ReLU decision of the SUMS is d_y * d_scale[c] + d_shift[c] > 0 instead of mask bytes
+extern "C" int snk_conv3x3_f16s_igrad_stats_masked_res_deferred(const float *d_x, const void *d_wS, const float *d_residual,
+                                                                const uint8_t *d_residual_mask, float *d_out, const float *d_y,
+                                                                const float *d_scale, const float *d_shift, const float *d_mean,
+                                                                const float *d_inv, float *d_partials, double *d_sums, int n_images,
+                                                                int height, int width, void *stream)
+{
+    SNK_REQUIRE(d_x && d_wS && d_residual && d_residual_mask && d_out && d_y && d_scale && d_shift && d_mean && d_inv && d_partials &&
+                d_sums && n_images > 0, "snk_conv3x3_f16s_igrad_stats_masked_res_deferred: bad argument");
+    int grid = 0;
+    const int rc = conv_f16s_launch(d_x, d_wS, nullptr, nullptr, d_residual, d_out, nullptr, 0.f, 0.f, nullptr, n_images, height, width, 0,
+                                    true, stream, 0, d_mean, d_partials, &grid, false, d_y, nullptr, d_inv, d_scale, d_shift, nullptr,
                                     d_residual_mask);
     if (rc) return rc;
     tf_fold<double>(d_partials, grid, 256, 256, 1.0, d_sums, (double *)(d_partials + (long)grid * 256), (hipStream_t)stream);

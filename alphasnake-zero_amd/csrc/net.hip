@@ -431,6 +431,7 @@ struct StemArgs {
     int group;           // k_stem_conv_mfma: images per iteration of a block (their padded copies sit side by side in LDS); 0 = 1
     const float *center; // k_stem_conv_mfma<0, true> (training step): per-channel centre of the batch-norm sums (or NULL = 0)
     float *stat_part;    //   [gridDim.x][2][128] sums of (out - center) and (out - center)^2 over the block's images
+    float *amax_part;    //   or NULL; [gridDim.x][128] largest |out - center| per channel (the range of a deferred batch norm's output)
 };
 
 // 256 pixels per block; thread (pg = tid / 32, cq = tid % 32) computes outputs 4 cq .. 4 cq + 3 of pixels pg + 8 k with its
@@ -577,8 +578,8 @@ __global__ __launch_bounds__(256) void k_stem_conv_mfma(StemArgs p)
 {
     extern __shared__ __align__(16) float st_img[];
     __shared__ float s_wmax[4];
-    __shared__ float s_stat[STATS ? 4 : 1][STATS ? 2 : 1][STATS ? CV_C : 1];
-    float cen[4] = {0.f, 0.f, 0.f, 0.f}, ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    __shared__ float s_stat[STATS ? 4 : 1][STATS ? 3 : 1][STATS ? CV_C : 1];
+    float cen[4] = {0.f, 0.f, 0.f, 0.f}, ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f}, smax[4] = {0.f, 0.f, 0.f, 0.f};
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
     const int Hd = p.Hd, Wd = p.Wd, HW = Hd * Wd, row3 = Wd * 3, P3 = (Wd + 2) * 3;
     const int n_img = p.M / HW;
@@ -717,7 +718,7 @@ __global__ __launch_bounds__(256) void k_stem_conv_mfma(StemArgs p)
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
                         const float v = fmaxf(__builtin_fmaf(acc[nt][r], scl[nt], shf[nt]), floor_);
-                        if (STATS) { const float e_ = v - cen[nt]; ssum[nt] += e_; ssq[nt] += e_ * e_; }
+                        if (STATS) { const float e_ = v - cen[nt]; ssum[nt] += e_; ssq[nt] += e_ * e_; smax[nt] = fmaxf(smax[nt], fabsf(e_)); }
                         if (OUT16 == 2) ((__bf16 *)out16)[(long)row * CV_C + 32 * nt + l31] = (__bf16)v;
                         else if (OUT16) out16[(long)row * CV_C + 32 * nt + l31] = (_Float16)fminf(v, 65504.f);
                         else out[(long)row * CV_C + 32 * nt + l31] = v;
@@ -731,11 +732,14 @@ __global__ __launch_bounds__(256) void k_stem_conv_mfma(StemArgs p)
         for (int nt = 0; nt < 4; ++nt) {
             ssum[nt] += __shfl_xor(ssum[nt], 32, 64);
             ssq[nt] += __shfl_xor(ssq[nt], 32, 64);
-            if (h == 0) { s_stat[wv][0][32 * nt + l31] = ssum[nt]; s_stat[wv][1][32 * nt + l31] = ssq[nt]; }
+            smax[nt] = fmaxf(smax[nt], __shfl_xor(smax[nt], 32, 64));
+            if (h == 0) { s_stat[wv][0][32 * nt + l31] = ssum[nt]; s_stat[wv][1][32 * nt + l31] = ssq[nt]; s_stat[wv][2][32 * nt + l31] = smax[nt]; }
         }
         __syncthreads();
         const int q = tid >> 7, c = tid & 127;
         p.stat_part[(size_t)blockIdx.x * 256 + tid] = ((s_stat[0][q][c] + s_stat[1][q][c]) + s_stat[2][q][c]) + s_stat[3][q][c];
+        if (p.amax_part && tid < CV_C)
+            p.amax_part[(size_t)blockIdx.x * CV_C + tid] = fmaxf(fmaxf(s_stat[0][2][tid], s_stat[1][2][tid]), fmaxf(s_stat[2][2][tid], s_stat[3][2][tid]));
     }
 }
 
@@ -919,7 +923,7 @@ template <int OUT16, bool STATS = false>
 static int stem_mfma_launch(StemArgs a, int n_images, size_t lds_one, int max_grid, hipStream_t st)
 {
     static const int group_max = getenv("SNK_STEM_GROUP") ? max(1, min(4, atoi(getenv("SNK_STEM_GROUP")))) : 4;
-    int g = (int)min((size_t)group_max, (size_t)((STATS ? 59 : 64) * 1024) / lds_one);     // (STATS: 4 KB of static LDS for the sums)
+    int g = (int)min((size_t)group_max, (size_t)((STATS ? 57 : 64) * 1024) / lds_one);     // (STATS: 6 KB of static LDS for the sums and maxima)
     g = max(1, min(g, n_images));
     a.group = g;
     const int grid = min((n_images + g - 1) / g, max_grid);
@@ -1013,6 +1017,30 @@ extern "C" int snk_stem_conv_f32(const float *d_x, const float *d_w, float *d_ou
     return 0;
 }
 
+// per-channel maximum over at most 512 rows of 128: [n_rows][128] -> [128]
+__global__ __launch_bounds__(128) void k_stem_amax_fold(const float *__restrict__ part, int n_rows, float *__restrict__ amax)
+{
+    float m = 0.f;
+    for (int r = 0; r < n_rows; ++r) m = fmaxf(m, part[(size_t)r * CV_C + threadIdx.x]);
+    amax[threadIdx.x] = m;
+}
+
+static int stem_stats_launch(const char *who, const float *d_x, const float *d_w, float *d_out, const float *d_center, float *d_amax,
+                             float *d_partials, double *d_sums, int n_images, int height, int width, void *stream)
+{
+    const long M = (long)n_images * height * width;
+    SNK_REQUIRE(M < (1l << 31), "%s: batch too large", who);
+    const size_t lds = (size_t)(height + 2) * (width + 2) * 3 * sizeof(float);
+    SNK_REQUIRE(lds <= 57 * 1024, "%s: observation %d x %d too large", who, height, width);
+    float *amax_part = d_amax ? d_partials + 512 * 256 : nullptr;          // (behind the at most 512 blocks' sums)
+    StemArgs a = {d_x, d_w, nullptr, nullptr, d_out, (int)M, height, width, 1, nullptr, 0, 0, d_center, d_partials, amax_part};
+    const int grid = stem_mfma_launch<0, true>(a, n_images, lds, 512, (hipStream_t)stream);
+    tf_fold<double>(d_partials, grid, 256, 256, 1.0, d_sums, (double *)(d_partials + 2048 * 256), (hipStream_t)stream);
+    if (d_amax) k_stem_amax_fold<<<1, 128, 0, (hipStream_t)stream>>>(amax_part, grid, d_amax);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // the same with the sums its batch norm starts from taken in the kernel's epilogue: d_sums[0..127] = sum over all pixels of (out -
 // center), d_sums[128..255] = sum of (out - center)^2 (float64; d_center: 128 floats or NULL) -- snk_bn_train_sums_f64(d_out) without
 // its pass over the output.  d_partials: snk_bn_train_partials() floats.
@@ -1020,15 +1048,16 @@ extern "C" int snk_stem_conv_f32_stats(const float *d_x, const float *d_w, float
                                        double *d_sums, int n_images, int height, int width, void *stream)
 {
     SNK_REQUIRE(d_x && d_w && d_out && d_partials && d_sums && n_images > 0, "snk_stem_conv_f32_stats: bad argument");
-    const long M = (long)n_images * height * width;
-    SNK_REQUIRE(M < (1l << 31), "snk_stem_conv_f32_stats: batch too large");
-    const size_t lds = (size_t)(height + 2) * (width + 2) * 3 * sizeof(float);
-    SNK_REQUIRE(lds <= 59 * 1024, "snk_stem_conv_f32_stats: observation %d x %d too large", height, width);
-    StemArgs a = {d_x, d_w, nullptr, nullptr, d_out, (int)M, height, width, 1, nullptr, 0, 0, d_center, d_partials};
-    const int grid = stem_mfma_launch<0, true>(a, n_images, lds, 512, (hipStream_t)stream);
-    tf_fold<double>(d_partials, grid, 256, 256, 1.0, d_sums, (double *)(d_partials + 2048 * 256), (hipStream_t)stream);
-    SNK_CHECK_HIP(hipGetLastError());
-    return 0;
+    return stem_stats_launch("snk_stem_conv_f32_stats", d_x, d_w, d_out, d_center, nullptr, d_partials, d_sums, n_images, height, width, stream);
+}
+
+// ... and, for a stem whose batch norm + ReLU output is never written (deferred, snake_engine/train_step.py), d_amax[128] = the largest
+// |out - center| per channel, what snk_bn_train_finalize_range turns into the range of that output
+extern "C" int snk_stem_conv_f32_stats_deferred(const float *d_x, const float *d_w, float *d_out, const float *d_center, float *d_amax,
+                                                float *d_partials, double *d_sums, int n_images, int height, int width, void *stream)
+{
+    SNK_REQUIRE(d_x && d_w && d_out && d_amax && d_partials && d_sums && n_images > 0, "snk_stem_conv_f32_stats_deferred: bad argument");
+    return stem_stats_launch("snk_stem_conv_f32_stats_deferred", d_x, d_w, d_out, d_center, d_amax, d_partials, d_sums, n_images, height, width, stream);
 }
 
 // the whole-canvas stem with the output written as f16 / bf16 [n][H][W][128] (input of snk_conv3x3_bn_f16_act16 / _bf16_act16)

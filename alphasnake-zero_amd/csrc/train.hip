@@ -105,10 +105,13 @@ __global__ __launch_bounds__(TR_THREADS) void k_bn_apply(const float *__restrict
                                                         float *__restrict__ out, long rows, int relu,
                                                         float *__restrict__ amax_part, uint8_t *__restrict__ mask_out,
                                                         const float *__restrict__ w1x1 = nullptr, const float *__restrict__ center1 = nullptr,
-                                                        float *__restrict__ z = nullptr, float *__restrict__ part1 = nullptr)
+                                                        float *__restrict__ z = nullptr, float *__restrict__ part1 = nullptr,
+                                                        const float *__restrict__ rsc = nullptr, const float *__restrict__ rsh = nullptr)
 {
     const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const float4 sc = *(const float4 *)(scale + 4 * cq), sh = *(const float4 *)(shift + 4 * cq);
+    float4 rs4 = sc, rh4 = sc;            // rsc: the shortcut is itself a deferred batch norm + ReLU output: res holds its PRE-batch-norm values
+    if (rsc) { rs4 = *(const float4 *)(rsc + 4 * cq); rh4 = *(const float4 *)(rsh + 4 * cq); }
     float4 w1 = sc;
     float cen1 = 0.f, hs = 0.f, hq = 0.f;
     if (HEAD) { w1 = *(const float4 *)(w1x1 + 4 * cq); if (center1) cen1 = center1[0]; }
@@ -118,7 +121,8 @@ __global__ __launch_bounds__(TR_THREADS) void k_bn_apply(const float *__restrict
         const float4 v = *(const float4 *)(y + o);
         float4 t = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
         if (res) {
-            const float4 a = *(const float4 *)(res + o);
+            float4 a = *(const float4 *)(res + o);
+            if (rsc) a = make_float4(fmaxf(a.x * rs4.x + rh4.x, 0.f), fmaxf(a.y * rs4.y + rh4.y, 0.f), fmaxf(a.z * rs4.z + rh4.z, 0.f), fmaxf(a.w * rs4.w + rh4.w, 0.f));
             t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
         }
         if (relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
@@ -244,6 +248,23 @@ extern "C" int snk_bn_train_apply(const float *d_y, const float *d_scale, const 
     const int grid = tr_grid(rows);
     k_bn_apply<false><<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_y, d_scale, d_shift, d_residual, d_out, rows, relu,
                                                                      d_out_scale_tail ? d_partials : nullptr, d_relu_mask);
+    if (d_out_scale_tail) k_amax_scale<<<1, 1024, 0, (hipStream_t)stream>>>(d_partials, grid, d_out_scale_tail);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// snk_bn_train_apply (relu = 1) whose shortcut is a deferred activation: d_res_y holds PRE-batch-norm values and every one is taken as
+// relu(y * res_scale[c] + res_shift[c]) -- the residual block right above a deferred stem reads the stem's output this way
+extern "C" int snk_bn_train_apply_res_deferred(const float *d_y, const float *d_scale, const float *d_shift, const float *d_res_y,
+                                               const float *d_res_scale, const float *d_res_shift, float *d_out, long rows,
+                                               float *d_partials, float *d_out_scale_tail, uint8_t *d_relu_mask, void *stream)
+{
+    SNK_REQUIRE(d_y && d_scale && d_shift && d_res_y && d_res_scale && d_res_shift && d_out && rows > 0 && (!d_out_scale_tail || d_partials),
+                "snk_bn_train_apply_res_deferred: bad argument");
+    const int grid = tr_grid(rows);
+    k_bn_apply<false><<<grid, TR_THREADS, 0, (hipStream_t)stream>>>(d_y, d_scale, d_shift, d_res_y, d_out, rows, 1,
+                                                                     d_out_scale_tail ? d_partials : nullptr, d_relu_mask, nullptr, nullptr,
+                                                                     nullptr, nullptr, d_res_scale, d_res_shift);
     if (d_out_scale_tail) k_amax_scale<<<1, 1024, 0, (hipStream_t)stream>>>(d_partials, grid, d_out_scale_tail);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;

@@ -116,6 +116,9 @@ PROTOTYPES = {
     "snk_conv3x3_f16s_stats": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "snk_conv3x3_f16s_igrad_stats": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "snk_train_deferred_bn_supported": (i32, [i32, i32]),
+    "snk_stem_conv_f32_stats_deferred": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "snk_bn_train_apply_res_deferred": (i32, [vp, vp, vp, vp, vp, vp, vp, C.c_long, vp, vp, vp, vp]),
+    "snk_conv3x3_f16s_igrad_stats_masked_res_deferred": (i32, [vp] * 12 + [i32, i32, i32, vp]),
     "snk_conv3x3_f16s_stats_deferred": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "snk_bn_train_finalize_range": (i32, [vp, f64, vp, vp, vp, vp, vp, f64, f64, vp, vp, vp, vp, vp, vp, i32, vp]),
     "snk_conv3x3_wgrad_f16s_deferred": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),

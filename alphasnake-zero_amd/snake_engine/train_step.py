@@ -58,6 +58,7 @@ _IGRAD_STATS = os.environ.get("SNK_TRAIN_IGRAD_STATS", "1") != "0"    # 0: the b
 _BATCH_PREP = os.environ.get("SNK_TRAIN_BATCH_PREP", "1") != "0"      # 0: every layer's weight images made one by one, each step (A/B runs)
 _RES_MASK = os.environ.get("SNK_TRAIN_RES_MASK", "1") != "0"          # 0: the shortcut's gradient is written as a masked copy (A/B runs)
 _HEAD_FUSED = os.environ.get("SNK_TRAIN_HEAD_FUSED", "1") != "0"      # 0: the head's 1x1 convolution in a pass of its own (A/B runs)
+_DEFER_STEM = os.environ.get("SNK_TRAIN_DEFER_STEM", "1") != "0"      # 0: the stem's batch norm + ReLU output is written (A/B runs)
 _DEFER_BN = os.environ.get("SNK_TRAIN_DEFER_BN", "1") != "0"          # 0: every layer's batch norm + ReLU output is written (A/B runs)
 BN_EPS, BN_MOMENTUM, L2_C = 1e-3, 0.99, 1e-5
 ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-7
@@ -113,6 +114,9 @@ class TrainStep:
             o += sz
         # a block's first layers (odd l) whose batch norm + ReLU is applied by the kernels that read its output (see the module text)
         self.defer = bool(_DEFER_BN and _CONV_STATS and self.L.snk_train_deferred_bn_supported(self.h, self.w) == 1)
+        # ... and the stem's (layer 0; readers: the first tower convolution, its weight gradient, the first block's shortcut, the stem's
+        # own batch-norm backward) -- only together with the masked shortcut gradient, whose launch is the one that takes layer 0's sums
+        self.defer_stem = bool(self.defer and _DEFER_STEM and _RES_MASK and _IGRAD_STATS)
         self.moving = {j: torch.as_tensor(ws[j].reshape(-1).copy(), device=self.dev) for j in range(len(ws)) if j not in self.view}
         self.adam_t = 0
         # ---- activations kept for the backward pass, gradients in flight
@@ -180,7 +184,7 @@ class TrainStep:
         return torch.cuda.current_stream(self.dev).cuda_stream
 
     def _deferred(self, l):
-        return self.defer and l % 2 == 1
+        return self.defer and (l % 2 == 1 or (l == 0 and self.defer_stem))
 
     def _k(self, l):                     # Keras list index of conv layer l's kernel (gamma, beta, moving mean / variance follow)
         return 5 * l
@@ -207,10 +211,18 @@ class TrainStep:
             return
         check(L.snk_bn_train_finalize(_p(self.sums), float(count), _p(mm), _p(self.view[k + 1]), _p(self.view[k + 2]), _p(mm), _p(mv),
                                       BN_MOMENTUM, BN_EPS, _p(self.mean[l]), _p(self.inv[l]), _p(self.scale[l]), _p(self.shift[l]), C, st))
-        if head:                                                 # the last layer: the head's 1x1 convolution and its sums ride along
+        if head and not isinstance(res, tuple):                  # the last layer: the head's 1x1 convolution and its sums ride along
             kh = self._k(self.n_layers)
             check(L.snk_bn_train_apply_head(_p(self.y[l]), _p(self.scale[l]), _p(self.shift[l]), _p(res), _p(relu_out), rows, _p(self.partials),
                                             _p(self.relu_mask[l]), _p(self.view[kh]), _p(self.moving[kh + 3]), _p(self.z), _p(self.h_sums), st))
+            return
+        if isinstance(res, tuple):                               # the shortcut is a deferred activation: (its y, its scale, its shift)
+            check(L.snk_bn_train_apply_res_deferred(_p(self.y[l]), _p(self.scale[l]), _p(self.shift[l]), _p(res[0]), _p(res[1]), _p(res[2]),
+                                                    _p(relu_out), rows, _p(self.partials), _p(tail), _p(self.relu_mask[l]), st))
+            if head:                                             # (a one-block net: the last layer's shortcut is the deferred stem)
+                kh = self._k(self.n_layers)
+                check(L.snk_head_conv1x1_sums(_p(relu_out), _p(self.view[kh]), rows, _p(self.moving[kh + 3]), _p(self.z), _p(self.partials),
+                                              _p(self.h_sums), st))
             return
         check(L.snk_bn_train_apply(_p(self.y[l]), _p(self.scale[l]), _p(self.shift[l]), _p(res), _p(relu_out), rows, 1,
                                    _p(self.partials), _p(tail), _p(self.relu_mask[l]), st))
@@ -228,7 +240,10 @@ class TrainStep:
         assert 0 < n <= self.max_rows and x.is_contiguous() and x.dtype == torch.float32 and tuple(x.shape[1:]) == (self.h, self.w, 3)
         count = n_global * self.hw
         self.x0, self.saved_rows = x, n
-        if _CONV_STATS:                                           # the stem's batch-norm sums leave its kernel with the output
+        if self._deferred(0):                                     # ... and the maxima its deferred batch norm is ranged by
+            check(L.snk_stem_conv_f32_stats_deferred(_p(x), _p(self.view[0]), _p(self.y[0]), _p(self.moving[3]), _p(self.amax), _p(self.partials),
+                                                     _p(self.sums), n, self.h, self.w, st))
+        elif _CONV_STATS:                                         # the stem's batch-norm sums leave its kernel with the output
             check(L.snk_stem_conv_f32_stats(_p(x), _p(self.view[0]), _p(self.y[0]), _p(self.moving[3]), _p(self.partials), _p(self.sums),
                                             n, self.h, self.w, st))
         else:
@@ -240,7 +255,8 @@ class TrainStep:
                 check(L.snk_conv3x3_prepare_weights_f16s_train(_p(self.view[k]), _p(self.img_f[l]), _p(self.tail_out[l - 1]), 0, None, st))
             if self._deferred(l - 1):                             # reads y_{l-1} through layer l - 1's batch norm + ReLU
                 check(L.snk_conv3x3_f16s_stats_deferred(_p(self.y[l - 1]), _p(self.img_f[l]), _p(self.y[l]), _p(self.moving[k + 3]),
-                                                        _p(self.scale[l - 1]), _p(self.shift[l - 1]), None, _p(self.cv_partials),
+                                                        _p(self.scale[l - 1]), _p(self.shift[l - 1]),
+                                                        _p(self.amax) if self._deferred(l) else None, _p(self.cv_partials),
                                                         _p(self.sums), n, self.h, self.w, st))
             elif self._deferred(l):                               # also takes the maxima its own deferred batch norm is ranged by
                 check(L.snk_conv3x3_f16s_stats_deferred(_p(self.out[l - 1]), _p(self.img_f[l]), _p(self.y[l]), _p(self.moving[k + 3]),
@@ -252,6 +268,8 @@ class TrainStep:
             else:
                 self._conv(self.out[l - 1], self.img_f[l], None, self.y[l], n)
             res = self.out[l - 2] if l % 2 == 0 else None                # a block's second layer adds the block's input
+            if l % 2 == 0 and self._deferred(l - 2):                     # ... which, above a deferred stem, is read from the stem's y
+                res = (self.y[l - 2], self.scale[l - 2], self.shift[l - 2])
             self._bn_forward(l, n, count, res, self.out[l], self.tail_out[l], have_sums=_CONV_STATS,
                              head=_HEAD_FUSED and l == self.n_layers - 1)
         kh = self._k(self.n_layers)
@@ -343,7 +361,14 @@ class TrainStep:
             have_sums = _IGRAD_STATS and (l - 1) not in self.mask_override
             dst = B if (masked and second) else A                 # (a block's second layer must not overwrite what its shortcut still needs)
             res = None if second else (A if masked else self.gres)
-            if masked and not second:
+            if have_sums and not second and not masked and self._deferred(l - 1):
+                have_sums = False                                 # (deferred stem below, shortcut as a masked copy: no launch takes both)
+            if masked and not second and self._deferred(l - 1):
+                check(L.snk_conv3x3_f16s_igrad_stats_masked_res_deferred(_p(self.dY), _p(self.img_b), _p(A), _p(self.relu_mask[l + 1]), _p(A),
+                                                                         _p(self.y[l - 1]), _p(self.scale[l - 1]), _p(self.shift[l - 1]),
+                                                                         _p(self.mean[l - 1]), _p(self.inv[l - 1]), _p(self.cv_partials),
+                                                                         _p(self.sums), n, self.h, self.w, st))
+            elif masked and not second:
                 check(L.snk_conv3x3_f16s_igrad_stats_masked_res(_p(self.dY), _p(self.img_b), _p(A), _p(self.relu_mask[l + 1]), _p(A),
                                                                 _p(self.y[l - 1]), _p(self.relu_mask[l - 1]), _p(self.mean[l - 1]),
                                                                 _p(self.inv[l - 1]), _p(self.cv_partials), _p(self.sums), n, self.h,

@@ -52,7 +52,7 @@ typedef struct {
 const char *snk_last_error(void);
 #define SNK_ABI_VERSION 111 /* 100: rounds 1-3; 110: round 5 (the gate argument d_skip of the tick kernels, round 4; the 16-bit
                              * towers' own weight image and rectangle plan, round 5); 111: the training step's deferred batch
-                             * norm (eleven entry points added, snk_conv3x3_stats_partials returns more): a caller compares it
+                             * norm (fourteen entry points added, snk_conv3x3_stats_partials returns more): a caller compares it
                              * with snk_version() */
 int snk_version(void);
 
@@ -509,14 +509,30 @@ int snk_conv3x3_f16s_igrad_stats(const float *d_x, const void *d_wS, const float
  * nor read: one element-wise pass over two 462 MB tensors less per block, in every step (also the forward-only steps at rate 0).
  *   snk_train_deferred_bn_supported(h, w)   1 when every kernel involved exists for the shape (the weight gradient's window form)
  *   snk_conv3x3_f16s_stats_deferred         snk_conv3x3_f16s_stats with d_in_scale / d_in_shift (both or neither: d_x is such a y)
- *                                           and d_amax (or NULL; plain input only): 128 floats, largest |out - center| per channel
+ *                                           and d_amax (or NULL): 128 floats, largest |out - center| per channel
  *   snk_bn_train_finalize_range             snk_bn_train_finalize + d_out_scale_tail = { ., ., 2^k, 2^-k } with 2^11 <= bound 2^k <
  *                                           2^12, bound = max_c relu(scale_c (center_c +- amax_c) + shift_c) >= every value the
  *                                           deferred activation takes (what snk_bn_train_apply measures while it writes)
  *   snk_conv3x3_wgrad_f16s_deferred         snk_conv3x3_wgrad_f16s whose X operand is such a y (d_x_tail from finalize_range)
  *   snk_conv3x3_f16s_igrad_stats_deferred   snk_conv3x3_f16s_igrad_stats whose ReLU decision is d_y * d_scale + d_shift > 0
  *   snk_bn_train_grad_sums_f64_deferred / snk_bn_train_grad_apply_deferred   the same decision in the two element-wise kernels */
+/*   The stem's own batch norm + ReLU output can be deferred the same way (readers: the first tower convolution, its weight gradient, the
+ *   first block's shortcut, the stem's batch-norm backward):
+ *   snk_stem_conv_f32_stats_deferred                snk_stem_conv_f32_stats + d_amax (128 floats: largest |out - center| per channel)
+ *   snk_conv3x3_f16s_stats_deferred                 with BOTH input scale / shift and d_amax: the layer right above
+ *   snk_bn_train_apply_res_deferred                 snk_bn_train_apply (relu = 1) whose shortcut d_res_y is PRE-batch-norm: relu(y s + t)
+ *   snk_conv3x3_f16s_igrad_stats_masked_res_deferred   ..._masked_res whose sums take the ReLU decision d_y * d_scale + d_shift > 0 */
 int snk_train_deferred_bn_supported(int height, int width);
+int snk_stem_conv_f32_stats_deferred(const float *d_x, const float *d_w, float *d_out, const float *d_center, float *d_amax,
+                                     float *d_partials, double *d_sums, int n_images, int height, int width, void *stream);
+int snk_bn_train_apply_res_deferred(const float *d_y, const float *d_scale, const float *d_shift, const float *d_res_y,
+                                    const float *d_res_scale, const float *d_res_shift, float *d_out, long rows, float *d_partials,
+                                    float *d_out_scale_tail, uint8_t *d_relu_mask, void *stream);
+int snk_conv3x3_f16s_igrad_stats_masked_res_deferred(const float *d_x, const void *d_wS, const float *d_residual,
+                                                     const uint8_t *d_residual_mask, float *d_out, const float *d_y,
+                                                     const float *d_scale, const float *d_shift, const float *d_mean,
+                                                     const float *d_inv, float *d_partials, double *d_sums, int n_images, int height,
+                                                     int width, void *stream);
 int snk_conv3x3_f16s_stats_deferred(const float *d_x, const void *d_wS, float *d_out, const float *d_center, const float *d_in_scale,
                                     const float *d_in_shift, float *d_amax, float *d_partials, double *d_sums, int n_images,
                                     int height, int width, void *stream);

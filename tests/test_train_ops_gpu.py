@@ -464,6 +464,7 @@ def test_shortcut_gradient_through_the_mask_bytes_equals_the_masked_copy(torch_g
     Y = torch.as_tensor(np.tanh(rs.randn(n, 3)).astype(np.float32), device="cuda")
     ws = net.glorot_uniform_weights((hw, hw, 3), blocks=blocks, seed=8)
     grads = {}
+    monkeypatch.setattr(train_step, "_DEFER_STEM", False)   # (layer 0's mask bytes are read below; the deferred stem has a test of its own)
     for masked in (True, False):
         monkeypatch.setattr(train_step, "_RES_MASK", masked)
         ts = train_step.TrainStep(ws, (hw, hw, 3), n, "cuda")
@@ -535,6 +536,80 @@ def test_sums_taken_in_the_stem_and_the_head_on_their_way_out(torch_gpu, n, hw):
     assert float((h_a - h_b).abs().max()) <= 1e-9 * float(h_a.abs().max())
     zr = (o_a.view(rows, 128).double() * w1.double()).sum(1)
     assert float((z_b.double() - zr).abs().max()) <= 1e-5 * float(zr.abs().max())
+
+
+@pytest.mark.parametrize("n,blocks,hw", [(24, 2, 21), (6, 1, 37), (10, 3, 13)])
+def test_deferred_stem_reads_the_same_values_as_the_written_activation(torch_gpu, monkeypatch, n, blocks, hw):
+    """round 5: the stem's batch norm + ReLU output deferred as well -- read from the stem's y by the first tower convolution (which
+    also takes its own maxima), by that layer's weight gradient (covered above), by the first block's shortcut
+    (snk_bn_train_apply_res_deferred) and, as a sign, by the launch that takes the stem's batch-norm backward sums
+    (snk_conv3x3_f16s_igrad_stats_masked_res_deferred).  Entry points bit-identical to their written-activation forms; whole
+    steps equal up to the input range's power of two (alpha_nnet.py:21-31 under Keras fit)"""
+    torch = torch_gpu
+    from snake_engine import net, train_step
+    from snake_engine._lib import lib, check
+    from snake_engine.train_step import _p
+    rs = np.random.RandomState(300 + n)
+    X = torch.as_tensor(rs.rand(n, hw, hw, 3).astype(np.float32), device="cuda")
+    Y = torch.as_tensor(np.tanh(rs.randn(n, 3)).astype(np.float32), device="cuda")
+    ws = net.glorot_uniform_weights((hw, hw, 3), blocks=blocks, seed=7)
+    for l in range(2 + 2 * blocks):
+        g_ = ws[5 * l + 1] * (0.6 + 0.8 * rs.rand(*ws[5 * l + 1].shape))
+        g_[::5] *= -1.0
+        ws[5 * l + 1] = g_.astype(np.float32)
+        ws[5 * l + 2] = (0.3 * rs.randn(*ws[5 * l + 2].shape)).astype(np.float32)
+    L, st = lib(), torch.cuda.current_stream().cuda_stream
+    runs = {}
+    for stem in (False, True):
+        monkeypatch.setattr(train_step, "_DEFER_STEM", stem)
+        ts = train_step.TrainStep(ws, (hw, hw, 3), n, "cuda")
+        assert ts.defer and ts.defer_stem == stem and (ts.out[0] is None) == stem and (ts.relu_mask[0] is None) == stem
+        q = ts.forward(X, Y, n).clone()
+        ts.backward(Y, n)
+        runs[stem] = (ts, q, ts.gradients(), ts.weights())
+    ts, q0, g0, w0 = runs[False]
+    td, q1, g1, w1 = runs[True]
+    rows, act = n * hw * hw, n * hw * hw * 128
+    true_max = float(ts.out[0][:act].max())
+    k_meas, k_bound = float(ts.tail_out[0][2]), float(td.tail_out[0][2])
+    assert true_max * k_bound < 2.0 ** 12 and k_bound >= k_meas / 64.0, (true_max, k_meas, k_bound)
+    # ---- the stem's maxima: exact
+    y0 = torch.empty(act, device="cuda")
+    amax = torch.zeros(128, device="cuda")
+    sums = torch.zeros(256, dtype=torch.float64, device="cuda")
+    check(L.snk_stem_conv_f32_stats_deferred(_p(X), _p(ts.view[0]), _p(y0), None, _p(amax), _p(ts.partials), _p(sums), n, hw, hw, st))
+    assert torch.equal(y0, ts.y[0][:act]) and torch.equal(amax, y0.view(rows, 128).abs().max(dim=0).values)
+    # ---- layer 1's forward convolution reading y_0 through the stem's scale / shift AND taking its own maxima
+    y1, y1_ref = torch.empty(act, device="cuda"), torch.empty(act, device="cuda")
+    ref = torch.zeros(256, dtype=torch.float64, device="cuda")
+    check(L.snk_conv3x3_f16s_stats(_p(ts.out[0]), _p(ts.img_f[1]), _p(y1_ref), None, _p(ts.cv_partials), _p(ref), n, hw, hw, st))
+    check(L.snk_conv3x3_f16s_stats_deferred(_p(ts.y[0]), _p(ts.img_f[1]), _p(y1), None, _p(ts.scale[0]), _p(ts.shift[0]), _p(amax),
+                                            _p(ts.cv_partials), _p(sums), n, hw, hw, st))
+    assert torch.equal(y1, y1_ref) and torch.equal(sums, ref) and torch.equal(amax, y1_ref.view(rows, 128).abs().max(dim=0).values)
+    # ---- the first block's shortcut read from y_0
+    o_a, o_b = torch.empty(act, device="cuda"), torch.empty(act, device="cuda")
+    m_a, m_b = torch.zeros(rows * 32, dtype=torch.uint8, device="cuda"), torch.zeros(rows * 32, dtype=torch.uint8, device="cuda")
+    t_a, t_b = torch.zeros(4, device="cuda"), torch.zeros(4, device="cuda")
+    check(L.snk_bn_train_apply(_p(ts.y[2]), _p(ts.scale[2]), _p(ts.shift[2]), _p(ts.out[0]), _p(o_a), rows, 1, _p(ts.partials), _p(t_a), _p(m_a), st))
+    check(L.snk_bn_train_apply_res_deferred(_p(ts.y[2]), _p(ts.scale[2]), _p(ts.shift[2]), _p(ts.y[0]), _p(ts.scale[0]), _p(ts.shift[0]), _p(o_b),
+                                            rows, _p(ts.partials), _p(t_b), _p(m_b), st))
+    assert torch.equal(o_a, o_b) and torch.equal(m_a, m_b) and torch.equal(t_a, t_b) and torch.equal(o_a, ts.out[2][:act])
+    # ---- the launch below layer 1: shortcut rows through layer 2's mask bytes, the stem's sums with the recomputed ReLU decision
+    g = torch.Generator(device="cuda").manual_seed(n)
+    R = torch.randn(act, device="cuda", generator=g) * 1e-3
+    out_a, out_b = R.clone(), R.clone()
+    check(L.snk_conv3x3_f16s_igrad_stats_masked_res(_p(ts.dY), _p(ts.img_b), _p(out_a), _p(ts.relu_mask[2]), _p(out_a), _p(ts.y[0]),
+                                                    _p(ts.relu_mask[0]), _p(ts.mean[0]), _p(ts.inv[0]), _p(ts.cv_partials), _p(ref), n, hw, hw, st))
+    check(L.snk_conv3x3_f16s_igrad_stats_masked_res_deferred(_p(ts.dY), _p(ts.img_b), _p(out_b), _p(ts.relu_mask[2]), _p(out_b), _p(ts.y[0]),
+                                                             _p(ts.scale[0]), _p(ts.shift[0]), _p(ts.mean[0]), _p(ts.inv[0]), _p(ts.cv_partials),
+                                                             _p(sums), n, hw, hw, st))
+    assert torch.equal(out_a, out_b) and torch.equal(sums, ref) and float(ref.abs().max()) > 0
+    # ---- whole steps
+    assert float((q0 - q1).abs().max()) <= 2e-6
+    for j in g0:
+        assert np.abs(g0[j] - g1[j]).max() <= 2e-5 * max(np.abs(g0[j]).max(), 1e-12), (j, np.abs(g0[j] - g1[j]).max(), np.abs(g0[j]).max())
+    for j, (u, v) in enumerate(zip(w0, w1)):
+        assert np.abs(u - v).max() <= 1e-6 * max(np.abs(u).max(), 1e-12), j
 
 
 def test_fit_on_the_kernels_tracks_fit_with_library_operators(torch_gpu):
