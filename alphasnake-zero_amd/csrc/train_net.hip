@@ -592,24 +592,48 @@ extern "C" int snk_head_dense_train_bwd(const float *d_q, const float *d_target,
 
 // 1-channel batch-norm backward fused with the rank-1 expansion into the last tower activation's gradient:
 // dz[r] = a (g[r] - b - zhat[r] c);  da[r][c] = dz[r] w1x1[c];  dw1x1[c] = sum_r a_last[r][c] dz[r]  (block partials)
+// STATS: the gradient it writes is the one the LAST tower layer's batch-norm backward starts from -- its two sums, sum(g') and
+//   sum(g' xhat) with g' = da where that layer's ReLU bit is set (k_bn_grad_sums, csrc/train.hip), are taken from the values on their
+//   way out (the layer's pre-batch-norm output and mask bytes are read here instead; the pass over da + y + mask is not needed)
+template <bool STATS>
 __global__ __launch_bounds__(TN_THREADS) void k_head_expand(const float *__restrict__ g, const float *__restrict__ z,
                                                            const float *__restrict__ mean_inv, const float *__restrict__ abc,
                                                            const float *__restrict__ a_last, const float *__restrict__ w1x1,
-                                                           float *__restrict__ da, float *__restrict__ part, long rows)
+                                                           float *__restrict__ da, float *__restrict__ part, long rows,
+                                                           const float *__restrict__ y_last = nullptr, const uint8_t *__restrict__ mask_last = nullptr,
+                                                           const float *__restrict__ mean_last = nullptr, const float *__restrict__ inv_last = nullptr,
+                                                           float *__restrict__ stat_part = nullptr)
 {
-    __shared__ float4 sh[8][32];
+    __shared__ float4 sh[STATS ? 24 : 8][32];
     const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const float4 w = *(const float4 *)(w1x1 + 4 * cq);
     const float mean = mean_inv[0], inv = mean_inv[1], A = abc[0], B = abc[1], Cc = abc[2];
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), ts = s, tq = s, mu = s, iv = s;
+    if (STATS) { mu = *(const float4 *)(mean_last + 4 * cq); iv = *(const float4 *)(inv_last + 4 * cq); }
     for (long r = (long)blockIdx.x * 8 + rl; r < rows; r += (long)gridDim.x * 8) {
         const float dz = A * (g[r] - B - ((z[r] - mean) * inv) * Cc);
         const float4 v = *(const float4 *)(a_last + r * TN_C + 4 * cq);
         s.x += v.x * dz; s.y += v.y * dz; s.z += v.z * dz; s.w += v.w * dz;
-        *(float4 *)(da + r * TN_C + 4 * cq) = make_float4(dz * w.x, dz * w.y, dz * w.z, dz * w.w);
+        const float4 d = make_float4(dz * w.x, dz * w.y, dz * w.z, dz * w.w);
+        *(float4 *)(da + r * TN_C + 4 * cq) = d;
+        if (STATS) {
+            const unsigned m_ = mask_last[r * 32 + cq];
+            const float4 yv = *(const float4 *)(y_last + r * TN_C + 4 * cq);
+            const float gx = (m_ & 1u) ? d.x : 0.f, gy = (m_ & 2u) ? d.y : 0.f, gz = (m_ & 4u) ? d.z : 0.f, gw = (m_ & 8u) ? d.w : 0.f;
+            ts.x += gx; ts.y += gy; ts.z += gz; ts.w += gw;
+            tq.x += gx * ((yv.x - mu.x) * iv.x); tq.y += gy * ((yv.y - mu.y) * iv.y);
+            tq.z += gz * ((yv.z - mu.z) * iv.z); tq.w += gw * ((yv.w - mu.w) * iv.w);
+        }
     }
     sh[rl][cq] = s;
+    if (STATS) { sh[8 + rl][cq] = ts; sh[16 + rl][cq] = tq; }
     __syncthreads();
+    if (STATS && rl >= 1 && rl <= 2) {
+        float4 t = sh[8 * rl][cq];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) { const float4 v = sh[8 * rl + r][cq]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        *(float4 *)(stat_part + (size_t)blockIdx.x * (2 * TN_C) + (rl - 1) * TN_C + 4 * cq) = t;
+    }
     if (rl == 0) {
         float4 t = sh[0][cq];
 #pragma unroll
@@ -625,8 +649,27 @@ extern "C" int snk_head_conv1x1_bwd(const float *d_g, const float *d_z, const fl
     SNK_REQUIRE(d_g && d_z && d_mean_inv && d_abc && d_a_last && d_w1x1 && d_da && d_dw1x1 && d_partials && rows > 0,
                 "snk_head_conv1x1_bwd: bad argument");
     const int grid = tn_grid(rows);
-    k_head_expand<<<grid, TN_THREADS, 0, (hipStream_t)stream>>>(d_g, d_z, d_mean_inv, d_abc, d_a_last, d_w1x1, d_da, d_partials, rows);
+    k_head_expand<false><<<grid, TN_THREADS, 0, (hipStream_t)stream>>>(d_g, d_z, d_mean_inv, d_abc, d_a_last, d_w1x1, d_da, d_partials, rows);
     tf_fold<float>(d_partials, grid, TN_C, TN_C, 1.0, d_dw1x1, (double *)(d_partials + TN_BN_PART), (hipStream_t)stream);
+    SNK_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// snk_head_conv1x1_bwd that also leaves the two sums the last tower layer's batch-norm backward starts from: d_sums[0..127] = sum(g'),
+// d_sums[128..255] = sum(g' (y - mean) inv), g' = d_da where d_mask_last's bit is set (snk_bn_train_grad_sums_f64(d_da, ..) without its
+// pass).  d_stat_partials: a second buffer of snk_bn_train_partials() floats.
+extern "C" int snk_head_conv1x1_bwd_stats(const float *d_g, const float *d_z, const float *d_mean_inv, const float *d_abc,
+                                          const float *d_a_last, const float *d_w1x1, float *d_da, float *d_dw1x1, float *d_partials,
+                                          const float *d_y_last, const uint8_t *d_mask_last, const float *d_mean_last,
+                                          const float *d_inv_last, float *d_stat_partials, double *d_sums, long rows, void *stream)
+{
+    SNK_REQUIRE(d_g && d_z && d_mean_inv && d_abc && d_a_last && d_w1x1 && d_da && d_dw1x1 && d_partials && d_y_last && d_mask_last &&
+                d_mean_last && d_inv_last && d_stat_partials && d_sums && rows > 0, "snk_head_conv1x1_bwd_stats: bad argument");
+    const int grid = tn_grid(rows);
+    k_head_expand<true><<<grid, TN_THREADS, 0, (hipStream_t)stream>>>(d_g, d_z, d_mean_inv, d_abc, d_a_last, d_w1x1, d_da, d_partials, rows,
+                                                                       d_y_last, d_mask_last, d_mean_last, d_inv_last, d_stat_partials);
+    tf_fold<float>(d_partials, grid, TN_C, TN_C, 1.0, d_dw1x1, (double *)(d_partials + TN_BN_PART), (hipStream_t)stream);
+    tf_fold<double>(d_stat_partials, grid, 2 * TN_C, 2 * TN_C, 1.0, d_sums, (double *)(d_stat_partials + TN_BN_PART), (hipStream_t)stream);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -137,6 +137,7 @@ PROTOTYPES = {
     "snk_head_dense_train_bwd_partials": (i32, [i32]),
     "snk_head_dense_train_bwd": (i32, [vp] * 10 + [f64] + [vp] * 6 + [i32, i32, i32, vp]),
     "snk_head_conv1x1_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_long, vp]),
+    "snk_head_conv1x1_bwd_stats": (i32, [vp] * 15 + [C.c_long, vp]),
     "snk_adam_l2_step": (i32, [vp, vp, vp, vp, vp, C.c_long, f64, f64, f64, f64, f64, vp]),
     "snk_l2_sum": (i32, [vp, vp, C.c_long, f64, vp, vp, vp]),
     "snk_clock_probe": (i32, [vp, i32, vp]),

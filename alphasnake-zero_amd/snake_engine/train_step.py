@@ -155,6 +155,7 @@ class TrainStep:
         self.ones, self.zeros = torch.ones(C, device=self.dev), f(C)
         self.sums, self.sums_local = f(2 * C, torch.float64), f(2 * C, torch.float64)
         self.partials = f(self.L.snk_bn_train_partials())
+        self.partials2 = f(self.L.snk_bn_train_partials())
         self.wg_partials = f(int(self.L.snk_conv3x3_wgrad_partials(self.h, self.w)))
         self.cv_partials = f(int(self.L.snk_conv3x3_stats_partials(self.max_rows, self.h, self.w)))
         self.sw_partials = f(int(self.L.snk_stem_wgrad_partials(self.max_rows, self.h, self.w)))
@@ -337,9 +338,15 @@ class TrainStep:
         check(L.snk_bn_train_grad_finalize(_p(self.h_sums), _p(local), float(count), _p(self.view[kh + 1]), _p(self.h_mean_inv) + 4,
                                            _p(self.h_abc), _p(self.h_abc) + 4, _p(self.h_abc) + 8, _p(self.gview[kh + 1]),
                                            _p(self.gview[kh + 2]), 1, st))
-        check(L.snk_head_conv1x1_bwd(_p(self.g1), _p(self.z), _p(self.h_mean_inv), _p(self.h_abc), _p(self.out[-1]), _p(self.view[kh]),
-                                     _p(self.dA), _p(self.gview[kh]), _p(self.partials), rows, st))
-        have_sums = False
+        top = self.n_layers - 1
+        have_sums = _HEAD_FUSED and top not in self.mask_override   # the top layer's backward sums leave with the gradient the head writes
+        if have_sums:
+            check(L.snk_head_conv1x1_bwd_stats(_p(self.g1), _p(self.z), _p(self.h_mean_inv), _p(self.h_abc), _p(self.out[-1]), _p(self.view[kh]),
+                                               _p(self.dA), _p(self.gview[kh]), _p(self.partials), _p(self.y[top]), _p(self.relu_mask[top]),
+                                               _p(self.mean[top]), _p(self.inv[top]), _p(self.partials2), _p(self.sums), rows, st))
+        else:
+            check(L.snk_head_conv1x1_bwd(_p(self.g1), _p(self.z), _p(self.h_mean_inv), _p(self.h_abc), _p(self.out[-1]), _p(self.view[kh]),
+                                         _p(self.dA), _p(self.gview[kh]), _p(self.partials), rows, st))
         A, B, masked = self.dA, self.dA2, False                   # A holds the gradient a block receives at its output
         for l in range(self.n_layers - 1, 0, -1):
             k, second = self._k(l), l % 2 == 0

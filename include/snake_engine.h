@@ -52,7 +52,7 @@ typedef struct {
 const char *snk_last_error(void);
 #define SNK_ABI_VERSION 111 /* 100: rounds 1-3; 110: round 5 (the gate argument d_skip of the tick kernels, round 4; the 16-bit
                              * towers' own weight image and rectangle plan, round 5); 111: the training step's deferred batch
-                             * norm (fourteen entry points added, snk_conv3x3_stats_partials returns more): a caller compares it
+                             * norm (fifteen entry points added, snk_conv3x3_stats_partials returns more): a caller compares it
                              * with snk_version() */
 int snk_version(void);
 
@@ -583,6 +583,13 @@ int snk_head_dense_train_bwd(const float *d_q, const float *d_target, const floa
                              double *d_gsums, float *d_partials, int n_images, int height, int width, void *stream);
 int snk_head_conv1x1_bwd(const float *d_g, const float *d_z, const float *d_mean_inv, const float *d_abc, const float *d_a_last,
                          const float *d_w1x1, float *d_da, float *d_dw1x1, float *d_partials, long rows, void *stream);
+/* snk_head_conv1x1_bwd that also leaves the two sums the LAST tower layer's batch-norm backward starts from (d_sums as
+ * snk_bn_train_grad_sums_f64(d_da, NULL, d_mask_last, d_y_last, d_mean_last, d_inv_last, ..) leaves them, without that pass over the
+ * gradient it has just written); d_stat_partials: a second buffer of snk_bn_train_partials() floats */
+int snk_head_conv1x1_bwd_stats(const float *d_g, const float *d_z, const float *d_mean_inv, const float *d_abc, const float *d_a_last,
+                               const float *d_w1x1, float *d_da, float *d_dw1x1, float *d_partials, const float *d_y_last,
+                               const uint8_t *d_mask_last, const float *d_mean_last, const float *d_inv_last,
+                               float *d_stat_partials, double *d_sums, long rows, void *stream);
 int snk_adam_l2_step(float *d_w, const float *d_g, float *d_m, float *d_v, const uint8_t *d_decay, long n, double lr_t,
                      double beta1, double beta2, double epsilon, double l2, void *stream);
 int snk_l2_sum(const float *d_w, const uint8_t *d_decay, long n, double scale, float *d_partials, float *d_out, void *stream);

@@ -536,6 +536,24 @@ def test_sums_taken_in_the_stem_and_the_head_on_their_way_out(torch_gpu, n, hw):
     assert float((h_a - h_b).abs().max()) <= 1e-9 * float(h_a.abs().max())
     zr = (o_a.view(rows, 128).double() * w1.double()).sum(1)
     assert float((z_b.double() - zr).abs().max()) <= 1e-5 * float(zr.abs().max())
+    # ---- and back: the head's expansion kernel leaves with the two sums the last layer's batch-norm backward starts from
+    gz = torch.randn(rows, device="cuda", generator=g) * 1e-2
+    mean_inv = torch.tensor([0.1, 1.7], device="cuda")
+    abc = torch.tensor([0.9, 0.01, 0.02], device="cuda")
+    mu, iv = torch.randn(128, device="cuda", generator=g) * 0.1, torch.rand(128, device="cuda", generator=g) + 0.5
+    da_a, da_b = torch.empty(rows * 128, device="cuda"), torch.empty(rows * 128, device="cuda")
+    dw_a, dw_b = torch.zeros(128, device="cuda"), torch.zeros(128, device="cuda")
+    part2 = torch.empty(L.snk_bn_train_partials(), device="cuda")
+    gs_a, gs_b = torch.zeros(256, dtype=torch.float64, device="cuda"), torch.zeros(256, dtype=torch.float64, device="cuda")
+    check(L.snk_head_conv1x1_bwd(gz.data_ptr(), z_a.data_ptr(), mean_inv.data_ptr(), abc.data_ptr(), o_a.data_ptr(), w1.data_ptr(),
+                                 da_a.data_ptr(), dw_a.data_ptr(), part.data_ptr(), rows, st))
+    check(L.snk_bn_train_grad_sums_f64(da_a.data_ptr(), None, m_a.data_ptr(), y.data_ptr(), mu.data_ptr(), iv.data_ptr(), rows, 1,
+                                       part.data_ptr(), gs_a.data_ptr(), st))
+    check(L.snk_head_conv1x1_bwd_stats(gz.data_ptr(), z_a.data_ptr(), mean_inv.data_ptr(), abc.data_ptr(), o_a.data_ptr(), w1.data_ptr(),
+                                       da_b.data_ptr(), dw_b.data_ptr(), part.data_ptr(), y.data_ptr(), m_a.data_ptr(), mu.data_ptr(),
+                                       iv.data_ptr(), part2.data_ptr(), gs_b.data_ptr(), rows, st))
+    assert torch.equal(da_a, da_b) and torch.equal(dw_a, dw_b)
+    assert float((gs_a - gs_b).abs().max()) <= 1e-9 * float(gs_a.abs().max()) and float(gs_a.abs().max()) > 0
 
 
 @pytest.mark.parametrize("n,blocks,hw", [(24, 2, 21), (6, 1, 37), (10, 3, 13)])
