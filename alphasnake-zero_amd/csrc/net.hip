@@ -1018,11 +1018,24 @@ extern "C" int snk_stem_conv_f32(const float *d_x, const float *d_w, float *d_ou
 }
 
 // per-channel maximum over at most 512 rows of 128: [n_rows][128] -> [128]
-__global__ __launch_bounds__(128) void k_stem_amax_fold(const float *__restrict__ part, int n_rows, float *__restrict__ amax)
+// (eight row lanes x 32 float4 columns: whole 512-byte rows per load, 64 loads in flight per lane group instead of 512 one after the other)
+__global__ __launch_bounds__(256) void k_stem_amax_fold(const float *__restrict__ part, int n_rows, float *__restrict__ amax)
 {
-    float m = 0.f;
-    for (int r = 0; r < n_rows; ++r) m = fmaxf(m, part[(size_t)r * CV_C + threadIdx.x]);
-    amax[threadIdx.x] = m;
+    __shared__ float4 sh[8][32];
+    const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int r = rl; r < n_rows; r += 8) {
+        const float4 v = *(const float4 *)(part + (size_t)r * CV_C + 4 * cq);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+    }
+    sh[rl][cq] = m;
+    __syncthreads();
+    if (rl == 0) {
+#pragma unroll
+        for (int r = 1; r < 8; ++r) { const float4 v = sh[r][cq]; m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w); }
+        *(float4 *)(amax + 4 * cq) = m;
+    }
 }
 
 static int stem_stats_launch(const char *who, const float *d_x, const float *d_w, float *d_out, const float *d_center, float *d_amax,
@@ -1036,7 +1049,7 @@ static int stem_stats_launch(const char *who, const float *d_x, const float *d_w
     StemArgs a = {d_x, d_w, nullptr, nullptr, d_out, (int)M, height, width, 1, nullptr, 0, 0, d_center, d_partials, amax_part};
     const int grid = stem_mfma_launch<0, true>(a, n_images, lds, 512, (hipStream_t)stream);
     tf_fold<double>(d_partials, grid, 256, 256, 1.0, d_sums, (double *)(d_partials + 2048 * 256), (hipStream_t)stream);
-    if (d_amax) k_stem_amax_fold<<<1, 128, 0, (hipStream_t)stream>>>(amax_part, grid, d_amax);
+    if (d_amax) k_stem_amax_fold<<<1, 256, 0, (hipStream_t)stream>>>(amax_part, grid, d_amax);
     SNK_CHECK_HIP(hipGetLastError());
     return 0;
 }
