@@ -169,6 +169,7 @@ class TrainStep:
         self.hb_partials = f(self.L.snk_head_dense_train_bwd_partials(self.max_rows))
         self.l2_partials = f(1024)
         self.l2_value = f(1)
+        self.l2_version = -1                                             # the weights' version l2_value was computed for
         self.mask_override = {}          # tests: layer -> tensor whose sign replaces out > 0 as the ReLU mask ('h', 'd1': the head's)
         self.saved_rows = 0
 
@@ -402,6 +403,7 @@ class TrainStep:
         self.backward(target, n_global)
         self._all_reduce(self.G)                                       # every gradient + the squared-error term, one bucket
         check(L.snk_l2_sum(_p(self.W), _p(self.decay), self.n_params, L2_C, _p(self.l2_partials), _p(self.l2_value), st))
+        self.l2_version = self.w_version
         loss = torch.stack([self.G[self.n_params], self.l2_value[0]])
         self.adam_t += 1
         lr_t = lr * np.sqrt(1.0 - ADAM_B2 ** self.adam_t) / (1.0 - ADAM_B1 ** self.adam_t)
@@ -416,7 +418,9 @@ class TrainStep:
         self.forward(x, target, n_global)
         mse = self.G[self.n_params:self.n_params + 1]
         self._all_reduce(mse)
-        check(L.snk_l2_sum(_p(self.W), _p(self.decay), self.n_params, L2_C, _p(self.l2_partials), _p(self.l2_value), st))
+        if self.l2_version != self.w_version:                          # (the weights of a forward-only step are those of the step before)
+            check(L.snk_l2_sum(_p(self.W), _p(self.decay), self.n_params, L2_C, _p(self.l2_partials), _p(self.l2_value), st))
+            self.l2_version = self.w_version
         self.adam_t += 1
         return torch.stack([mse[0], self.l2_value[0]])
 
