@@ -640,8 +640,13 @@ __device__ __forceinline__ void hs_block(const ConvHsArgs &p, unsigned char *sme
             // gfx950 reads a 16-byte store's data registers over several cycles; the compiler guards a VALU write to them that follows at
             // once only when the store has NO scalar offset (measured here: rows whose data register pair was rewritten by the
             // next row's v_pk_fma_f32 in the cycle after the store reached HBM with the NEXT row's values in the last four lanes of
-            // every sixteen, tools/dbg/igrad_dbg.py) -- so: wait states by hand, and nothing scheduled across them
+            // every sixteen, tools/dbg/igrad_dbg.py) -- so: wait states by hand, and nothing scheduled across them.  The rule as
+            // measured (tools/micro/store_hazard.hip, profiles/r6_store_hazard_micro.json): with an SGPR soffset ONE wait state is
+            // enough, without one it takes two (those the compiler inserts).  tests/test_store_hazard_cpu.py checks every wide
+            // store of the shipped code objects against it; HS_NO_STORE_NOP is that test's proof that it bites.
+#ifndef HS_NO_STORE_NOP
             asm volatile("s_nop 2");
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     }

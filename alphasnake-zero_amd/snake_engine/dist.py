@@ -14,6 +14,10 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+# the seed the ranks share for share_counts comes from a stream of this module's own: a run over N ranks must leave the caller's
+# global NumPy / random state exactly where a one-rank run leaves it (the reference draws nothing here, trainer.py:63-75)
+_seed_stream = np.random.Generator(np.random.PCG64())
+
 BATCH_ROWS = 2048          # trainer.py:63
 MAX_BATCHES = 5            # trainer.py:65
 
@@ -34,7 +38,7 @@ def sample_plan(n_records_all_ranks, world=1):
 def gather_counts(n_local_records, group=None, single_rank_collective=False):
     """(every rank's record count, a seed all ranks share): one small all-gather.  The counts decide how many rows each rank
     contributes (share_counts); the seed is rank 0's draw, so that every rank computes the same split."""
-    seed = int(np.random.randint(1 << 31))
+    seed = int(_seed_stream.integers(1 << 31))
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not single_rank_collective):
         return [int(n_local_records)], seed
     world = dist.get_world_size(group)

@@ -176,7 +176,13 @@ class DeviceMCTS:
             self.guard.guard_post()
             torch.cuda.current_stream().synchronize()
             if self.guard.guard_tripped():
-                self.guard.guard_recover()
+                try:
+                    self.guard.guard_recover()
+                except EngineError as e:
+                    # a tower with nothing to widen (f16a) reports the saturation by raising -- but THIS flag was left by an earlier
+                    # launch (range_flags has cleared it by now): no evaluation of this search has run yet, nothing to refuse
+                    import warnings
+                    warnings.warn(f"range flag left set by a launch before this search (cleared): {e}")
         for ep in range(epochs):
             t_epoch = time()
             root.clone_to(self.roll, src_slots=live_slots, n=G, fanout=par)       # game.subgame (agent.py:46-50)
@@ -236,7 +242,11 @@ class DeviceMCTS:
                         guard.guard_recover()
                         self.clear()
                         raise EngineError("the Q-net's range guard tripped four times on the same batch; use SNK_CONV_ALGO=winograd")
-                    guard.guard_recover()
+                    try:
+                        guard.guard_recover()
+                    except EngineError:
+                        self.clear()       # the tick's new entries have no priors: a caller that catches this must not keep them
+                        raise
                     pend["redos"] += 1
                     self.guard_redos += 1
                     tail(pend)

@@ -256,7 +256,14 @@ class QNet:
                     self._tail(i, torch.int32)[4] = 0
         return out
 
+    F16A_SATURATED = ("f16-activation tower: outputs of tower layer(s) {} exceeded the f16 range and were saturated; use "
+                      "SNK_CONV_ALGO=bf16 (float32's exponent range) or the float32-accurate default")
+
     def widen(self, layers, factor=2.0 ** -6):
+        if layers and self.conv_algo == "f16a":
+            # the 16-bit frame never multiplies by the activation scale, but its epilogue multiplies by the tail's inverse: a
+            # "lowered" scale would silently scale that layer's outputs by 2^6 from then on.  There is nothing to widen.
+            raise EngineError(self.F16A_SATURATED.format(list(layers)))
         for i in layers:
             self.set_x_scale(i, self.conv_x_scale[i] * factor)
 
@@ -318,11 +325,8 @@ class QNet:
     def guard_recover(self):
         """a launch clamped: lower the flagged layers' activation scales by 2^6, clear the flags and the word"""
         bad = [i for i, f in enumerate(self.range_flags()) if f]      # also clears the word and its mirror
-        if bad and self.conv_algo == "f16a":
-            # f16 activations in HBM have no scale to lower: an output beyond 65 504 was saturated and nothing can evaluate the batch
-            # exactly in this form -- say so instead of handing on values computed from saturated activations
-            raise EngineError(f"f16-activation tower: outputs of tower layer(s) {bad} exceeded the f16 range and were saturated; "
-                              "use SNK_CONV_ALGO=bf16 (float32's exponent range) or the float32-accurate default")
+        # (f16a: f16 activations in HBM have no scale to lower -- an output beyond 65 504 was saturated and nothing can evaluate the
+        # batch exactly in this form; widen() says so instead of handing on values computed from saturated activations)
         self.widen(bad)
         self.guard_trips += 1
         return bad

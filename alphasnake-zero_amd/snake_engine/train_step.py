@@ -69,11 +69,13 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-def supported(input_shape):
-    """the shapes whose weight-gradient kernels exist (square observations that fit their LDS images)"""
+def supported(input_shape, blocks=1):
+    """the shapes whose weight-gradient kernels exist (square observations that fit their LDS images).  A net WITHOUT residual
+    blocks (stem -> head; not a reference shape, alpha_nnet.py:25 builds four) has no tower for the batched weight images, the
+    fused head sums and the deferred stem to hang on: it is not supported and fit() says so."""
     h, w = int(input_shape[0]), int(input_shape[1])
     L = lib()
-    return h == w and L.snk_conv3x3_wgrad_partials(h, w) > 0 and L.snk_stem_wgrad_partials(1, h, w) > 0
+    return blocks >= 1 and h == w and L.snk_conv3x3_wgrad_partials(h, w) > 0 and L.snk_stem_wgrad_partials(1, h, w) > 0
 
 
 class TrainStep:
@@ -86,8 +88,8 @@ class TrainStep:
         self.blocks = (len(weights) - 14) // 10
         self.n_layers = 1 + 2 * self.blocks                     # stem + tower layers, all 128 channels wide
         self.max_rows = int(max_rows)
-        if not supported(input_shape):
-            raise ValueError(f"TrainStep: no weight-gradient kernel for {self.h} x {self.w} observations")
+        if not supported(input_shape, self.blocks):
+            raise ValueError(f"TrainStep: no weight-gradient kernel for {self.h} x {self.w} observations and {self.blocks} residual blocks")
         ws = [np.asarray(w, np.float32) for w in weights]
         # ---- flat parameters: per conv layer kernel, gamma, beta; then Dense kernels and biases (Keras order without the moving stats)
         self.param_idx, self.kernel_idx = [], []

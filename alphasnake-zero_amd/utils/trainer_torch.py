@@ -203,12 +203,12 @@ def fit(weights, input_shape, X, Y, epochs=32, batch_size=2048, lr_schedule=None
     native = None
     if _NATIVE and device.type == "cuda" and dtype == torch.float32:
         from snake_engine import train_step
-        if train_step.supported(input_shape):
+        if train_step.supported(input_shape, (len(weights) - 14) // 10):
             native = train_step.TrainStep(weights, input_shape, -(-min(batch_size, n) // world), device, dist)
         else:
             import warnings
-            warnings.warn(f"fit: no weight-gradient kernel for {tuple(input_shape)} observations (square, width 3 .. 96): "
-                          "this fit runs on PyTorch's operators")
+            warnings.warn(f"fit: no weight-gradient kernel for {tuple(input_shape)} observations (square, width 3 .. 96, at least one "
+                          "residual block): this fit runs on PyTorch's operators")
     if native is None:
         net = _Net(weights, device, dtype)        # float64 only for the cross-checks in tests/test_trainer_cpu.py
         params = net.params()

@@ -203,6 +203,45 @@ def conv_traffic_profile(L, algo, n_rect, flops_per_launch, profiles_dir=None, b
     return d["hbm_bytes_per_state_layer"] * flops_per_launch / (2.0 * side * side * 9 * 128 * 128), os.path.relpath(path, REPO)
 
 
+def conv_counters_profile(L, algo, board=11, profiles_dir=None):
+    """(SQ-counter summary of the conv launches, profile file) from the newest profiles/*sq_counters.json taken on the kernel
+    sources the loaded library was built from (tools/pmc_tower.sh -> tools/pmc_collect.py name every csrc hash); (None, reason)
+    otherwise -- counters of another build say nothing about this one"""
+    import glob
+    have = {f: (L.snk_source_hash(f.encode()) or b"").decode() for f in ("conv_split.hip", "common.h")}
+    want = "f16s<" if algo == "f16s" else "false, 3"            # the split form's symbols / the 16-bit frame's (SPLIT = false, IO16 = 3)
+    cands = []
+    for path in glob.glob(os.path.join(profiles_dir or os.path.join(REPO, "profiles"), "*sq_counters.json")):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        src = d.get("source_sha256", {})
+        note = d.get("note", "")
+        args = note.split("tower_only.py", 1)[1].split()[:3] if "tower_only.py" in note else []      # games, forwards[, board]
+        note_board = int(args[2]) if len(args) > 2 and args[2].isdigit() else 11
+        if all(src.get(f) == h for f, h in have.items()) and f"SNK_CONV_ALGO={algo}" in note and note_board == board:
+            cands.append((os.path.getmtime(path), path, d))
+    if not cands:
+        return None, "no SQ-counter profile under profiles/ was taken on this library's csrc/conv_split.hip (snk_source_hash) for this tower"
+    _, path, d = max(cands)
+    out = {}
+    for k, v in d.get("kernels", {}).items():
+        p_, dv = v.get("per_dispatch", {}), v.get("derived", {})
+        if p_.get("SQ_INSTS_MFMA", 0) < 1e5 or (want not in k and algo != "f16s"):
+            continue
+        row = {"dispatches": v.get("dispatches")}
+        if "mfma_busy_per_busy_cycle" in dv:
+            # SQ_VALU_MFMA_BUSY_CYCLES sums over 1 024 SIMDs, SQ_BUSY_CYCLES over 32 shader engines: 32 = every SIMD's pipe busy
+            row["mfma_busy_share"] = dv["mfma_busy_per_busy_cycle"] / 32.0
+        for a, b in (("lds_conflict_share", "lds_conflict_share"), ("wait_inst_any_share_of_wave_cycles", "sq_wait_inst_any_share_of_wave_cycles"),
+                     ("wait_any_share_of_wave_cycles", "sq_wait_any_share_of_wave_cycles"), ("valu_per_mfma", "valu_instructions_per_mfma")):
+            if b in dv:
+                row[a] = dv[b]
+        out[k] = row
+    return out, os.path.relpath(path, REPO)
+
+
 def workload_label(board, snakes, blocks, games, breadth, world):
     """which BASELINE.json config a run is (shape AND size), or 'custom'"""
     if (board, snakes, blocks) == (11, 4, 4):
@@ -293,6 +332,9 @@ def main():
     ap.add_argument("--no-conv-timing", action="store_true",
                     help="no HIP events around the conv launches (roofline.achieved is then null): for small, launch-bound runs")
     ap.add_argument("--no-kernel-rooflines", action="store_true")
+    ap.add_argument("--trace-markers", action="store_true",
+                    help="launch the one-wavefront k_clock_probe kernel (1 us) at the start and at the end of the timed self-play steps: "
+                         "tools/gpu_busy.py finds the timed region in a rocprofv3 kernel trace by these two launches")
     ap.add_argument("--no-clock-probe", action="store_true",
                     help="skip the untimed extra root turn that samples the shader clock beside the forward chunks (roofline.clock_mhz)")
     args = ap.parse_args()
@@ -367,6 +409,7 @@ def main():
     log(f"[rank {rank}] warmup {args.warmup} turns in {time.time() - t_w:.1f} s")
     m = alice._mcts
     ev0, sim0 = (m.stats["net_evals"], m.stats["sim_steps"]) if m is not None else (0, 0)     # --warmup 0: nothing ran yet
+    tick0 = m.stats["rollout_ticks"] if m is not None else 0
     nnet._qnet.conv_timing = None if args.no_conv_timing else []
     nnet._qnet.rect_tiles = None if args.no_conv_timing or not nnet._qnet.n_rect else []      # GEMM tiles the sub-rectangle layers execute
     coll_dev = "cuda" if backend == "nccl" else "cpu"
@@ -374,15 +417,24 @@ def main():
     def sync_clock():
         torch.cuda.synchronize()
         return time.time()
+    marker = None
+    if args.trace_markers:
+        marker = torch.zeros((2, 2), dtype=torch.int64, device="cuda")
+
+    def mark(i):
+        if marker is not None:
+            se.check(se.lib().snk_clock_probe(marker[i].data_ptr(), 1, torch.cuda.current_stream().cuda_stream))
     barrier()
     t0 = time.time()
     cpu0 = time.process_time()
     env_steps = 0
+    mark(0)
     for k in range(args.steps):                # one root turn per call: the same launches, plus a progress line per step
         gr.run(alice, max_turns=1)
         env_steps += gr.env_steps
         if rank == 0:
             log(f"[rank 0] step {k + 1}/{args.steps}: {gr.env_steps} env-steps, {time.time() - t0:.1f} s since the start of the timed region")
+    mark(1)
     t_play = sync_clock() - t0
     cpu_play = time.process_time() - cpu0      # user + system cpu seconds of this rank's process over the self-play steps
     # iteration-end exchange (trainer.py:63-75 across ranks): the row count comes from the records of ALL ranks, every rank
@@ -406,6 +458,7 @@ def main():
     m = alice._mcts
     evals = m.stats["net_evals"] - ev0
     sims = m.stats["sim_steps"] - sim0
+    rollout_ticks = m.stats["rollout_ticks"] - tick0
     n_records = len(alice.records)
     tm = nnet._qnet.conv_timing or []
     nnet._qnet.conv_timing = None
@@ -473,6 +526,7 @@ def main():
         traffic, traffic_src = None, None
         if tm:
             traffic, traffic_src = conv_traffic_profile(se.lib(), algo, qn.n_rect, conv_flops / len(tm), board=B)
+        counters, counters_src = conv_counters_profile(se.lib(), algo, board=B)
         res = {
             "metric": "self-play env-steps/sec (11x11, 4 snakes, 50 MCTS sims)",
             "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -491,7 +545,8 @@ def main():
                        "games_total": args.games * world, "host_threads_per_rank": host_threads,
                        "env": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")},
                        "net_evals_per_env_step": evals / max(1, env_steps_rank0), "sim_steps_per_env_step": sims / max(1, env_steps_rank0),
-                       "net_evals_per_s_rank0": evals / dt, "sample_rows_gathered": int(Xg.shape[0])},
+                       "net_evals_per_s_rank0": evals / dt, "rollout_ticks_per_step": rollout_ticks / max(1, args.steps),
+                       "net_evals_per_rollout_tick": evals / max(1, rollout_ticks), "sample_rows_gathered": int(Xg.shape[0])},
             "roofline": {"bound": "mfma",
                          "kernel": {"winograd": "k_conv3x3_wino_f32", "bf16": "k_conv3x3_f16s<SPLIT = false, IO16, BF = true>" + (" + its sub-rectangle form" if rect else ""),
                                     "f16s": "k_conv3x3_f16s" + (" + k_conv3x3_f16s_rect (the same body on sub-rectangles)" if rect else ""),
@@ -499,6 +554,7 @@ def main():
                                     "f16a": "k_conv3x3_f16s<SPLIT = false, IO16>"}.get(algo, "k_conv3x3_f32"),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
+                         "counters": counters, "counters_source": counters_src,
                          "launches": len(tm),
                          "flops_convention": "algorithmic = direct 3x3 convolution, 2*441*1152*128 per state and layer (SURVEY 8d)",
                          "executed_frac": achieved / peak * executed if achieved else None,

@@ -179,6 +179,107 @@ def test_a_rank_without_records_fails_on_every_rank_and_a_short_trailing_batch_i
         assert np.array_equal(a, b) and np.abs(a - c).max() <= 1e-9 * max(1.0, np.abs(c).max())
 
 
+EIGHT_COUNTS = [3000, 10, 2500, 700, 5000, 1, 2048, 4000]          # records per rank: three ranks hold less than their share of 1 280
+
+
+def _eight_worker(rank, world, port, out_dir):
+    """the whole iteration-end exchange and a data-parallel fit at the world size the headline is quoted on (8), over gloo"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    import datetime
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [repo, os.path.join(repo, "alphasnake-zero_amd")]
+    torch.set_num_threads(1)
+    from snake_engine import dist as sdist
+    from utils.alpha_snake_zero_trainer import AlphaSnakeZeroTrainer
+    from utils import trainer_torch
+    from snake_engine.net import glorot_uniform_weights
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        np.random.seed(77)
+        state0 = np.random.get_state()
+        n_local = EIGHT_COUNTS[rank]
+        counts, seed = sdist.gather_counts(n_local)
+        wanted, batch, _ = sdist.sample_plan(sum(counts), world)
+        rows = sdist.share_counts(counts, wanted, seed)
+        idx = sdist.sample_share(n_local, rows[rank], np.random.RandomState(100 + rank))
+        X = torch.zeros((len(idx), 3, 3, 3))
+        X[:, 0, 0, 0] = rank
+        X[:, 0, 0, 1] = torch.as_tensor(idx, dtype=torch.float32)
+        V = torch.full((len(idx), 3), float(rank))
+        Xg, Vg = sdist.all_gather_samples(X, V, rows)
+        lo, hi = sdist.shard_range(262144, rank, world)
+        avg, games = sdist.all_reduce_counters([float(rank + 1)] * 6, hi - lo, "cpu")
+        state1 = np.random.get_state()
+        untouched = state0[0] == state1[0] and np.array_equal(state0[1], state1[1]) and state0[2:] == state1[2:]
+        torch.save(dict(counts=counts, seed=seed, wanted=wanted, batch=batch, rows=rows, Xg=Xg, Vg=Vg, avg=avg, games=games,
+                        untouched=untouched), os.path.join(out_dir, f"e{rank}.pt"))
+
+        class Alice:                       # rank 5 played games that recorded nothing
+            records = [0] * (0 if rank == 5 else 40 + rank)
+            values = records
+        try:
+            AlphaSnakeZeroTrainer(8, 8, 8, 1e-3, 0.98)._collect(Alice())
+            what = "returned"
+        except RuntimeError as e:
+            what = str(e)
+        open(os.path.join(out_dir, f"c{rank}.txt"), "w").write(what)
+        # the fit over 8 ranks: batch-norm sums and gradients all-reduced; 19 rows in batches of 8 -> a trailing batch of 3 rows,
+        # fewer than ranks (five ranks join that step's all-reduces with sums over no rows)
+        ws = glorot_uniform_weights((5, 5, 3), blocks=1, seed=0)
+        rs = np.random.RandomState(3)
+        Xf = rs.rand(19, 5, 5, 3).astype(np.float32); Yf = np.tanh(rs.randn(19, 3)).astype(np.float32)
+        out = trainer_torch.fit(ws, (5, 5, 3), Xf, Yf, epochs=2, batch_size=8, lr_schedule=([100], [1e-3, 0.0]), device="cpu", seed=0,
+                                verbose=False, dtype=torch.float64)
+        np.savez(os.path.join(out_dir, f"f{rank}.npz"), *out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_rehearsal_over_gloo(tmp_path):
+    """no 8-GPU node has ever run this code, so the N = 8 path is rehearsed on the CPU: 8 ranks over gloo,
+    uneven shards (three ranks below their share of 1 280 rows, one holding a single record): every rank computes the same split,
+    10 240 distinct rows arrive rank-major on every rank, the counters average over all 262 144 games, the caller's NumPy
+    stream is left alone; a rank without records fails on all eight ranks alike; the data-parallel fit (batch-norm sums and
+    gradients all-reduced, a trailing batch smaller than the world) ends with the one-process fit's weights on every rank.
+    The exchange being rehearsed: alpha_snake_zero_trainer.py:63-75."""
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [p for p in (repo, os.path.join(repo, "alphasnake-zero_amd")) if p not in sys.path]
+    world, port = 8, _free_port()
+    mp.spawn(_eight_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f"e{r}.pt", weights_only=False) for r in range(world)]
+    share = 10240 // 8
+    for r in res:
+        assert r["counts"] == EIGHT_COUNTS and (r["wanted"], r["batch"]) == (10240, 2048)
+        assert r["rows"] == res[0]["rows"] and r["seed"] == res[0]["seed"] and sum(r["rows"]) == 10240
+        assert [r["rows"][i] for i in (1, 3, 5)] == [10, 700, 1]                       # short ranks give all they have
+        assert all(share <= r["rows"][i] <= EIGHT_COUNTS[i] for i in (0, 2, 4, 6, 7))   # the others make up the difference
+        assert r["untouched"], "the exchange drew from the caller's global NumPy stream"
+        Xg, Vg = r["Xg"], r["Vg"]
+        assert Xg.shape == (10240, 3, 3, 3) and Vg.shape == (10240, 3)
+        tags = {(int(a), int(b)) for a, b in zip(Xg[:, 0, 0, 0].tolist(), Xg[:, 0, 0, 1].tolist())}
+        assert len(tags) == 10240, "a row was used twice"
+        owners = Xg[:, 0, 0, 0].to(torch.int64)
+        assert torch.equal(owners, torch.repeat_interleave(torch.arange(8), torch.tensor(r["rows"])))     # rank-major
+        assert torch.equal(Vg[:, 0].to(torch.int64), owners)
+        assert r["games"] == 262144 and np.allclose(r["avg"], [sum(range(1, 9)) / 262144.0] * 6)
+        assert torch.equal(Xg, res[0]["Xg"])
+    for r in range(world):
+        assert "1 of 8 ranks recorded no state" in open(tmp_path / f"c{r}.txt").read()
+    got = [[z[k] for k in z.files] for z in (np.load(tmp_path / f"f{r}.npz") for r in range(world))]
+    from utils import trainer_torch
+    from snake_engine.net import glorot_uniform_weights
+    ws = glorot_uniform_weights((5, 5, 3), blocks=1, seed=0)
+    rs = np.random.RandomState(3)
+    Xf = rs.rand(19, 5, 5, 3).astype(np.float32); Yf = np.tanh(rs.randn(19, 3)).astype(np.float32)
+    one = trainer_torch.fit(ws, (5, 5, 3), Xf, Yf, epochs=2, batch_size=8, lr_schedule=([100], [1e-3, 0.0]), device="cpu", seed=0,
+                            verbose=False, dtype=torch.float64)
+    for r in range(world):
+        for a, b, c in zip(got[r], got[0], one):
+            assert np.array_equal(a, b) and np.abs(a - c).max() <= 1e-9 * max(1.0, np.abs(c).max())
+
+
 def test_shard_range_partitions_everything():
     from snake_engine.dist import shard_range, sample_share
     for total in (1, 7, 8, 4096, 262144):

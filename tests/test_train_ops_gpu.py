@@ -318,6 +318,25 @@ def test_steps_at_learning_rate_zero_are_forward_only_and_change_nothing_else(to
     assert min(moved[j] for j in (3, 4)) > 0                # moving statistics did move
 
 
+def test_a_net_without_residual_blocks_is_fitted_off_the_kernels_and_says_so(torch_gpu):
+    """stem -> head (blocks = 0; not a reference shape, alpha_nnet.py:25 builds four blocks) used to reach the batched
+    weight-image preparation with zero layers (EngineError) or, with that switched off, skip the head's sums unseen.  Such a net
+    is not a TrainStep shape: fit warns, runs on autograd and moves the weights."""
+    from snake_engine import net, train_step
+    from utils import trainer_torch
+    assert train_step.supported((21, 21, 3), 4) and not train_step.supported((21, 21, 3), 0)
+    rs = np.random.RandomState(4)
+    X = rs.rand(16, 21, 21, 3).astype(np.float32)
+    Y = np.tanh(rs.randn(16, 3)).astype(np.float32)
+    ws = net.glorot_uniform_weights((21, 21, 3), blocks=0, seed=5)
+    with pytest.warns(UserWarning, match="at least one residual block"):
+        out = trainer_torch.fit(ws, (21, 21, 3), X, Y, 2, 8, ([100], [1e-3, 0.0]), seed=11, verbose=False)
+    assert trainer_torch.fit.last_mode == "autograd"
+    assert any(np.abs(a - np.asarray(b)).max() > 0 for a, b in zip(out, ws))
+    with pytest.raises(ValueError, match="0 residual blocks"):
+        train_step.TrainStep(ws, (21, 21, 3), 8, "cuda")
+
+
 @pytest.mark.parametrize("n,blocks,hw", [(24, 2, 21), (6, 1, 37), (10, 2, 13)])
 def test_batch_norm_backward_sums_in_the_input_gradient_epilogue_change_nothing_but_rounding(torch_gpu, monkeypatch, n, blocks, hw):
     """round 5: the input-gradient convolution of layer l also takes the two sums layer l - 1's batch-norm backward starts with
@@ -358,6 +377,61 @@ def test_batch_norm_backward_sums_in_the_input_gradient_epilogue_change_nothing_
         assert torch.equal(dA1[:n * hw * hw * 128], dA2[:n * hw * hw * 128])
         err = (sums - ref).abs().max().item()
         assert err <= 1e-5 * max(ref.abs().max().item(), 1e-12), (err, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("n,hw", [(5, 21), (3, 13), (2, 37)])
+def test_input_gradient_epilogue_reads_nothing_behind_the_last_image(torch_gpu, monkeypatch, n, hw):
+    """ADVICE round 5, finding 1.  The input-gradient epilogue (conv_split.hip, MODE 5 / 8) steps from row to row through the buffer
+    instructions' SGPR soffset and relies on the image's descriptor to return zero for rows past the image (hw * hw is no multiple
+    of 32 here: the last block of every image has such rows, and behind the LAST image lies whatever the allocator put there).
+    LLVM documents soffset as excluded from the range check; on gfx950 it is included (tools/micro/store_hazard.hip,
+    profiles/r6_store_hazard_micro.json: 64 of 64 lanes read zero).  This pins it where it matters: every tensor the epilogue
+    reads is followed by NaN (mask bytes: all ones), the output by a sentinel -- sums and gradient are bit-identical to the run
+    on ordinary buffers, finite, and nothing is written behind the output."""
+    torch = torch_gpu
+    from snake_engine import net, train_step
+    from snake_engine._lib import lib, check
+    from snake_engine.train_step import _p
+    assert (hw * hw) % 32 != 0
+    rs = np.random.RandomState(7 * n + hw)
+    X = torch.as_tensor(rs.rand(n, hw, hw, 3).astype(np.float32), device="cuda")
+    Y = torch.as_tensor(np.tanh(rs.randn(n, 3)).astype(np.float32), device="cuda")
+    ws = net.glorot_uniform_weights((hw, hw, 3), blocks=2, seed=4)
+    monkeypatch.setattr(train_step, "_DEFER_BN", False)
+    ts = train_step.TrainStep(ws, (hw, hw, 3), n, "cuda")          # n == max_rows: nothing of the step's own lies behind image n - 1
+    ts.forward(X, Y, n)
+    ts.backward(Y, n)
+    L, st = lib(), torch.cuda.current_stream().cuda_stream
+    act, l = n * hw * hw * 128, 2
+    slack = 64 * 128                                                # 64 rows: more than any block reaches past its image
+
+    def padded(t, count, fill):
+        buf = torch.full((count + (slack if t.dtype != torch.uint8 else slack // 4),), fill, dtype=t.dtype, device="cuda")
+        buf[:count] = t.reshape(-1)[:count]
+        return buf
+    nan = float("nan")
+    dY, res = padded(ts.dY, act, nan), padded(ts.gres, act, nan)
+    y, mask = padded(ts.y[l - 1], act, nan), padded(ts.relu_mask[l - 1], act // 4, 255)
+    rmask = padded(ts.relu_mask[l], act // 4, 255)
+    for masked in (False, True):
+        outs = []
+        for pad in (False, True):
+            out = torch.full((act + slack,), 12345.0, device="cuda")
+            sums = torch.zeros(256, dtype=torch.float64, device="cuda")
+            a = (dY, res, y, mask, rmask) if pad else (ts.dY, ts.gres, ts.y[l - 1], ts.relu_mask[l - 1], ts.relu_mask[l])
+            if masked:
+                check(L.snk_conv3x3_f16s_igrad_stats_masked_res(_p(a[0]), _p(ts.img_b), _p(a[1]), _p(a[4]), _p(out), _p(a[2]), _p(a[3]),
+                                                                _p(ts.mean[l - 1]), _p(ts.inv[l - 1]), _p(ts.cv_partials), _p(sums), n, hw, hw, st))
+            else:
+                check(L.snk_conv3x3_f16s_igrad_stats(_p(a[0]), _p(ts.img_b), _p(a[1]), _p(out), _p(a[2]), _p(a[3]), _p(ts.mean[l - 1]),
+                                                     _p(ts.inv[l - 1]), _p(ts.cv_partials), _p(sums), n, hw, hw, st))
+            torch.cuda.synchronize()
+            outs.append((out.clone(), sums.clone()))
+        (o0, s0), (o1, s1) = outs
+        assert torch.isfinite(s1).all() and torch.isfinite(o1[:act]).all()
+        assert torch.equal(o0[:act], o1[:act]) and torch.equal(s0, s1)
+        assert (o1[act:] == 12345.0).all() and (o0[act:] == 12345.0).all(), "the epilogue stored behind the last image"
+        assert float(s1.abs().max()) > 0
 
 
 @pytest.mark.parametrize("n,blocks,hw", [(24, 2, 21), (6, 1, 37), (10, 2, 13)])
