@@ -39,3 +39,31 @@ def test_committed_traffic_profiles_with_provenance_are_well_formed():
         if "source_sha256" in d:
             assert set(d["source_sha256"]) == {"conv_split.hip", "common.h"} and all(len(v) == 64 for v in d["source_sha256"].values())
             assert d["conv_algo"] in ("f16s", "f16a", "bf16", "f16") and d["kernel_symbols"] and d["hbm_bytes_per_state_layer"] > 0
+
+
+def test_counter_profile_is_quoted_only_for_the_sources_tower_and_board_it_was_taken_on(tmp_path):
+    """round 6: roofline.counters / counters_source follow the rule of traffic / traffic_source -- SQ counters of
+    another build of csrc/conv_split.hip, another tower or another canvas are not this run's counters"""
+    import bench
+    have = {"conv_split.hip": "a" * 64, "common.h": "b" * 64}
+    kern = {"k_conv3x3_f16s<7, 1, true, 0, false>": {"dispatches": 4, "per_dispatch": {"SQ_INSTS_MFMA": 8.0e7},
+                                                     "derived": {"mfma_busy_per_busy_cycle": 25.6, "lds_conflict_share": 0.46,
+                                                                 "sq_wait_inst_any_share_of_wave_cycles": 0.58, "valu_instructions_per_mfma": 3.0}},
+            "k_f16s_wscale": {"dispatches": 1, "per_dispatch": {"SQ_INSTS_MFMA": 0.0}, "derived": {}}}
+    prof = {"source_sha256": dict(have, **{"engine.hip": "e" * 64}), "kernels": kern,
+            "note": "tools/pmc_tower.sh r6_f16s f16s 2300 11: tools/tower_only.py 2300 2 11 with SNK_CONV_ALGO=f16s (two forwards ...)"}
+    json.dump(prof, open(tmp_path / "rX_conv_f16s_sq_counters.json", "w"))
+    c, src = bench.conv_counters_profile(_Lib(have), "f16s", 11, str(tmp_path))
+    assert src.endswith("rX_conv_f16s_sq_counters.json") and list(c) == ["k_conv3x3_f16s<7, 1, true, 0, false>"]
+    row = c["k_conv3x3_f16s<7, 1, true, 0, false>"]
+    assert abs(row["mfma_busy_share"] - 0.8) < 1e-12 and row["lds_conflict_share"] == 0.46 and row["valu_per_mfma"] == 3.0
+    for lib_, algo, board in ((_Lib(dict(have, **{"conv_split.hip": "c" * 64})), "f16s", 11), (_Lib(have), "bf16", 11),
+                              (_Lib(have), "f16s", 19), (_Lib({}), "f16s", 11)):
+        c, why = bench.conv_counters_profile(lib_, algo, board, str(tmp_path))
+        assert c is None and "no SQ-counter profile" in why
+    # round 5's file (pmc_a16.sh's note: "... tower_only.py 500 2 19 with SNK_CONV_ALGO=bf16 ...") is found for the bf16 tower at 19
+    prof19 = dict(prof, note="tools/pmc_a16.sh r5_bf16: tools/tower_only.py 500 2 19 with SNK_CONV_ALGO=bf16 (two forwards ...)",
+                  kernels={"k_conv3x3_f16s<8, 1, false, 3, true>": kern["k_conv3x3_f16s<7, 1, true, 0, false>"]})
+    json.dump(prof19, open(tmp_path / "rY_a16_sq_counters.json", "w"))
+    c, src = bench.conv_counters_profile(_Lib(have), "bf16", 19, str(tmp_path))
+    assert src.endswith("rY_a16_sq_counters.json") and list(c) == ["k_conv3x3_f16s<8, 1, false, 3, true>"]

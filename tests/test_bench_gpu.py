@@ -84,6 +84,33 @@ def test_bench_gpus_2_launches_its_own_ranks():
     assert d["config"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
+def test_bench_five_ranks_share_one_gpu_over_gloo():
+    """the launcher's N-rank path beyond two ranks, rehearsed on the one GPU there is.  The pool's process
+    guard allows six processes on a card (this pytest process is one of them), so N = 5 here; the 8-rank exchange and fit run over
+    gloo on the CPU (tests/test_dist_cpu.py::test_eight_rank_rehearsal_over_gloo).  Checked: one row per rank, every rank's env-steps,
+    the per-rank thread cap (usable cpus // ranks), value = sum of env-steps / the slowest rank's wall, equal shares of the exchange."""
+    import torch
+    if torch.cuda.device_count() >= 5:
+        pytest.skip("five GPUs present: this rehearsal is for boxes where ranks must share a card")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "5", "--games", "16", "--breadth", "8",
+                          "--steps", "2", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 5 and d["config"]["parallelism"] == "games sharded x5" and d["config"]["dist_backend"] == "gloo"
+    assert [r["rank"] for r in d["ranks"]] == [0, 1, 2, 3, 4]
+    threads = d["config"]["host_threads_per_rank"]
+    assert threads >= 1 and all(r["host_threads"] == threads for r in d["ranks"])
+    for r in d["ranks"]:
+        assert r["env_steps"] == 32 and r["records"] == 192 and r["net_evals"] > 0 and 0 < r["self_play_s"] <= r["wall_s"]
+    assert abs(d["value"] - sum(r["env_steps"] for r in d["ranks"]) / max(r["wall_s"] for r in d["ranks"])) / d["value"] < 0.05
+    # 5 x 192 records < one batch of 2 048: every record is sampled, 192 from each rank
+    assert d["config"]["sample_rows_gathered"] == 960 and d["exchange"]["rows_per_rank"] == 192
+    assert "cpu_baseline" not in d
+
+
 def test_one_rank_under_the_launcher_is_the_plain_line():
     """N = 1 started the way the driver starts N > 1 (python -m torch.distributed.run) describes the same workload as the plain run"""
     import socket
