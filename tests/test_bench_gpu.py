@@ -103,11 +103,12 @@ def test_bench_five_ranks_share_one_gpu_over_gloo():
     assert [r["rank"] for r in d["ranks"]] == [0, 1, 2, 3, 4]
     threads = d["config"]["host_threads_per_rank"]
     assert threads >= 1 and all(r["host_threads"] == threads for r in d["ranks"])
-    for r in d["ranks"]:
-        assert r["env_steps"] == 32 and r["records"] == 192 and r["net_evals"] > 0 and 0 < r["self_play_s"] <= r["wall_s"]
+    for r in d["ranks"]:            # 2 timed turns x 16 games; (1 + 2) turns x 16 games x <= 4 snakes recorded (a snake may die early)
+        assert 28 <= r["env_steps"] <= 32 and 160 <= r["records"] <= 192 and r["net_evals"] > 0 and 0 < r["self_play_s"] <= r["wall_s"]
     assert abs(d["value"] - sum(r["env_steps"] for r in d["ranks"]) / max(r["wall_s"] for r in d["ranks"])) / d["value"] < 0.05
-    # 5 x 192 records < one batch of 2 048: every record is sampled, 192 from each rank
-    assert d["config"]["sample_rows_gathered"] == 960 and d["exchange"]["rows_per_rank"] == 192
+    # fewer records than one batch of 2 048: every record is sampled (trainer.py:63-72), a whole number of rows per rank
+    total = sum(r["records"] for r in d["ranks"])
+    assert d["config"]["sample_rows_gathered"] == total // 5 * 5 and total // 5 <= d["exchange"]["rows_per_rank"] <= 192
     assert "cpu_baseline" not in d
 
 

@@ -136,6 +136,31 @@ __global__ void k_range(float *buf, unsigned bytes, unsigned *res)
                  : : "v"(mark), "v"(vo), "s"(rs), "s"(so2), "v"(vo_far2) : "memory");
 }
 
+// ---- a neighbour that keeps a compute unit's other pipes busy while the sequences run (second pass of main: "stress") ------------
+// one workgroup per compute unit on a stream of its own: MFMAs back to back, LDS reads and writes, global loads and 16-byte global
+// stores, for `iters` rounds -- the sequences above then issue their stores into busy vector-memory and LDS paths
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void k_stress(float4 *scratch, int iters)
+{
+    __shared__ float4 lds[1024];
+    const int t = threadIdx.x;
+    f32x16 acc = {0};
+    f16x8 a = {1, 2, 3, 4, 5, 6, 7, 8}, b = {8, 7, 6, 5, 4, 3, 2, 1};
+    float4 v = make_float4(t, 1.f, 2.f, 3.f);
+    float4 *mine = scratch + (size_t)blockIdx.x * 4096 + t;
+    for (int i = 0; i < iters; ++i) {
+        lds[(t * 5 + i) & 1023] = v;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, acc, 0, 0, 0);
+        const float4 u = lds[(t * 7 + 3 * i) & 1023];
+        const float4 g = mine[(i & 7) * 256];
+        v.x += u.y + g.z; v.y += acc[i & 15];
+        mine[((i + 3) & 7) * 256] = v;
+    }
+    if (v.x == 123.456f) scratch[0] = v;
+}
+
 struct Variant { const char *st, *gap, *ov; void (*fn)(P); int width; };
 #define VAR(ST, GAP, OV, W) {#ST, #GAP, #OV, k_##ST##_##GAP##_##OV, W},
 #define VAR_OV(ST, GAP, W) VAR(ST, GAP, m0, W) VAR(ST, GAP, m1, W) VAR(ST, GAP, m2, W) VAR(ST, GAP, m3, W) VAR(ST, GAP, p01, W) VAR(ST, GAP, p23, W)
@@ -145,7 +170,13 @@ static const Variant variants[] = {VAR_GAP(bsg4, 4) VAR_GAP(bim4, 4) VAR_GAP(bsg
 int main(int argc, char **argv)
 {
     const int reps = argc > 1 ? atoi(argv[1]) : 3;
+    const int stress = argc > 2 ? atoi(argv[2]) : 0;             // 1: every launch runs beside k_stress on another stream
     const unsigned grids[2] = {8, 2048};                         // a nearly idle chip, and every CU's store path busy
+    hipStream_t s_other;
+    float4 *scratch;
+    CK(hipStreamCreateWithFlags(&s_other, hipStreamNonBlocking));
+    CK(hipMalloc(&scratch, (size_t)256 * 4096 * sizeof(float4)));
+    CK(hipMemset(scratch, 0, (size_t)256 * 4096 * sizeof(float4)));
     float *out;
     unsigned *hist;
     const size_t max_bytes = (size_t)2048 * 256 * 16 * ROWS;
@@ -153,7 +184,7 @@ int main(int argc, char **argv)
     CK(hipMalloc(&hist, 4 * 16 * 3 * sizeof(unsigned)));
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
-    printf("{\"device\": \"%s\", \"reps\": %d, \"rows_per_thread\": %d,\n \"variants\": [\n", prop.gcnArchName, reps, ROWS);
+    printf("{\"device\": \"%s\", \"reps\": %d, \"rows_per_thread\": %d, \"stress\": %d,\n \"variants\": [\n", prop.gcnArchName, reps, ROWS, stress);
     bool first = true;
     for (const Variant &v : variants)
         for (unsigned grid : grids) {
@@ -163,6 +194,7 @@ int main(int argc, char **argv)
             for (int rep = 0; rep < reps; ++rep) {
                 CK(hipMemset(out, 0xff, (size_t)rowb * ROWS));
                 P p{out, rowb * ROWS, rowb};
+                if (stress) hipLaunchKernelGGL(k_stress, dim3(256), dim3(256), 0, s_other, scratch, 600);      // ~100 us beside it
                 hipLaunchKernelGGL(v.fn, dim3(grid), dim3(256), 0, 0, p);
                 hipLaunchKernelGGL(k_check, dim3(grid), dim3(256), 0, 0, out, nthreads, rowb, v.width, hist);
             }
