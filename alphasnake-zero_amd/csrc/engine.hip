@@ -71,8 +71,17 @@ __device__ static inline int row_share16(int v, int o)
 
 // per-wave LDS carve-up used by step / observe
 __host__ __device__ static inline int lds_per_wave(const Layout &L) { return L.stride + 4 * L.nc_pad + 64; }
-// k_observe: the record + two float planes (channel 0 and channel 1 values per board cell)
-__host__ __device__ static inline int lds_per_obs(const Layout &L) { return L.stride + 8 * L.nc_pad; }
+// k_observe: the record + two float planes (channel 0 and channel 1 values per board cell).  Boards of more than 255 cells (16-bit
+// ring entries: 19x19 / 8 snakes = 8 KB of rings per record) keep the rings in HBM / L2 and bring only the record's tail (meta,
+// food, counters) and the LIVE ring segments -- at most one node per cell plus the stacked tails -- to LDS (round 6: with the
+// whole record an observation took 19.8 KB of LDS, 8 wavefronts per CU; now 11.2 KB, 12): obs_rec_bytes
+__host__ __device__ static inline int obs_seg_cap(const Layout &L) { return L.nc_pad + 32; }             // live nodes of all snakes
+__host__ __device__ static inline int obs_rec_bytes(const Layout &L)
+{
+    if (L.cell_bytes == 1) return L.stride;
+    return (L.stride - L.meta_off) + 32 + (2 * obs_seg_cap(L) + 15) / 16 * 16;       // record tail, 8 segment offsets, the segments
+}
+__host__ __device__ static inline int lds_per_obs(const Layout &L) { return obs_rec_bytes(L) + 8 * L.nc_pad; }
 // k_observe, NHWC planes: + a canvas of the H window rows, 3 (2W-1) H floats (+ two pieces of slack at the ends)
 __host__ __device__ static inline int lds_per_wave_win(const Layout &L)
 {
@@ -712,37 +721,67 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
     // instruction count or the HBM rate, set the time (measured: 8 192 wave slots x 5.3 KB per ~10 us lifetime).
     const int pi0 = ((blockIdx.x * WPB + wv) * GPW + gq) * reps;
     const int S = L.S, mask = L.cap_mask;
-    const int nch = L.stride / 16;
-    uint4 ahead = make_uint4(0u, 0u, 0u, 0u);             // chunk `sl` of the record of the next observation
+    constexpr bool RG = sizeof(cell_t) == 2;              // rings stay in global memory (lds_per_obs above)
+    const int roff = RG ? L.meta_off : 0;                 // first byte of the record that is staged in LDS
+    const int nch = (L.stride - roff) / 16;
+    uint4 ahead = make_uint4(0u, 0u, 0u, 0u);             // chunk `sl` of the (staged part of the) record of the next observation
     int ahead_you = 0;
     const uint8_t *ahead_src = state;
     if (pi0 < m) {
         ahead_src = state + (size_t)pairs[2 * pi0] * L.stride;
         ahead_you = pairs[2 * pi0 + 1];
-        if (sl < nch) ahead = ((const uint4 *)ahead_src)[sl];
+        if (sl < nch) ahead = ((const uint4 *)(ahead_src + roff))[sl];
     }
     for (int rep = 0; rep < reps; ++rep) {
     const int pi = pi0 + rep;
     const bool valid = pi < m;
     uint8_t *g = smem + (wv * GPW + gq) * (!planes ? lds_per_obs(L) : layout == SNK_NHWC_F32 ? lds_per_wave_win(L) : lds_per_wave_obs(L));
-    float *v1 = (float *)(g + L.stride);                    // channel 1 per board cell: 0.02 x the largest tail-distance of a node on it
+    float *v1 = (float *)(g + obs_rec_bytes(L));            // channel 1 per board cell: 0.02 x the largest tail-distance of a node on it
     float *v0 = v1 + L.nc_pad;                              // channel 0 per board cell: the head value of the snake whose head is here
+    int *seg_off = (int *)(g + (L.stride - roff));          // RG: where each snake's live segment starts in `seg`
+    cell_t *seg = (cell_t *)(g + (L.stride - roff) + 32);   // RG: the snakes' nodes tail -> head, one snake after the other
 
     const int you = ahead_you;
     const uint8_t *gsrc = ahead_src;
     if (valid && sl < nch) ((uint4 *)g)[sl] = ahead;
     if (valid)
-        for (int i = sl + GL; i < nch; i += GL) ((uint4 *)g)[i] = ((const uint4 *)gsrc)[i];
+        for (int i = sl + GL; i < nch; i += GL) ((uint4 *)g)[i] = ((const uint4 *)(gsrc + roff))[i];
     if (rep + 1 < reps && pi + 1 < m) {                     // request the next record now
         ahead_src = state + (size_t)pairs[2 * (pi + 1)] * L.stride;
         ahead_you = pairs[2 * (pi + 1) + 1];
-        if (sl < nch) ahead = ((const uint4 *)ahead_src)[sl];
+        if (sl < nch) ahead = ((const uint4 *)(ahead_src + roff))[sl];
     }
     for (int i = sl * 16; i < 8 * L.nc_pad; i += GL * 16) *(uint4 *)((uint8_t *)v1 + i) = make_uint4(0u, 0u, 0u, 0u);   // both planes
     GAME_SYNC();
 
-    const SnakeMeta *meta = (const SnakeMeta *)(g + L.meta_off);
-    const uint64_t *food = (const uint64_t *)(g + L.food_off);
+    const SnakeMeta *meta = (const SnakeMeta *)(g + L.meta_off - roff);
+    const uint64_t *food = (const uint64_t *)(g + L.food_off - roff);
+    if constexpr (RG) {
+        // the live ring segments, straight from the record in global memory (its rings are L2-resident: the snakes of a game share
+        // them) into `seg`, all snakes in ONE flattened pass so that the loads of different snakes travel together
+        int tl_[SNK_MAX_SNAKES], of_[SNK_MAX_SNAKES], total = 0;
+#pragma unroll
+        for (int s = 0; s < SNK_MAX_SNAKES; ++s) {
+            SnakeMeta ms = meta[s < S ? s : 0];
+            const int len = (valid && s < S && ms.alive) ? (int)ms.len : 0;
+            tl_[s] = ms.tail; of_[s] = total; total += len;
+        }
+        total = min(total, obs_seg_cap(L));                 // (a legal board holds at most one node per cell plus the stacked tails)
+        if (sl < SNK_MAX_SNAKES) {
+            int o = 0;
+#pragma unroll
+            for (int s = 0; s < SNK_MAX_SNAKES; ++s) o = sl == s ? of_[s] : o;
+            seg_off[sl] = o;
+        }
+        for (int idx = sl; idx < total; idx += GL) {
+            int s = 0, tl = tl_[0], of = 0;
+#pragma unroll
+            for (int q = 1; q < SNK_MAX_SNAKES; ++q)
+                if (idx >= of_[q]) { s = q; tl = tl_[q]; of = of_[q]; }     // the LAST snake that starts at or before idx (dead ones are empty)
+            seg[idx] = ((const cell_t *)(gsrc + s * L.ring_bytes))[(tl + (idx - of)) & mask];
+        }
+        GAME_SYNC();
+    }
     SnakeMeta me = meta[you];
     if (GL == 64) {
         uint2 w = *(const uint2 *)&me;
@@ -764,10 +803,13 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
         if (by_snake && (s0 > 0 || s >= S)) break;
         const SnakeMeta ms = meta[s];
         if (!ms.alive) continue;
-        const cell_t *r = (const cell_t *)(g + s * L.ring_bytes);
-        for (int k = by_snake ? sl % LPS : sl; k < ms.len; k += LPS) {
-            const int c = r[(ms.tail + k) & mask];
-            const bool last = (k == ms.len - 1) || (r[(ms.tail + k + 1) & mask] != c);
+        // node k of snake s, tail -> head: from the ring in LDS, or (RG) from the snake's segment
+        const cell_t *r = RG ? seg + seg_off[s] : (const cell_t *)(g + s * L.ring_bytes);
+        const int rt = RG ? 0 : ms.tail, rm = RG ? 0xFFFF : mask;
+        const int len_s = RG ? min((int)ms.len, obs_seg_cap(L) - seg_off[s]) : (int)ms.len;
+        for (int k = by_snake ? sl % LPS : sl; k < len_s; k += LPS) {
+            const int c = r[(rt + k) & rm];
+            const bool last = (k == ms.len - 1) || (r[(rt + k + 1) & rm] != c);
             if (last) v1[c] = (float)((double)(k + 1) * 0.02);          // float64 product, then float32 (game.py:236-241, 257)
             if (k == ms.len - 1)   // (snake.length - (you.length - 0.5)) * 0.04 in float64, then float32 (game.py:229-232,257)
                 v0[c] = (float)(((double)ms.len - ((double)me.len - 0.5)) * 0.04);
@@ -775,7 +817,8 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
     }
     GAME_SYNC();
 
-    int my_head = (int)((const cell_t *)(g + you * L.ring_bytes))[(me.tail + me.len - 1) & mask];
+    int my_head = RG ? (int)seg[max(0, min(seg_off[you] + me.len - 1, obs_seg_cap(L) - 1))]
+                     : (int)((const cell_t *)(g + you * L.ring_bytes))[(me.tail + me.len - 1) & mask];
     if (GL == 64) my_head = __builtin_amdgcn_readfirstlane(my_head);
     const int hy = my_head / WW, hx = my_head - hy * WW;
     const int k = me.dir & 3;

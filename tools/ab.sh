@@ -24,7 +24,7 @@ try:
     print('$side [$E] run $rep: %.1f %s | conv %.1f TFLOP/s | %s MHz | executed/held %s | %.1f ms/step' % (d['value'], d['unit'], r['achieved'] or 0,
           round(c['median']) if c else '-', round(r.get('executed_frac_of_held_clock_peak', 0), 3) or '-', d['ms_per_step']))
 except Exception:
-    print('$side [$E] run $rep:', last[:300])
+    print('$side [$E] run $rep:', ' | '.join(l[:200] for l in lines[-2:]))
 "
   done
 done

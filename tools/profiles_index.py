@@ -36,8 +36,12 @@ def main():
         if not isinstance(src, dict):
             rows.append((os.path.basename(path), "-", "(a bench line or log: names no sources)"))
             continue
-        state = "current" if all(src.get(f) == h for f, h in now.items() if f in src) else \
-            "older: " + ", ".join(f for f, h in now.items() if f in src and src[f] != h)
+        conv = ("conv_split.hip", "common.h")                   # what the conv profiles describe and bench.py compares
+        other = [f for f, h in now.items() if f in src and src[f] != h and f not in conv]
+        if all(src.get(f) == now[f] for f in conv if f in src):
+            state = "current" + (f" (since then changed, not a conv source: {', '.join(other)})" if other else "")
+        else:
+            state = "older: " + ", ".join(f for f in conv if f in src and src[f] != now[f])
         rows.append((os.path.basename(path), (src.get("conv_split.hip") or "-")[:10], state))
     w = max(len(r[0]) for r in rows) if rows else 10
     for r in rows:
