@@ -1327,7 +1327,7 @@ static void raw_to_canonical(const Layout &L, const uint8_t *raw, snk_game_state
     for (int q = 0; q < 6; ++q) o->counters[q] = (int32_t)cnt[q];
 }
 
-static int canonical_to_raw(const Layout &L, const snk_game_state *in, uint8_t *raw)
+static int canonical_to_raw(const Layout &L, const snk_game_state *in, uint8_t *raw, int ring_start = 0)
 {
     memset(raw, 0, (size_t)L.stride);
     if (in->H != L.H || in->W != L.W || in->S != L.S) return -1;
@@ -1341,13 +1341,14 @@ static int canonical_to_raw(const Layout &L, const snk_game_state *in, uint8_t *
         if (!in->alive[s]) continue;
         const int len = in->length[s];
         if (len < 1 || len > L.cap || len > SNK_MAX_NODES) return -2;
-        meta[s].alive = 1; meta[s].tail = 0; meta[s].len = (uint16_t)len;
+        meta[s].alive = 1; meta[s].tail = (uint16_t)(ring_start & L.cap_mask); meta[s].len = (uint16_t)len;
         meta[s].health = in->health[s]; meta[s].dir = in->dir[s];
         uint8_t *r = raw + s * L.ring_bytes;
         for (int k = 0; k < len; ++k) {
-            const int cell = in->nodes[s][len - 1 - k];                          // ring index k counts from the tail
+            const int cell = in->nodes[s][len - 1 - k];                          // ring index tail + k counts from the tail
             if (cell < 0 || cell >= L.NC) return -3;
-            if (L.cell_bytes == 1) r[k] = (uint8_t)cell; else ((uint16_t *)r)[k] = (uint16_t)cell;
+            const int at = (ring_start + k) & L.cap_mask;
+            if (L.cell_bytes == 1) r[at] = (uint8_t)cell; else ((uint16_t *)r)[at] = (uint16_t)cell;
         }
     }
     for (int c = 0; c < L.NC; ++c) if (in->food[c]) food[c >> 6] |= 1ull << (c & 63);
@@ -1376,7 +1377,20 @@ extern "C" int snk_engine_export_sync(const snk_engine *e, const int32_t *h_slot
     return 0;
 }
 
+static int engine_import(snk_engine *e, const int32_t *h_slots, int n, const snk_game_state *h_in, int ring_start);
 extern "C" int snk_engine_import_sync(snk_engine *e, const int32_t *h_slots, int n, const snk_game_state *h_in)
+{
+    return engine_import(e, h_slots, n, h_in, 0);
+}
+// the same games with every snake's ring laid out from index ring_start on (tail = ring_start mod cap): the state a long game reaches
+// -- after cap ticks a live segment straddles the ring's end -- without playing it (tests: the wrap of k_step's and k_observe's ring
+// arithmetic).  Export gives back what was imported whatever ring_start is.
+extern "C" int snk_engine_import_at_sync(snk_engine *e, const int32_t *h_slots, int n, const snk_game_state *h_in, int ring_start)
+{
+    SNK_REQUIRE(ring_start >= 0, "snk_engine_import_at_sync: ring_start %d", ring_start);
+    return engine_import(e, h_slots, n, h_in, ring_start);
+}
+static int engine_import(snk_engine *e, const int32_t *h_slots, int n, const snk_game_state *h_in, int ring_start)
 {
     SNK_REQUIRE(e != nullptr && h_in != nullptr, "snk_engine_import_sync: NULL argument");
     SNK_REQUIRE(n >= 0 && (h_slots || n <= e->n_slots), "snk_engine_import_sync: n=%d exceeds %d slots", n, e->n_slots);
@@ -1386,7 +1400,7 @@ extern "C" int snk_engine_import_sync(snk_engine *e, const int32_t *h_slots, int
     for (int i = 0; i < n; ++i) {
         const int slot = h_slots ? h_slots[i] : i;
         SNK_REQUIRE(slot >= 0 && slot < e->n_slots, "snk_engine_import_sync: slot %d out of range", slot);
-        const int rc = canonical_to_raw(L, &h_in[i], raw.data());
+        const int rc = canonical_to_raw(L, &h_in[i], raw.data(), ring_start);
         SNK_REQUIRE(rc == 0, "snk_engine_import_sync: game %d is malformed (code %d)", i, rc);
         SNK_CHECK_HIP(hipMemcpy(e->d_state + (size_t)slot * L.stride, raw.data(), (size_t)L.stride, hipMemcpyHostToDevice));
     }

@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SNK_LIB_PATH") or os.path.join(_HERE, "libsnake_engine.so")      # SNK_LIB_PATH: a variant build (A/B runs)
 
 MAX_SNAKES, MAX_CELLS, MAX_NODES = 8, 361, 384
-ABI_VERSION = 111        # SNK_ABI_VERSION of include/snake_engine.h these prototypes were written against
+ABI_VERSION = 112        # SNK_ABI_VERSION of include/snake_engine.h these prototypes were written against
 
 
 class EngineError(RuntimeError):
@@ -51,6 +51,7 @@ PROTOTYPES = {
     "snk_engine_observe": (i32, [vp, vp, i32, i32, vp, vp, vp, i32, vp]),
     "snk_engine_export_sync": (i32, [vp, vp, i32, vp]),
     "snk_engine_import_sync": (i32, [vp, vp, i32, vp]),
+    "snk_engine_import_at_sync": (i32, [vp, vp, i32, vp, i32]),
     "snk_engine_sum_counters_sync": (i32, [vp, vp, i32, vp]),
     "snk_compact_scratch_elems": (i32, [i32]),
     "snk_compact_flags": (i32, [vp, i32, vp, vp, vp, vp]),

@@ -156,10 +156,13 @@ class Engine:
         check(self.L.snk_engine_export_sync(self.h, hs.ctypes.data if hs is not None else None, n, arr))
         return arr
 
-    def import_states(self, states, slots=None):
+    def import_states(self, states, slots=None, ring_start=0):
         n = len(states)
         arr = (SnkGameState * n)(*states) if not isinstance(states, C.Array) else states
         hs = None if slots is None else np.ascontiguousarray(slots, np.int32)
+        if ring_start:          # tests: the same games with their ring buffers laid out from that index on (snk_engine_import_at_sync)
+            check(self.L.snk_engine_import_at_sync(self.h, hs.ctypes.data if hs is not None else None, n, arr, int(ring_start)))
+            return
         check(self.L.snk_engine_import_sync(self.h, hs.ctypes.data if hs is not None else None, n, arr))
 
     def sum_counters(self, slots=None, n=None):

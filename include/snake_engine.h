@@ -50,10 +50,10 @@ typedef struct {
 } snk_game_state;
 
 const char *snk_last_error(void);
-#define SNK_ABI_VERSION 111 /* 100: rounds 1-3; 110: round 5 (the gate argument d_skip of the tick kernels, round 4; the 16-bit
+#define SNK_ABI_VERSION 112 /* 100: rounds 1-3; 110: round 5 (the gate argument d_skip of the tick kernels, round 4; the 16-bit
                              * towers' own weight image and rectangle plan, round 5); 111: the training step's deferred batch
-                             * norm (fifteen entry points added, snk_conv3x3_stats_partials returns more): a caller compares it
-                             * with snk_version() */
+                             * norm (fifteen entry points added, snk_conv3x3_stats_partials returns more); 112: round 6,
+                             * snk_engine_import_at_sync added: a caller compares it with snk_version() */
 int snk_version(void);
 
 /* ---- engine lifetime -------------------------------------------------------------------
@@ -145,6 +145,10 @@ int snk_engine_observe(const snk_engine *e, const int32_t *d_pairs, int m, int l
  * Synchronous.  h_slots: host int32[n] or NULL.                                               */
 int snk_engine_export_sync(const snk_engine *e, const int32_t *h_slots, int n, snk_game_state *h_out);
 int snk_engine_import_sync(snk_engine *e, const int32_t *h_slots, int n, const snk_game_state *h_in);
+/* snk_engine_import_sync with every snake's ring buffer (Snake / Node, game.py:329-365) laid out from ring index ring_start on
+ * instead of 0: the same game as far as any entry point can tell (export returns h_in), in the memory state a game reaches after
+ * ring_start moves -- used by the tests to put live ring segments across the ring's end without playing hundreds of ticks.    */
+int snk_engine_import_at_sync(snk_engine *e, const int32_t *h_slots, int n, const snk_game_state *h_in, int ring_start);
 
 /* ---- MPGameRunner's log counters (mp_game_runner.py:54-60, 71-76) ------------------------
  * Sums the six per-game counters over the given slots into h_out[6] (int64). Synchronous.     */

@@ -587,3 +587,69 @@ def test_observe_with_several_observations_per_wavefront():
                        env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_observe_and_tick_after_the_rings_have_wrapped(se, oracle):
+    """round 6: on boards of more than 255 cells k_observe brings only the LIVE ring segments to LDS (csrc/engine.hip, RG).  A ring's
+    tail index advances with every move, so after `cap` ticks (512 at 19x19, 128 at 11x11) a live segment straddles the ring's end --
+    a memory state no golden run and no fuzzer (<= 60 ticks) reaches.  snk_engine_import_at_sync puts the same games there directly:
+    mid-game boards are exported, imported into a second engine with every ring laid out from `cap - 5` on (and from a multiple of
+    cap, and mid-ring), and then (i) every observation, mask and key equals the first engine's byte for byte, (ii) export returns
+    the same games, (iii) the same moves and spawn tape played on both engines for 12 ticks give the same states tick by tick and
+    the oracle's -- so the tick kernels' ring arithmetic wraps too.  19x19 / 8, 16x16 / 6 (16-bit cells: segments), 11x11 / 4 (8-bit:
+    the whole record in LDS)."""
+    import torch
+    from snake_engine.engine import compact_from_state
+    for hw, S, n in ((19, 8, 48), (16, 6, 48), (11, 4, 64)):
+        a = se.Engine(n, hw, hw, S, 1, 0.15, seed=777 + hw)
+        a.reset()
+        sub = torch.arange(n, dtype=torch.int32, device="cuda").repeat_interleave(S)
+        allp = torch.stack([sub, torch.arange(S, dtype=torch.int32, device="cuda").repeat(n)], dim=1).contiguous()
+        blocked = torch.empty((S * n, 3), dtype=torch.uint8, device="cuda")
+        gen = torch.Generator(device="cuda").manual_seed(11)
+
+        def steer(eng):
+            eng.observe(allp, S * n, None, blocked, None)          # a uniformly random OPEN move (straight when none is)
+            r = torch.rand((S * n, 3), device="cuda", generator=gen) - 2.0 * blocked.float()
+            mv = torch.where(blocked.bool().all(dim=1), torch.ones((), dtype=torch.int64, device="cuda"), r.argmax(dim=1))
+            return mv.to(torch.uint8).reshape(n, S).contiguous()
+        for _ in range(40):                                        # mid-game: bodies of 4-8 nodes, some snakes dead, some games over
+            a.step(steer(a))
+        states = a.export()
+        cap = 512 if hw * hw > 255 else 128
+        longest = max(int(st.length[s]) for st in states for s in range(S) if st.alive[s])
+        assert longest >= 5
+        pairs = torch.nonzero(a.alive()).to(torch.int32).contiguous()
+        pa, ma, ka = a.observe_all(pairs)
+        for start in (cap - 5, cap - 1, 3 * cap, cap // 2 + 1):
+            b = se.Engine(n, hw, hw, S, 1, 0.15, seed=1)
+            b.import_states(states, ring_start=start)
+            back = b.export()
+            for g in range(n):
+                x, y = compact_from_state(states[g]), compact_from_state(back[g])
+                assert all(np.array_equal(x[k], y[k]) for k in x), (hw, start, g)
+            pb, mb, kb = b.observe_all(pairs)
+            assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(ka, kb), (hw, start)
+            _, m2, k2 = b.observe_all(pairs, want_planes=False)     # the mask + key form (four per wavefront on the small boards)
+            assert torch.equal(m2, ma) and torch.equal(k2, ka)
+        # twelve ticks on both engines (b starts five entries before the ring's end: every live snake's head crosses it) and the oracle
+        b = se.Engine(n, hw, hw, S, 1, 0.15, seed=1)
+        b.import_states(states, ring_start=cap - 5)
+        games = [oracle.Game.from_compact(hw, hw, S, 1, 0.15, compact_from_state(states[g])) for g in range(n)]
+        spawned = a.new((n,), torch.int16, 0)
+        for t in range(12):
+            mv = steer(a)
+            a.step(mv, spawned=spawned)
+            b.step(mv, spawn_tape=spawned)
+            sp, mh = spawned.cpu().numpy(), mv.cpu().numpy()
+            ea, eb = a.export(), b.export()
+            for g in range(n):
+                if sum(games[g].g.alive[:S]) > 1:
+                    games[g].tic(mh[g], spawn_cell=int(sp[g]))
+                x, y, z = compact_from_state(ea[g]), compact_from_state(eb[g]), games[g].compact()
+                for k in x:
+                    assert np.array_equal(x[k], y[k]) and np.array_equal(x[k], z[k]), (hw, t, g, k)
+        pairs = torch.nonzero(a.alive()).to(torch.int32).contiguous()
+        pa, ma, ka = a.observe_all(pairs)
+        pb, mb, kb = b.observe_all(pairs)
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(ka, kb)
