@@ -17,7 +17,15 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """the current HIP stream's handle.  torch.cuda.current_stream() builds a Stream object through four Python layers (6.5 us per
+    call, five or six calls per rollout tick: round 6's host profile of a small run); the two C getters behind it take 0.3 us"""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 

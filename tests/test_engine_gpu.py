@@ -653,3 +653,15 @@ def test_observe_and_tick_after_the_rings_have_wrapped(se, oracle):
         pa, ma, ka = a.observe_all(pairs)
         pb, mb, kb = b.observe_all(pairs)
         assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(ka, kb)
+
+
+def test_fast_stream_getter_follows_the_current_stream(se):
+    """snake_engine.engine._stream() (two C getters instead of torch.cuda.current_stream()'s Python layers) must name the stream
+    torch considers current -- also inside a `torch.cuda.stream(...)` block, which is how QNet's second forward stream is used"""
+    import torch
+    from snake_engine.engine import _stream
+    assert _stream() == torch.cuda.current_stream().cuda_stream
+    other = torch.cuda.Stream()
+    with torch.cuda.stream(other):
+        assert _stream() == other.cuda_stream == torch.cuda.current_stream().cuda_stream
+    assert _stream() == torch.cuda.current_stream().cuda_stream != other.cuda_stream
