@@ -179,7 +179,40 @@ def engine_kernel_rooflines(se, n=32768):
         out["step_262144_games"] = big["step"]
         out["step_rollout_form_262144_games"] = big["step_rollout_form"]
         out["clone_262144_games"] = big["clone"]
+        out["observe_19x19_8_snakes"] = observe_roofline_19(se)
     return out
+
+
+def observe_roofline_19(se, n=16384):
+    """k_observe on BASELINE configs[4]'s boards (19x19, 8 snakes: 16-bit ring entries, 8 352-byte records, 16 428-byte observations),
+    planes form, mid-game boards -- the one engine kernel whose share of a configs[4] run is not negligible (5-8 % of the GPU time)"""
+    S, B = 8, 19
+    eng = se.Engine(n, B, B, S, 1, 0.15, seed=1234)
+    eng.reset()
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    sub = torch.arange(n, dtype=torch.int32, device="cuda").repeat_interleave(S)
+    all_pairs = torch.stack([sub, torch.arange(S, dtype=torch.int32, device="cuda").repeat(n)], dim=1).contiguous()
+    blocked = torch.empty((S * n, 3), dtype=torch.uint8, device="cuda")
+    for _ in range(32):
+        eng.observe(all_pairs, S * n, None, blocked, None)
+        r = torch.rand((S * n, 3), device="cuda", generator=g) - 2.0 * blocked.float()
+        mv = torch.where(blocked.bool().all(dim=1), torch.ones((), dtype=torch.int64, device="cuda"), r.argmax(dim=1))
+        eng.step(mv.to(torch.uint8).reshape(n, S).contiguous())
+    pairs = torch.nonzero(eng.alive()).to(torch.int32).contiguous()
+    m = pairs.shape[0]
+    planes = torch.empty((m, 2 * B - 1, 2 * B - 1, 3), device="cuda")
+    eng.observe(pairs, m, planes, None, None)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(10):
+        eng.observe(pairs, m, planes, None, None)
+    b.record(); torch.cuda.synchronize()
+    t = a.elapsed_time(b) * 1e-4
+    G = eng.slot_bytes
+    byts = m * (G + (2 * B - 1) ** 2 * 12)
+    return {"bound": "hbm", "achieved": byts / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": byts / t / 8e12,
+            "bytes_per_unit": G + (2 * B - 1) ** 2 * 12, "units": m, "us": t * 1e6, "form": "planes only, 19x19 / 8 snakes, 16 384 games"}
 
 
 def conv_traffic_profile(L, algo, n_rect, flops_per_launch, profiles_dir=None, board=11):

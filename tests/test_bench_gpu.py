@@ -46,7 +46,8 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert d["config"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "env-steps/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
-    for k in ("step", "clone", "observe"):
+    assert (r["counters"] is None) != str(r["counters_source"]).endswith(".json"), (r["counters"], r["counters_source"])
+    for k in ("step", "clone", "observe", "observe_19x19_8_snakes"):
         e = d["engine_kernels"][k]
         assert e["bound"] == "hbm" and e["unit"] == "GB/s" and 0 < e["frac"] < 1
 
