@@ -62,7 +62,8 @@ def test_the_rule_is_the_one_the_micro_experiment_measured():
     when the rule was written (a changed profile must change the rule knowingly)."""
     m = json.load(open(os.path.join(REPO, "profiles", "r6_store_hazard_micro.json")))
     need = {k: v["wait_states_needed"] for k, v in m["rule"].items()}
-    assert need == {"bsg4": 1, "bim4": 2, "bsg3": 1, "bsg2": 0, "gsa4": 2, "gva4": 2}
+    assert need == {"bsg4": 1, "bim4": 2, "bsg3": 1, "bsg2": 0, "gsa4": 2, "gva4": 2, "ldw4": 0, "ldw3": 0, "ldw2": 0}
+    # (ds_write_b64 / b96 / b128 were run for completeness: the LDS path interlocks, no distance stored a new value)
     assert shs.WAIT_STATES["buffer_sgpr"] == max(need["bsg4"], need["bsg3"]) + 1
     assert shs.WAIT_STATES["buffer_imm"] >= need["bim4"] and shs.WAIT_STATES["global"] >= max(need["gsa4"], need["gva4"])
     # every cell with wrong data was wrong in lanes 8..15 of a group of sixteen only (the last data-read passes), never "other" values

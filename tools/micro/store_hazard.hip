@@ -49,6 +49,20 @@ __device__ inline i32x4 make_rsrc(const void *ptr, unsigned bytes)
 #define ST_bsg2(R0, R1, R2, R3) "buffer_store_dwordx2 " VR(R0, R1) ", %[vo], %[rs], %[so] offen\n"
 #define ST_gsa4(R0, R1, R2, R3) "global_store_dwordx4 %[vo2], " VR(R0, R3) ", %[sa]\n"
 #define ST_gva4(R0, R1, R2, R3) "global_store_dwordx4 %[va], " VR(R0, R3) ", off\n"
+// LDS stores (round 6, for completeness: no hazard is documented for them; a ds_write moves its data registers to the LDS over
+// several cycles too).  The row goes to LDS and is copied out to the checker's array by ordinary code afterwards.
+#define ST_ldw4(R0, R1, R2, R3) "ds_write_b128 %[la], " VR(R0, R3) "\n"
+#define ST_ldw3(R0, R1, R2, R3) "ds_write_b96 %[la], " VR(R0, R2) "\n"
+#define ST_ldw2(R0, R1, R2, R3) "ds_write_b64 %[la], " VR(R0, R1) "\n"
+#define IS_LDS_bsg4 0
+#define IS_LDS_bim4 0
+#define IS_LDS_bsg3 0
+#define IS_LDS_bsg2 0
+#define IS_LDS_gsa4 0
+#define IS_LDS_gva4 0
+#define IS_LDS_ldw4 1
+#define IS_LDS_ldw3 1
+#define IS_LDS_ldw2 1
 
 #define GAP_d0 ""
 #define GAP_v1 "v_mov_b32 v60, v61\n"
@@ -72,7 +86,7 @@ __device__ inline i32x4 make_rsrc(const void *ptr, unsigned bytes)
                  :                                                                                                                \
                  : [o0] "v"(o0), [o1] "v"(o1), [o2] "v"(o2), [o3] "v"(o3), [n0] "v"(n0), [n1] "v"(n1), [n2] "v"(n2), [n3] "v"(n3), \
                    [np01] "v"(np01), [np23] "v"(np23), [one2] "v"(one2), [vo] "v"(vo), [vo2] "v"(vo2), [rs] "s"(rs),               \
-                   [so] "s"(so), [sa] "s"(sa), [va] "v"(va)                                                                        \
+                   [so] "s"(so), [sa] "s"(sa), [va] "v"(va), [la] "v"(la)                                                          \
                  : "memory", "v40", "v41", "v42", "v43", "v48", "v49", "v50", "v51", "v60", "v61", "v62", "v63")
 
 #define ROWS 8
@@ -82,6 +96,7 @@ __device__ inline i32x4 make_rsrc(const void *ptr, unsigned bytes)
 #define DEFK(ST, GAP, OV)                                                                                                        \
     __global__ __launch_bounds__(256) void k_##ST##_##GAP##_##OV(P p)                                                           \
     {                                                                                                                             \
+        __shared__ float4 lds_rows[IS_LDS_##ST ? 256 * ROWS : 1];          /* the block's only LDS: offset 0 */                    \
         const unsigned t = blockIdx.x * 256 + threadIdx.x;                                                                        \
         const i32x4 rs = make_rsrc(p.out, p.bytes);                                                                               \
         const unsigned long long sa = (unsigned long long)p.out;                                                                  \
@@ -91,6 +106,7 @@ __device__ inline i32x4 make_rsrc(const void *ptr, unsigned bytes)
         {                                                                                                                         \
             const unsigned so = (unsigned)r * p.rowb;                                                                             \
             const unsigned vo2 = vo + so;                                                                                         \
+            const unsigned la = ((unsigned)r * 256u + threadIdx.x) * 16u;                                                         \
             const unsigned long long va = sa + vo2;                                                                               \
             const float o0 = OLDV(t, r, 0), o1 = OLDV(t, r, 1), o2 = OLDV(t, r, 2), o3 = OLDV(t, r, 3);                           \
             const float n0 = NEWV(t, r, 0), n1 = NEWV(t, r, 1), n2 = NEWV(t, r, 2), n3 = NEWV(t, r, 3);                           \
@@ -98,11 +114,17 @@ __device__ inline i32x4 make_rsrc(const void *ptr, unsigned bytes)
             if (r & 1) ROW_ASM(ST, GAP, OV, 48, 49, 50, 51);                                                                      \
             else ROW_ASM(ST, GAP, OV, 40, 41, 42, 43);                                                                            \
         }                                                                                                                         \
+        if (IS_LDS_##ST) {                                                                                                        \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        /* the compiler does not count the asm blocks' ds_writes */   \
+            __syncthreads();                                                                                                      \
+            for (int r = 0; r < ROWS; ++r)                                                                                        \
+                *(float4 *)((char *)p.out + (size_t)r * p.rowb + (size_t)t * 16) = lds_rows[r * 256 + threadIdx.x];               \
+        }                                                                                                                         \
     }
 
 #define FOR_OV(ST, GAP) DEFK(ST, GAP, m0) DEFK(ST, GAP, m1) DEFK(ST, GAP, m2) DEFK(ST, GAP, m3) DEFK(ST, GAP, p01) DEFK(ST, GAP, p23)
 #define FOR_GAP(ST) FOR_OV(ST, d0) FOR_OV(ST, v1) FOR_OV(ST, v2) FOR_OV(ST, v3) FOR_OV(ST, v4) FOR_OV(ST, n0) FOR_OV(ST, n1) FOR_OV(ST, n2)
-FOR_GAP(bsg4) FOR_GAP(bim4) FOR_GAP(bsg3) FOR_GAP(bsg2) FOR_GAP(gsa4) FOR_GAP(gva4)
+FOR_GAP(bsg4) FOR_GAP(bim4) FOR_GAP(bsg3) FOR_GAP(bsg2) FOR_GAP(gsa4) FOR_GAP(gva4) FOR_GAP(ldw4) FOR_GAP(ldw3) FOR_GAP(ldw2)
 
 // ---- checker: class every dword; hist[k][lane & 15][class]  (class 0 = OLD, 1 = NEW, 2 = other) --------------------------------
 __global__ void k_check(const float *out, unsigned nthreads, unsigned rowb, int width, unsigned *hist)
@@ -165,7 +187,8 @@ struct Variant { const char *st, *gap, *ov; void (*fn)(P); int width; };
 #define VAR(ST, GAP, OV, W) {#ST, #GAP, #OV, k_##ST##_##GAP##_##OV, W},
 #define VAR_OV(ST, GAP, W) VAR(ST, GAP, m0, W) VAR(ST, GAP, m1, W) VAR(ST, GAP, m2, W) VAR(ST, GAP, m3, W) VAR(ST, GAP, p01, W) VAR(ST, GAP, p23, W)
 #define VAR_GAP(ST, W) VAR_OV(ST, d0, W) VAR_OV(ST, v1, W) VAR_OV(ST, v2, W) VAR_OV(ST, v3, W) VAR_OV(ST, v4, W) VAR_OV(ST, n0, W) VAR_OV(ST, n1, W) VAR_OV(ST, n2, W)
-static const Variant variants[] = {VAR_GAP(bsg4, 4) VAR_GAP(bim4, 4) VAR_GAP(bsg3, 3) VAR_GAP(bsg2, 2) VAR_GAP(gsa4, 4) VAR_GAP(gva4, 4)};
+static const Variant variants[] = {VAR_GAP(bsg4, 4) VAR_GAP(bim4, 4) VAR_GAP(bsg3, 3) VAR_GAP(bsg2, 2) VAR_GAP(gsa4, 4) VAR_GAP(gva4, 4)
+                                   VAR_GAP(ldw4, 4) VAR_GAP(ldw3, 3) VAR_GAP(ldw2, 2)};
 
 int main(int argc, char **argv)
 {

@@ -8,7 +8,8 @@ import sys
 
 GAP_WS = {"d0": 0, "v1": 1, "v2": 2, "v3": 3, "v4": 4, "n0": 1, "n1": 2, "n2": 3}
 FORMS = {"bsg4": "buffer_store_dwordx4, SGPR soffset", "bim4": "buffer_store_dwordx4, soffset 0", "bsg3": "buffer_store_dwordx3, SGPR soffset",
-         "bsg2": "buffer_store_dwordx2, SGPR soffset", "gsa4": "global_store_dwordx4, saddr", "gva4": "global_store_dwordx4, vaddr"}
+         "bsg2": "buffer_store_dwordx2, SGPR soffset", "gsa4": "global_store_dwordx4, saddr", "gva4": "global_store_dwordx4, vaddr",
+         "ldw4": "ds_write_b128", "ldw3": "ds_write_b96", "ldw2": "ds_write_b64"}
 
 
 def table_of(d):
@@ -32,6 +33,8 @@ def main():
     tables = [table_of(d) for d in runs]
     rule = {}
     for s in FORMS:
+        if not all(s in t for t in tables):
+            continue
         worst = max([g["wait_states"] for t in tables for g in t[s].values() if g["dwords_new"]] + [-1])
         rule[s] = {"form": FORMS[s], "largest_wait_states_with_wrong_data": worst if worst >= 0 else None, "wait_states_needed": worst + 1}
     out = {"what": "tools/micro/store_hazard.hip on an MI355X (gfx950), round 6: <data registers := OLD>; STORE; GAP; VALU write of data "
