@@ -703,8 +703,13 @@ template <int H, int W, int GL, int WPB>
 __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict__ state, Layout L,
                                                           const int32_t *__restrict__ pairs, int m, int layout,
                                                           float *__restrict__ planes, uint8_t *__restrict__ mask_out,
-                                                          uint64_t *__restrict__ key_out, int legacy_mask, int reps)
+                                                          uint64_t *__restrict__ key_out, int legacy_mask, int reps,
+                                                          const int32_t *__restrict__ index, const uint8_t *__restrict__ sub_active,
+                                                          uint8_t *__restrict__ row_active)
 {
+    // index (optional): output row i observes pairs[index[i]] (the rollout tick's rows to evaluate: no gathered copy of the pairs);
+    // row_active (optional, with sub_active): row_active[i] = the observing snake is alive AND sub_active[its slot] -- the tick's
+    // "which rows are live" (mp_game_runner.py:99-103) taken where the record is in hand instead of by two launches of its own
     using cell_t = typename CellT<H * W>::type;
     BOARD_DIMS(L)
     const int N = 2 * HH - 1, NPIX = N * N, NEL = NPIX * 3;
@@ -725,11 +730,13 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
     const int roff = RG ? L.meta_off : 0;                 // first byte of the record that is staged in LDS
     const int nch = (L.stride - roff) / 16;
     uint4 ahead = make_uint4(0u, 0u, 0u, 0u);             // chunk `sl` of the (staged part of the) record of the next observation
-    int ahead_you = 0;
+    int ahead_you = 0, ahead_slot = 0;
     const uint8_t *ahead_src = state;
     if (pi0 < m) {
-        ahead_src = state + (size_t)pairs[2 * pi0] * L.stride;
-        ahead_you = pairs[2 * pi0 + 1];
+        const int pr = index ? index[pi0] : pi0;
+        ahead_slot = pairs[2 * pr];
+        ahead_src = state + (size_t)ahead_slot * L.stride;
+        ahead_you = pairs[2 * pr + 1];
         if (sl < nch) ahead = ((const uint4 *)(ahead_src + roff))[sl];
     }
     for (int rep = 0; rep < reps; ++rep) {
@@ -741,14 +748,16 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
     int *seg_off = (int *)(g + (L.stride - roff));          // RG: where each snake's live segment starts in `seg`
     cell_t *seg = (cell_t *)(g + (L.stride - roff) + 32);   // RG: the snakes' nodes tail -> head, one snake after the other
 
-    const int you = ahead_you;
+    const int you = ahead_you, slot = ahead_slot;
     const uint8_t *gsrc = ahead_src;
     if (valid && sl < nch) ((uint4 *)g)[sl] = ahead;
     if (valid)
         for (int i = sl + GL; i < nch; i += GL) ((uint4 *)g)[i] = ((const uint4 *)(gsrc + roff))[i];
     if (rep + 1 < reps && pi + 1 < m) {                     // request the next record now
-        ahead_src = state + (size_t)pairs[2 * (pi + 1)] * L.stride;
-        ahead_you = pairs[2 * (pi + 1) + 1];
+        const int pr = index ? index[pi + 1] : pi + 1;
+        ahead_slot = pairs[2 * pr];
+        ahead_src = state + (size_t)ahead_slot * L.stride;
+        ahead_you = pairs[2 * pr + 1];
         if (sl < nch) ahead = ((const uint4 *)(ahead_src + roff))[sl];
     }
     for (int i = sl * 16; i < 8 * L.nc_pad; i += GL * 16) *(uint4 *)((uint8_t *)v1 + i) = make_uint4(0u, 0u, 0u, 0u);   // both planes
@@ -968,6 +977,7 @@ __global__ __launch_bounds__(WPB * 64) void k_observe(const uint8_t *__restrict_
                 }
             }
     }
+    if (row_active && valid && sl == 0) row_active[pi] = (live && sub_active[slot]) ? 1 : 0;
     if (mask_out && valid && sl < 3) {
         uint8_t b = 1;
         if (live) {
@@ -1268,8 +1278,24 @@ extern "C" int snk_engine_alive(const snk_engine *e, const int32_t *d_slots, int
     return 0;
 }
 
+static int engine_observe(const snk_engine *e, const int32_t *d_pairs, const int32_t *d_index, int m, int layout, float *d_planes,
+                          uint8_t *d_mask, uint64_t *d_key, int legacy_mask, const uint8_t *d_sub_active, uint8_t *d_row_active,
+                          void *stream);
 extern "C" int snk_engine_observe(const snk_engine *e, const int32_t *d_pairs, int m, int layout,
                                   float *d_planes, uint8_t *d_mask, uint64_t *d_key, int legacy_mask, void *stream)
+{
+    return engine_observe(e, d_pairs, nullptr, m, layout, d_planes, d_mask, d_key, legacy_mask, nullptr, nullptr, stream);
+}
+extern "C" int snk_engine_observe_rows(const snk_engine *e, const int32_t *d_pairs, const int32_t *d_index, int m, int layout,
+                                       float *d_planes, uint8_t *d_mask, uint64_t *d_key, int legacy_mask,
+                                       const uint8_t *d_sub_active, uint8_t *d_row_active, void *stream)
+{
+    SNK_REQUIRE((d_row_active == nullptr) == (d_sub_active == nullptr), "snk_engine_observe_rows: d_row_active needs d_sub_active (and the other way round)");
+    return engine_observe(e, d_pairs, d_index, m, layout, d_planes, d_mask, d_key, legacy_mask, d_sub_active, d_row_active, stream);
+}
+static int engine_observe(const snk_engine *e, const int32_t *d_pairs, const int32_t *d_index, int m, int layout, float *d_planes,
+                          uint8_t *d_mask, uint64_t *d_key, int legacy_mask, const uint8_t *d_sub_active, uint8_t *d_row_active,
+                          void *stream)
 {
     SNK_REQUIRE(e != nullptr, "snk_engine_observe: engine is NULL");
     SNK_REQUIRE(layout == SNK_NHWC_F32 || layout == SNK_NCHW_F32 || layout == SNK_NCHW_BF16, "snk_engine_observe: unknown layout %d", layout);
@@ -1283,16 +1309,16 @@ extern "C" int snk_engine_observe(const snk_engine *e, const int32_t *d_pairs, i
         constexpr int WPB = 4;
         const size_t lds = (size_t)WPB * 4 * lds_per_obs(L);
         const int grid = (m + WPB * 4 - 1) / (WPB * 4);
-        if (L.H == 11) k_observe<11, 11, 16, WPB><<<grid, WPB * 64, lds, (hipStream_t)stream>>>(e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask, 1);
-        else if (L.H == 7) k_observe<7, 7, 16, WPB><<<grid, WPB * 64, lds, (hipStream_t)stream>>>(e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask, 1);
-        else k_observe<0, 0, 16, WPB><<<grid, WPB * 64, lds, (hipStream_t)stream>>>(e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask, 1);
+        if (L.H == 11) k_observe<11, 11, 16, WPB><<<grid, WPB * 64, lds, (hipStream_t)stream>>>(e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask, 1, d_index, d_sub_active, d_row_active);
+        else if (L.H == 7) k_observe<7, 7, 16, WPB><<<grid, WPB * 64, lds, (hipStream_t)stream>>>(e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask, 1, d_index, d_sub_active, d_row_active);
+        else k_observe<0, 0, 16, WPB><<<grid, WPB * 64, lds, (hipStream_t)stream>>>(e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask, 1, d_index, d_sub_active, d_row_active);
     } else {
         const size_t lds = (size_t)WAVES_PER_BLOCK * (!d_planes ? lds_per_obs(L) : layout == SNK_NHWC_F32 ? lds_per_wave_win(L) : lds_per_wave_obs(L));
         // several observations per wavefront once the request fills the chip's wave slots (256 CUs x 32) a few times over
         static const int reps_env = getenv("SNK_OBS_REPS") ? atoi(getenv("SNK_OBS_REPS")) : 0;
         const int reps = reps_env > 0 ? reps_env : (d_planes && m >= 4 * 8192) ? 2 : 1;
         DISPATCH_BOARD(L, (k_observe<BH, BW, 64, WAVES_PER_BLOCK><<<wave_grid((m + reps - 1) / reps), BLOCK_THREADS, lds, (hipStream_t)stream>>>(
-            e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask, reps)));
+            e->d_state, L, d_pairs, m, layout, d_planes, d_mask, d_key, legacy_mask, reps, d_index, d_sub_active, d_row_active)));
     }
     SNK_CHECK_HIP(hipGetLastError());
     return 0;

@@ -49,6 +49,7 @@ PROTOTYPES = {
     "snk_engine_alive": (i32, [vp, vp, i32, vp, vp, vp]),
     "snk_engine_ids": (i32, [vp, vp, i32, vp, vp, vp, vp, vp]),
     "snk_engine_observe": (i32, [vp, vp, i32, i32, vp, vp, vp, i32, vp]),
+    "snk_engine_observe_rows": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp]),
     "snk_engine_export_sync": (i32, [vp, vp, i32, vp]),
     "snk_engine_import_sync": (i32, [vp, vp, i32, vp]),
     "snk_engine_import_at_sync": (i32, [vp, vp, i32, vp, i32]),

@@ -137,11 +137,22 @@ class Engine:
         return pairs, cnt
 
     # ---- Game.get_states + obstacle mask + transposition key ----------------------------------
-    def observe(self, pairs, m=None, planes=None, mask=None, key=None, layout=NHWC_F32, legacy_mask=False):
+    def observe(self, pairs, m=None, planes=None, mask=None, key=None, layout=NHWC_F32, legacy_mask=False, index=None,
+                sub_active=None, row_active=None):
+        """index: int32[m], row i observes pairs[index[i]]; sub_active uint8[n_slots] + row_active uint8[m]: row_active[i] = the
+        observing snake is alive and its slot is active (snk_engine_observe_rows: the rollout tick's forms)"""
         pairs = self._i32(pairs)
         m = pairs.shape[0] if m is None else m
-        check(self.L.snk_engine_observe(self.h, _ptr(pairs), m, layout, _ptr(planes), _ptr(mask), _ptr(key),
-                                        int(legacy_mask), _stream()))
+        if index is None and row_active is None:
+            check(self.L.snk_engine_observe(self.h, _ptr(pairs), m, layout, _ptr(planes), _ptr(mask), _ptr(key),
+                                            int(legacy_mask), _stream()))
+            return
+        assert index is None or (index.dtype == torch.int32 and index.is_cuda and index.is_contiguous() and index.numel() >= m)
+        assert (row_active is None) == (sub_active is None)
+        if row_active is not None:
+            assert sub_active.dtype == row_active.dtype == torch.uint8 and sub_active.is_cuda and row_active.is_cuda and row_active.numel() >= m
+        check(self.L.snk_engine_observe_rows(self.h, _ptr(pairs), _ptr(index), m, layout, _ptr(planes), _ptr(mask), _ptr(key),
+                                             int(legacy_mask), _ptr(sub_active), _ptr(row_active), _stream()))
 
     def observe_all(self, pairs, want_planes=True, want_mask=True, want_key=True, layout=NHWC_F32, legacy_mask=False):
         pairs = self._i32(pairs)

@@ -5,6 +5,7 @@ for buffers, index plumbing (gather / cumsum) and the single host read-back per 
 number of cache misses, which sizes the net batch).
 """
 import ctypes as C
+import os
 from time import time
 
 import numpy as np
@@ -14,6 +15,10 @@ from ._lib import lib, check, EngineError
 from .engine import Engine, _ptr, _stream
 
 PARALLEL = 8     # agent.py:32
+# round 6: the tick's "which rows are live" and "the rows to evaluate" ride in the observe launches that hold the records anyway
+# (snk_engine_observe_rows) instead of three launches of their own (snk_engine_alive, snk_mcts_row_active, snk_mcts_gather_rows):
+# 23 launches per tick instead of 26; SNK_MCTS_FOLD=0 keeps the separate launches (A/B runs; same rows, same results)
+_FOLD = os.environ.get("SNK_MCTS_FOLD", "1") != "0"
 
 def _pow2_at_least(v):
     p = 1024
@@ -196,9 +201,13 @@ class DeviceMCTS:
 
             def head(pp):
                 """the tick up to its read-back: which rows are live, their masks and keys, table lookup, the list of new keys"""
-                self.roll.alive(n=B, out=self.alive_rows)
-                check(L.snk_mcts_row_active(_ptr(self.alive_rows), _ptr(sub_active), B, S, _ptr(row_active), st))
-                self.roll.observe(self.pairs, m, None, self.mask, self.key, legacy_mask=self.legacy_mask)
+                if _FOLD:
+                    self.roll.observe(self.pairs, m, None, self.mask, self.key, legacy_mask=self.legacy_mask, sub_active=sub_active,
+                                      row_active=row_active)
+                else:
+                    self.roll.alive(n=B, out=self.alive_rows)
+                    check(L.snk_mcts_row_active(_ptr(self.alive_rows), _ptr(sub_active), B, S, _ptr(row_active), st))
+                    self.roll.observe(self.pairs, m, None, self.mask, self.key, legacy_mask=self.legacy_mask)
                 check(L.snk_tt_lookup_insert(tt, _ptr(self.key), _ptr(row_active), m, self.now, self.max_depth,
                                              _ptr(self.entry), _ptr(self.is_new), st))
                 check(L.snk_compact_flags(_ptr(self.is_new), m, _ptr(self.cmp_idx[pp]), _ptr(self.cmp_cnt),
@@ -210,9 +219,12 @@ class DeviceMCTS:
                 if t["n_eval"]:
                     idx = self.cmp_idx[t["pp"]][:t["n_eval"]]
                     eval_pairs, eval_mask = self.eval_pairs[:t["n_eval"]], self.eval_mask[:t["n_eval"]]
-                    check(L.snk_mcts_gather_rows(_ptr(idx), t["n_eval"], _ptr(self.pairs), _ptr(self.mask), _ptr(eval_pairs), _ptr(eval_mask), st))
                     planes = self._planes(t["n_eval"])
-                    self.roll.observe(eval_pairs, t["n_eval"], planes, None, None)
+                    if _FOLD:       # row i of the batch observes pairs[idx[i]]; its obstacle mask comes out of the same launch
+                        self.roll.observe(self.pairs, t["n_eval"], planes, eval_mask, None, legacy_mask=self.legacy_mask, index=idx)
+                    else:
+                        check(L.snk_mcts_gather_rows(_ptr(idx), t["n_eval"], _ptr(self.pairs), _ptr(self.mask), _ptr(eval_pairs), _ptr(eval_mask), st))
+                        self.roll.observe(eval_pairs, t["n_eval"], planes, None, None)
                     q = self.evaluate(planes, eval_mask)            # nnet.v(all_states) (agent.py:190)
                     check(L.snk_tt_set_priors(tt, _ptr(self.entry), _ptr(idx), t["n_eval"], _ptr(q.contiguous()), gate or None, st))
                 rank = None

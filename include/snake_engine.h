@@ -53,7 +53,7 @@ const char *snk_last_error(void);
 #define SNK_ABI_VERSION 112 /* 100: rounds 1-3; 110: round 5 (the gate argument d_skip of the tick kernels, round 4; the 16-bit
                              * towers' own weight image and rectangle plan, round 5); 111: the training step's deferred batch
                              * norm (fifteen entry points added, snk_conv3x3_stats_partials returns more); 112: round 6,
-                             * snk_engine_import_at_sync added: a caller compares it with snk_version() */
+                             * snk_engine_import_at_sync and snk_engine_observe_rows added: a caller compares it with snk_version() */
 int snk_version(void);
 
 /* ---- engine lifetime -------------------------------------------------------------------
@@ -140,6 +140,14 @@ enum { SNK_NHWC_F32 = 0, SNK_NCHW_F32 = 1, SNK_NCHW_BF16 = 2 };
 int snk_engine_observe(const snk_engine *e, const int32_t *d_pairs, int m, int layout,
                        float *d_planes, uint8_t *d_mask, uint64_t *d_key, int legacy_mask,
                        void *stream);
+/* snk_engine_observe for the rows of a rollout tick (MCTSAgent.make_moves, agent.py:161-201; MCTSMPGameRunner.run,
+ * mp_game_runner.py:99-103), two launches of bookkeeping folded into the one that holds the record anyway:
+ * d_index (optional): int32[m]; output row i observes d_pairs[d_index[i]] (the rows whose keys were new: no gathered copy).
+ * d_sub_active + d_row_active (optional, together): uint8[n_slots] / uint8[m]; d_row_active[i] = 1 when the observing snake is
+ *   alive AND d_sub_active[its slot] != 0 -- the tick's live rows (what snk_engine_alive + snk_mcts_row_active computed).      */
+int snk_engine_observe_rows(const snk_engine *e, const int32_t *d_pairs, const int32_t *d_index, int m, int layout,
+                            float *d_planes, uint8_t *d_mask, uint64_t *d_key, int legacy_mask,
+                            const uint8_t *d_sub_active, uint8_t *d_row_active, void *stream);
 
 /* ---- host views (goldens, Game.snakes / .food / .rewards accessors, Game.draw) -----------
  * Synchronous.  h_slots: host int32[n] or NULL.                                               */

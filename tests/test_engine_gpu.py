@@ -665,3 +665,54 @@ def test_fast_stream_getter_follows_the_current_stream(se):
     with torch.cuda.stream(other):
         assert _stream() == other.cuda_stream == torch.cuda.current_stream().cuda_stream
     assert _stream() == torch.cuda.current_stream().cuda_stream != other.cuda_stream
+
+
+@pytest.mark.parametrize("hw,S", [(11, 4), (19, 8), (7, 2)])
+def test_observe_rows_folds_the_ticks_bookkeeping(se, hw, S):
+    """round 6: snk_engine_observe_rows = snk_engine_observe that also (i) writes "the observing snake is alive and its sub-game is
+    active" per row -- what snk_engine_alive + snk_mcts_row_active computed in two launches -- and (ii) observes pairs[index[i]]
+    for row i -- what snk_mcts_gather_rows + a second pairs array did.  Same bytes out as the separate launches, in both kernel
+    forms (four observations per wavefront without planes on the small boards, one per wavefront with planes)."""
+    import torch
+    from snake_engine._lib import lib, check
+    from snake_engine.engine import _ptr, _stream
+    L = lib()
+    n = 96
+    eng = se.Engine(n, hw, hw, S, 1, 0.15, seed=99 + hw)
+    eng.reset()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    sub = torch.arange(n, dtype=torch.int32, device="cuda").repeat_interleave(S)
+    pairs = torch.stack([sub, torch.arange(S, dtype=torch.int32, device="cuda").repeat(n)], dim=1).contiguous()
+    blocked = torch.empty((S * n, 3), dtype=torch.uint8, device="cuda")
+    for _ in range(30):                                        # mid-game: some snakes dead, some games over
+        eng.observe(pairs, S * n, None, blocked, None)
+        r = torch.rand((S * n, 3), device="cuda", generator=g) - 2.0 * blocked.float()
+        mv = torch.where(blocked.bool().all(dim=1), torch.ones((), dtype=torch.int64, device="cuda"), r.argmax(dim=1))
+        eng.step(mv.to(torch.uint8).reshape(n, S).contiguous())
+    m = S * n
+    sub_active = (torch.rand(n, device="cuda", generator=g) < 0.7).to(torch.uint8)
+    alive = eng.alive()
+    assert 0 < int(alive.sum()) < m
+    want_rows = torch.empty(m, dtype=torch.uint8, device="cuda")
+    check(L.snk_mcts_row_active(_ptr(alive), _ptr(sub_active), n, S, _ptr(want_rows), _stream()))
+    _, mask0, key0 = eng.observe_all(pairs, want_planes=False)
+    mask1, key1 = torch.empty_like(mask0), torch.empty_like(key0)
+    rows = torch.full((m,), 7, dtype=torch.uint8, device="cuda")
+    eng.observe(pairs, m, None, mask1, key1, sub_active=sub_active, row_active=rows)
+    assert torch.equal(rows, want_rows) and torch.equal(mask1, mask0) and torch.equal(key1, key0)
+    assert 0 < int(rows.sum()) < int(alive.sum())
+    # (ii) a shuffled subset of the rows through the index, planes + mask in one launch == gather, then observe
+    idx = torch.randperm(m, device="cuda", generator=g)[: m // 3].to(torch.int32).contiguous()
+    k = idx.numel()
+    gp = torch.empty((k, 2), dtype=torch.int32, device="cuda")
+    gm = torch.empty((k, 3), dtype=torch.uint8, device="cuda")
+    check(L.snk_mcts_gather_rows(_ptr(idx), k, _ptr(pairs), _ptr(mask0), _ptr(gp), _ptr(gm), _stream()))
+    want_planes, _, want_key = eng.observe_all(gp)
+    planes = torch.full_like(want_planes, float("nan"))
+    mask2 = torch.full((k, 3), 9, dtype=torch.uint8, device="cuda")
+    key2 = torch.empty((k, 2), dtype=torch.int64, device="cuda")
+    eng.observe(pairs, k, planes, mask2, key2, index=idx)
+    assert torch.equal(planes, want_planes) and torch.equal(mask2, gm) and torch.equal(key2, want_key)
+    rows2 = torch.empty(k, dtype=torch.uint8, device="cuda")
+    eng.observe(pairs, k, None, mask2, None, index=idx, sub_active=sub_active, row_active=rows2)      # both at once
+    assert torch.equal(rows2, want_rows[idx.long()])

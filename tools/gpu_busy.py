@@ -69,7 +69,8 @@ def main():
     if "--" not in sys.argv or len(sys.argv) < 3:
         raise SystemExit(__doc__)
     cut = sys.argv.index("--")
-    prefix, bench_args = sys.argv[1], sys.argv[cut + 1:]
+    prefix, bench_args = os.path.abspath(sys.argv[1]), sys.argv[cut + 1:]        # (the child runs with cwd = /tmp)
+    os.makedirs(os.path.dirname(prefix), exist_ok=True)
     out_dir = prefix + "_trace"
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", out_dir, "--", sys.executable, os.path.join(REPO, "bench.py"),
